@@ -1,0 +1,267 @@
+"""CPU ORACLE for the EaBNet hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module, and only as the checker.  ``eabnet_amd`` never
+imports it; the product path fails loudly when the HIP library is missing.
+
+What it is: a functional (stateless, parameters-as-dict) restatement on
+PyTorch-CPU of ``prepare_data`` (reference train_distributed.py:68-95) and
+``EaBNet.forward`` (reference EaBNet.py:88-125) for the default topology
+(is_u2, lstm beam-former, mimo, cat skips, InstanceNorm, causal).  It uses the
+same ATen primitives the reference reaches (conv2d / conv_transpose2d /
+conv1d / instance_norm / prelu / layer_norm / linear) so its rounding behaviour
+is the reference's; the LSTM is spelled out step by step (gate order i,f,g,o)
+with ``fast_lstm=True`` switching to ATen's fused LSTM for the timed baseline.
+
+Parity pin: tests/test_oracle_golden.py checks this file against fixtures in
+tests/golden/*.npz that were produced by importing the reference's own
+EaBNet.py in the authoring container (tests/golden/make_golden.py).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Params = Dict[str, torch.Tensor]
+EPS_IN = 1e-5          # nn.InstanceNorm default eps (reference EaBNet.py:684-686)
+EPS_LN = 1e-5          # nn.LayerNorm default eps (reference EaBNet.py:598)
+
+
+# ----------------------------------------------------------------------------
+# STFT front end
+# ----------------------------------------------------------------------------
+def frame_index(L: int, n_fft: int, hop: int):
+    """Sample index read by (frame t, tap n) of a centred, reflect-padded STFT
+    (torch.stft(center=True, pad_mode='reflect'), reference
+    train_distributed.py:83).  Returns an int64 (T, n_fft) tensor of indices into
+    the un-padded wave; T = 1 + L // hop."""
+    pad = n_fft // 2
+    T = 1 + L // hop
+    j = torch.arange(T).unsqueeze(1) * hop + torch.arange(n_fft).unsqueeze(0) - pad
+    j = torch.where(j < 0, -j, j)                       # left reflection (no edge repeat)
+    j = torch.where(j >= L, 2 * (L - 1) - j, j)         # right reflection
+    return j
+
+
+def stft_frames(wav: torch.Tensor, n_fft: int, hop: int) -> torch.Tensor:
+    """(N, L) -> (N, T, n_fft) raw (un-windowed) frames; pure indexing."""
+    return wav[:, frame_index(wav.shape[-1], n_fft, hop)]
+
+
+def hann_periodic(n: int, dtype=torch.float32) -> torch.Tensor:
+    """The window prepare_data builds (train_distributed.py:83):
+    torch.hann_window(n), periodic, = 0.5 - 0.5 cos(2 pi k / n) evaluated in
+    fp32 by ATen (1-3 ulp away from the double-rounded formula, so the
+    product takes the window as an input instead of recomputing it)."""
+    return torch.hann_window(n, dtype=dtype)
+
+
+def stft_oracle(wav: torch.Tensor, n_fft: int, hop: int) -> torch.Tensor:
+    """(N, L) -> (N, F, T, 2); frames * periodic Hann -> one-sided rfft."""
+    fr = stft_frames(wav, n_fft, hop) * hann_periodic(n_fft, wav.dtype)
+    X = torch.fft.rfft(fr, n=n_fft, dim=-1)             # (N, T, F)
+    return torch.view_as_real(X).permute(0, 2, 1, 3).contiguous()
+
+
+def compress_oracle(X: torch.Tensor, ri_dim: int) -> torch.Tensor:
+    """sqrt-magnitude compression keeping the phase (train_distributed.py:89-92):
+    mag = |X|**0.5, phase = atan2(im, re), out = mag*(cos, sin)."""
+    re, im = X.select(ri_dim, 0), X.select(ri_dim, -1)
+    mag = torch.norm(X, dim=ri_dim) ** 0.5
+    ph = torch.atan2(im, re)
+    return torch.stack((mag * torch.cos(ph), mag * torch.sin(ph)), dim=ri_dim)
+
+
+def prepare_data_oracle(x: torch.Tensor, target: Optional[torch.Tensor], n_fft: int = 320,
+                        hop: int = 160, win: int = 320
+                        ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """x (B,M,L), target (B,1,L) -> noisy (B,T,F,M,2), target (B,2,T,F)."""
+    assert win == n_fft, "the reference always uses win_size == fft_num (320)"
+    B, M, L = x.shape
+    X = stft_oracle(x.reshape(B * M, L), n_fft, hop)               # (B*M, F, T, 2)
+    X = X.view(B, M, X.shape[1], X.shape[2], 2).permute(0, 3, 2, 1, 4)   # (B,T,F,M,2)
+    noisy = compress_oracle(X, -1).contiguous()
+    tgt = None
+    if target is not None:
+        Y = stft_oracle(target.reshape(B, L), n_fft, hop).permute(0, 3, 2, 1)   # (B,2,T,F)
+        tgt = compress_oracle(Y, 1).contiguous()
+    return noisy, tgt
+
+
+# ----------------------------------------------------------------------------
+# network blocks
+# ----------------------------------------------------------------------------
+def _in_prelu(x, P: Params, norm_prefix: str, act_prefix: str):
+    y = F.instance_norm(x, weight=P[f"{norm_prefix}.norm.weight"], bias=P[f"{norm_prefix}.norm.bias"],
+                        use_input_stats=True, eps=EPS_IN)
+    return F.prelu(y, P[f"{act_prefix}.weight"])
+
+
+def gate_conv2d(x, w, b):
+    """GateConv2d (EaBNet.py:434-460): zero-pad k_t-1 rows on top (causal),
+    strided conv to 2*C channels, first half * sigmoid(second half)."""
+    kt = w.shape[2]
+    y = F.conv2d(F.pad(x, (0, 0, kt - 1, 0)), w, b, stride=(1, 2))
+    a, g = y.chunk(2, dim=1)
+    return a * torch.sigmoid(g)
+
+
+def gate_deconv2d(x, w, b):
+    """GateConvTranspose2d (EaBNet.py:463-490, Chomp_T 617-624): transposed conv,
+    drop the LAST k_t-1 time rows, GLU."""
+    kt = w.shape[2]
+    y = F.conv_transpose2d(x, w, b, stride=(1, 2))
+    if kt > 1:
+        y = y[:, :, :-(kt - 1), :]
+    a, g = y.chunk(2, dim=1)
+    return a * torch.sigmoid(g)
+
+
+def unet_module(x, P: Params, pre: str, scale: int, is_deconv: bool, taps=None):
+    """En_unet_module.forward (EaBNet.py:372-388)."""
+    wk = f"{pre}.in_conv.0.conv.{0 if is_deconv else 1}"
+    gated = (gate_deconv2d if is_deconv else gate_conv2d)(x, P[f"{wk}.weight"], P[f"{wk}.bias"])
+    resi = _in_prelu(gated, P, f"{pre}.in_conv.1", f"{pre}.in_conv.2")
+    if taps is not None:
+        taps[f"{pre}.in_conv"] = resi
+    y = resi
+    downs: List[torch.Tensor] = []
+    for j in range(scale):
+        q = f"{pre}.enco.{j}.conv"
+        y = _in_prelu(F.conv2d(y, P[f"{q}.0.weight"], P[f"{q}.0.bias"], stride=(1, 2)), P, f"{q}.1", f"{q}.2")
+        downs.append(y)
+    for j in range(scale):
+        q = f"{pre}.deco.{j}.deconv"
+        if j > 0:
+            y = torch.cat((y, downs[-(j + 1)]), dim=1)
+        y = _in_prelu(F.conv_transpose2d(y, P[f"{q}.0.weight"], P[f"{q}.0.bias"], stride=(1, 2)),
+                      P, f"{q}.1", f"{q}.2")
+    return resi + y
+
+
+def squeezed_tcm(x, P: Params, pre: str, dilation: int, kd: int):
+    """SqueezedTCM.forward (EaBNet.py:572-578), causal branch (:551)."""
+    y = F.conv1d(x, P[f"{pre}.in_conv.weight"])
+    pad = (kd - 1) * dilation
+
+    def branch(side):
+        z = F.prelu(y, P[f"{pre}.{side}.0.weight"])
+        z = F.instance_norm(z, weight=P[f"{pre}.{side}.1.norm.weight"], bias=P[f"{pre}.{side}.1.norm.bias"],
+                            use_input_stats=True, eps=EPS_IN)
+        return F.conv1d(F.pad(z, (pad, 0)), P[f"{pre}.{side}.3.weight"], dilation=dilation)
+
+    z = branch("left_conv") * torch.sigmoid(branch("right_conv"))
+    z = F.prelu(z, P[f"{pre}.out_conv.0.weight"])
+    z = F.instance_norm(z, weight=P[f"{pre}.out_conv.1.norm.weight"], bias=P[f"{pre}.out_conv.1.norm.bias"],
+                        use_input_stats=True, eps=EPS_IN)
+    return F.conv1d(z, P[f"{pre}.out_conv.2.weight"]) + x
+
+
+def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, fast: bool = False):
+    """One batch_first nn.LSTM layer with zero initial state (EaBNet.py:591-592,
+    610-611).  x: (N, T, I) -> (N, T, H).  Gate order i, f, g, o."""
+    N, T, _ = x.shape
+    H = w_hh.shape[1]
+    if fast:
+        zeros = x.new_zeros(1, N, H)
+        out, _, _ = torch._VF.lstm(x, (zeros, zeros), [w_ih, w_hh, b_ih, b_hh], True, 1, 0.0, False, False, True)
+        return out
+    pre = x @ w_ih.t() + (b_ih + b_hh)                 # (N, T, 4H)
+    h = x.new_zeros(N, H)
+    c = x.new_zeros(N, H)
+    outs = []
+    for t in range(T):
+        g = pre[:, t] + h @ w_hh.t()
+        i, f, gg, o = g.chunk(4, dim=1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        outs.append(h)
+    return torch.stack(outs, dim=1)
+
+
+def lstm_bf(e, P: Params, M: int, fast: bool = False, taps=None):
+    """LSTM_BF.forward (EaBNet.py:600-614): e (B,C,T,F) -> weights (B,T,F,M,2)."""
+    B, C, T, Fq = e.shape
+    x = F.layer_norm(e.permute(0, 3, 2, 1).contiguous(), (C,), P["bf_map.norm.weight"], P["bf_map.norm.bias"], EPS_LN)
+    x = x.view(B * Fq, T, C)
+    for name in ("rnn1", "rnn2"):
+        x = lstm_layer(x, P[f"bf_map.{name}.weight_ih_l0"], P[f"bf_map.{name}.weight_hh_l0"],
+                       P[f"bf_map.{name}.bias_ih_l0"], P[f"bf_map.{name}.bias_hh_l0"], fast)
+        if taps is not None:
+            taps[f"bf_map.{name}"] = x.view(B, Fq, T, -1)
+    x = x.view(B, Fq, T, -1).transpose(1, 2).contiguous()
+    x = F.relu(F.linear(x, P["bf_map.w_dnn.0.weight"], P["bf_map.w_dnn.0.bias"]))
+    w = F.linear(x, P["bf_map.w_dnn.2.weight"], P["bf_map.w_dnn.2.bias"])
+    return w.view(B, T, Fq, M, 2)
+
+
+def filter_and_sum(w, x):
+    """Y = sum_m W_m * X_m, complex, no conjugate (EaBNet.py:114-117).
+    w, x: (B,T,F,M,2) -> (B,2,T,F)."""
+    wr, wi = w[..., 0], w[..., 1]
+    xr, xi = x[..., 0], x[..., 1]
+    return torch.stack(((wr * xr - wi * xi).sum(-1), (wr * xi + wi * xr).sum(-1)), dim=1)
+
+
+def eabnet_forward(P: Params, inpt: torch.Tensor, p: int = 6, q: int = 3, kd: int = 5,
+                   fast_lstm: bool = False, taps: Optional[dict] = None) -> torch.Tensor:
+    """EaBNet.forward (EaBNet.py:88-117), default topology.
+    inpt (B,T,F,M,2) [or (B,T,F,2)] -> (B,2,T,F)."""
+    if inpt.ndim == 4:
+        inpt = inpt.unsqueeze(-2)
+    B, T, Fq, M, _ = inpt.shape
+    # (B,T,F,M,2) -> (B,2M,T,F), channel = ri*M + m   (EaBNet.py:96-97)
+    x = inpt.transpose(-2, -1).contiguous().view(B, T, Fq, 2 * M).permute(0, 3, 1, 2)
+
+    skips = []
+    for i in range(4):
+        x = unet_module(x, P, f"en.meta_unet_list.{i}", 4 - i, False, taps)
+        skips.append(x)
+        if taps is not None:
+            taps[f"en.{i}"] = x
+    x = gate_conv2d(x, P["en.last_conv.0.conv.1.weight"], P["en.last_conv.0.conv.1.bias"])
+    x = _in_prelu(x, P, "en.last_conv.1", "en.last_conv.2")
+    skips.append(x)
+    if taps is not None:
+        taps["en.4"] = x
+
+    C = x.shape[1]
+    x = x.transpose(-2, -1).contiguous().view(B, -1, T)           # (B, C*4, T), ch = c*4 + f
+    acc = torch.zeros_like(x)
+    for g in range(q):
+        for i in range(p):
+            x = squeezed_tcm(x, P, f"stcns.{g}.tcm_list.{i}", 2 ** i, kd)
+            if taps is not None and g == 0 and i == 0:
+                taps["stcns.0.0"] = x
+        acc = acc + x
+    x = acc.view(B, C, -1, T).transpose(-2, -1).contiguous()      # (B,C,T,4)
+    if taps is not None:
+        taps["stcns"] = x
+
+    for i in range(4):
+        x = unet_module(torch.cat((x, skips[-(i + 1)]), dim=1), P, f"de.meta_unet_list.{i}", i + 1, True, taps)
+        if taps is not None:
+            taps[f"de.{i}"] = x
+    x = gate_deconv2d(torch.cat((x, skips[0]), dim=1), P["de.last_conv.0.conv.0.weight"], P["de.last_conv.0.conv.0.bias"])
+    x = _in_prelu(x, P, "de.last_conv.1", "de.last_conv.2")
+    if taps is not None:
+        taps["de.4"] = x
+
+    w = lstm_bf(x, P, M, fast_lstm, taps)
+    if taps is not None:
+        taps["bf_w"] = w
+    return filter_and_sum(w, inpt)
+
+
+def com_mag_mse_loss(esti: torch.Tensor, label: torch.Tensor, frame_list) -> torch.Tensor:
+    """EaBNet.py:627-640 with per-utterance frame masks."""
+    B, _, T, Fq = esti.shape
+    mask = torch.zeros(B, T, Fq, dtype=esti.dtype)
+    for i, n in enumerate(frame_list):
+        mask[i, :n] = 1.0
+    mag_e, mag_l = torch.norm(esti, dim=1), torch.norm(label, dim=1)
+    l1 = (((mag_e - mag_l) ** 2) * mask).sum() / mask.sum()
+    l2 = (((esti - label) ** 2) * mask.unsqueeze(1)).sum() / (2.0 * mask.sum())
+    return 0.5 * (l1 + l2)

@@ -1,0 +1,158 @@
+"""Generate tests/golden/*.npz|json by RUNNING THE REFERENCE in the authoring
+container.  Not run by the test-suite (the reference does not exist on the GPU
+box); committed so the fixtures can be regenerated and audited.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+* Network fixtures import the reference's own ``EaBNet`` class
+  (/root/reference/EaBNet.py), load parameters from paramgen.py (key-seeded,
+  reference-free) with ``strict=True`` and record outputs + hook taps.
+* ``train_distributed.py`` cannot be imported here (torchaudio, tensorboard,
+  ... are absent: SURVEY §8c), so the STFT fixtures call ``torch.stft`` with
+  the arguments ``prepare_data`` passes (train_distributed.py:83-92) and apply
+  the same norm/atan2/cos/sin compression.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+sys.path.insert(0, "/root/reference")
+
+from EaBNet import EaBNet as RefEaBNet, com_mag_mse_loss as ref_loss  # noqa: E402  (reference)
+import paramgen  # noqa: E402
+from eabnet_amd.spec import NetConfig, param_specs  # noqa: E402
+
+torch.set_num_threads(8)
+N_FFT, HOP = 320, 160
+
+
+def ref_model(M: int, seed: int):
+    specs = param_specs(NetConfig(M=M))
+    net = RefEaBNet(M=M).eval()
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(specs.keys()), "key order/name mismatch vs reference"
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(specs[k].shape), (k, v.shape, specs[k].shape)
+    params = paramgen.make_params(specs, seed)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    return net, specs
+
+
+def ref_prepare(x: torch.Tensor, target: torch.Tensor):
+    """torch.stft with prepare_data's arguments + its compression."""
+    B, M, L = x.shape
+    win = torch.hann_window(N_FFT)
+    ns = torch.stft(x.contiguous().view(B * M, -1), N_FFT, HOP, N_FFT, win, return_complex=False)
+    ts = torch.stft(target.squeeze(1), N_FFT, HOP, N_FFT, win, return_complex=False)
+    _, Fq, T, _ = ns.shape
+    ns = ns.view(B, M, Fq, T, -1).permute(0, 3, 2, 1, 4)
+    ts = ts.permute(0, 3, 2, 1)
+    nmag, nph = torch.norm(ns, dim=-1) ** 0.5, torch.atan2(ns[..., -1], ns[..., 0])
+    tmag, tph = torch.norm(ts, dim=1) ** 0.5, torch.atan2(ts[:, -1, ...], ts[:, 0, ...])
+    ns = torch.stack((nmag * torch.cos(nph), nmag * torch.sin(nph)), dim=-1)
+    ts = torch.stack((tmag * torch.cos(tph), tmag * torch.sin(tph)), dim=1)
+    return ns.contiguous(), ts.contiguous()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f"{name}: {os.path.getsize(path) / 1e3:.0f} kB")
+
+
+def main():
+    # -- state-dict inventory ------------------------------------------------
+    for M in (8, 9):
+        sd = RefEaBNet(M=M).state_dict()
+        with open(os.path.join(HERE, f"keys_M{M}.json"), "w") as f:
+            json.dump([[k, list(v.shape)] for k, v in sd.items()], f)
+
+    # -- STFT front end --------------------------------------------------------
+    for (B, M, L, seed) in ((1, 2, 1600, 0), (2, 8, 4000, 1), (1, 3, 2085, 2)):
+        x = torch.from_numpy(paramgen.make_wave(B, M, L, seed))
+        tgt = x[:, :1].clone()
+        with torch.no_grad():
+            ns, ts = ref_prepare(x, tgt)
+        save(f"stft_B{B}_M{M}_L{L}.npz", noisy=ns.numpy(), target=ts.numpy(), seed=seed)
+    # zero-signal bins must map to exactly 0 (atan2(0,0)=0, mag 0)
+    x = torch.from_numpy(paramgen.make_wave(1, 2, 1600, 3)); x[:, 1] = 0.0
+    with torch.no_grad():
+        ns, _ = ref_prepare(x, x[:, :1])
+    save("stft_zero_mic.npz", noisy=ns.numpy(), seed=3)
+
+    # -- network, with taps ------------------------------------------------------
+    net8, _ = ref_model(8, seed=100)
+    taps = {}
+
+    def hook(name):
+        def fn(_m, _i, o):
+            taps[name] = (o[0] if isinstance(o, tuple) else o).detach().numpy()
+        return fn
+    hs = []
+    for i in range(4):
+        hs.append(net8.en.meta_unet_list[i].register_forward_hook(hook(f"en.{i}")))
+        hs.append(net8.en.meta_unet_list[i].in_conv.register_forward_hook(hook(f"en.meta_unet_list.{i}.in_conv")))
+        hs.append(net8.de.meta_unet_list[i].register_forward_hook(hook(f"de.{i}")))
+    hs.append(net8.en.last_conv.register_forward_hook(hook("en.4")))
+    hs.append(net8.de.last_conv.register_forward_hook(hook("de.4")))
+    hs.append(net8.stcns[0].tcm_list[0].register_forward_hook(hook("stcns.0.0")))
+    hs.append(net8.bf_map.register_forward_hook(hook("bf_w")))
+    hs.append(net8.bf_map.rnn1.register_forward_hook(hook("rnn1")))
+    hs.append(net8.bf_map.rnn2.register_forward_hook(hook("rnn2")))
+    x = torch.from_numpy(paramgen.make_spec_input(1, 12, 161, 8, seed=7))
+    with torch.no_grad():
+        y = net8(x)
+    for h in hs:
+        h.remove()
+    save("e2e_M8_B1_T12_taps.npz", out=y.numpy(), param_seed=100, input_seed=7,
+         **{"tap/" + k: v for k, v in taps.items()})
+
+    # -- network, batch 2, ragged loss --------------------------------------------
+    x = torch.from_numpy(paramgen.make_spec_input(2, 20, 161, 8, seed=8))
+    with torch.no_grad():
+        y = net8(x)
+        label = torch.from_numpy(paramgen.make_spec_input(2, 20, 161, 1, seed=9)[..., 0, :]).permute(0, 3, 1, 2).contiguous()
+        loss_full = ref_loss(y, label, [20, 20])
+        # the reference pads masks to the longest entry, so keep one entry at T
+        loss_ragged = ref_loss(y, label, [20, 13])
+    save("e2e_M8_B2_T20.npz", out=y.numpy(), param_seed=100, input_seed=8, label_seed=9,
+         loss_full=loss_full.numpy(), loss_ragged=loss_ragged.numpy())
+
+    # -- 4-D input (B,T,F,2) == single mic (EaBNet.py:93-94) and odd mic count -------
+    net1, _ = ref_model(1, seed=101)
+    x = torch.from_numpy(paramgen.make_spec_input(1, 10, 161, 1, seed=10))
+    with torch.no_grad():
+        y5 = net1(x)
+        y4 = net1(x[..., 0, :])
+    assert torch.equal(y4, y5)
+    save("e2e_M1_B1_T10.npz", out=y5.numpy(), param_seed=101, input_seed=10)
+    net9, _ = ref_model(9, seed=102)
+    x = torch.from_numpy(paramgen.make_spec_input(1, 10, 161, 9, seed=11))
+    with torch.no_grad():
+        y = net9(x)
+    save("e2e_M9_B1_T10.npz", out=y.numpy(), param_seed=102, input_seed=11)
+
+    # -- full C1 size: wave -> prepare_data -> EaBNet (4 s, 8 mics) -----------------
+    wav = torch.from_numpy(paramgen.make_wave(1, 8, 64000, seed=12))
+    with torch.no_grad():
+        ns, ts = ref_prepare(wav, wav[:, :1])
+        y = net8(ns)
+    probes_t = [0, 1, 200, 400]
+    save("c1_M8_T401.npz", out=y.numpy(), param_seed=100, wave_seed=12,
+         stft_probe_t=np.array(probes_t), stft_probe=ns[:, probes_t].numpy(),
+         stft_l2=np.float64(torch.linalg.vector_norm(ns.double()).item()),
+         target_l2=np.float64(torch.linalg.vector_norm(ts.double()).item()))
+
+
+if __name__ == "__main__":
+    with torch.no_grad():
+        main()

@@ -1,0 +1,121 @@
+"""The oracle (oracle/eabnet_oracle.py) against fixtures produced by the
+reference itself (tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import paramgen
+from eabnet_amd.spec import NetConfig, param_specs
+from oracle import eabnet_oracle as orc
+from util import GOLDEN, TOL_ORACLE, assert_close, assert_compressed_close, load, torch_params
+
+
+@pytest.mark.parametrize("M", [8, 9])
+def test_spec_matches_reference_state_dict(M):
+    ref = json.load(open(os.path.join(GOLDEN, f"keys_M{M}.json")))
+    specs = param_specs(NetConfig(M=M))
+    assert [k for k, _ in ref] == list(specs.keys())
+    for k, shape in ref:
+        assert tuple(shape) == tuple(specs[k].shape), k
+    assert len(ref) == 498
+    if M == 8:
+        assert sum(int(np.prod(s)) for _, s in ref) == 2_835_920
+
+
+@pytest.mark.parametrize("name", ["stft_B1_M2_L1600.npz", "stft_B2_M8_L4000.npz", "stft_B1_M3_L2085.npz"])
+def test_prepare_data_oracle(name):
+    g = load(name)
+    B, T, F, M, _ = g["noisy"].shape
+    L = int(name.split("_L")[1].split(".")[0])
+    x = torch.from_numpy(paramgen.make_wave(B, M, L, int(g["seed"])))
+    noisy, tgt = orc.prepare_data_oracle(x, x[:, :1])
+    assert T == 1 + L // 160 and F == 161
+    assert_compressed_close(noisy.numpy(), g["noisy"], TOL_ORACLE, "noisy")
+    assert_compressed_close(np.moveaxis(tgt.numpy(), 1, -1), np.moveaxis(g["target"], 1, -1), TOL_ORACLE, "target")
+
+
+def test_stft_frames_bit_exact_vs_torch_stft():
+    """Frame indexing must be bit-exact: un-windowed frames through a
+    rectangular-window torch.stft equal rfft of the oracle's gathered frames, and
+    the gather equals an explicit reflect pad."""
+    x = torch.from_numpy(paramgen.make_wave(1, 2, 2085, 5))[0]
+    fr = orc.stft_frames(x, 320, 160)
+    padded = torch.nn.functional.pad(x.unsqueeze(0), (160, 160), mode="reflect")[0]
+    T = 1 + 2085 // 160
+    for t in range(T):
+        assert torch.equal(fr[:, t], padded[:, t * 160:t * 160 + 320])
+    k = torch.arange(320, dtype=torch.float64)
+    assert (orc.hann_periodic(320).double() - (0.5 - 0.5 * torch.cos(2 * torch.pi * k / 320))).abs().max() < 3e-7
+
+
+def test_zero_mic_maps_to_zero():
+    g = load("stft_zero_mic.npz")
+    x = torch.from_numpy(paramgen.make_wave(1, 2, 1600, 3)); x[:, 1] = 0.0
+    noisy, _ = orc.prepare_data_oracle(x, None)
+    assert torch.count_nonzero(noisy[..., 1, :]) == 0
+    assert np.count_nonzero(g["noisy"][..., 1, :]) == 0
+    assert_compressed_close(noisy.numpy(), g["noisy"], TOL_ORACLE)
+
+
+def test_e2e_taps():
+    g = load("e2e_M8_B1_T12_taps.npz")
+    P = torch_params(8, int(g["param_seed"]))
+    x = torch.from_numpy(paramgen.make_spec_input(1, 12, 161, 8, int(g["input_seed"])))
+    taps = {}
+    with torch.no_grad():
+        y = orc.eabnet_forward(P, x, taps=taps)
+    for k in g.files:
+        if not k.startswith("tap/"):
+            continue
+        name = k[4:]
+        if name in ("rnn1", "rnn2"):
+            mine = taps[f"bf_map.{name}"].reshape(g[k].shape)
+        elif name == "stcns.0.0":
+            mine = taps[name]
+        else:
+            mine = taps[name]
+        assert_close(mine.numpy(), g[k], TOL_ORACLE, name)
+    assert_close(y.numpy(), g["out"], TOL_ORACLE, "out")
+
+
+def test_e2e_batch2_and_loss():
+    g = load("e2e_M8_B2_T20.npz")
+    P = torch_params(8, int(g["param_seed"]))
+    x = torch.from_numpy(paramgen.make_spec_input(2, 20, 161, 8, int(g["input_seed"])))
+    with torch.no_grad():
+        y = orc.eabnet_forward(P, x)
+        y_fast = orc.eabnet_forward(P, x, fast_lstm=True)
+    assert_close(y.numpy(), g["out"], TOL_ORACLE)
+    assert_close(y_fast.numpy(), g["out"], TOL_ORACLE)
+    label = torch.from_numpy(paramgen.make_spec_input(2, 20, 161, 1, int(g["label_seed"]))[..., 0, :]).permute(0, 3, 1, 2)
+    assert abs(float(orc.com_mag_mse_loss(y, label, [20, 20])) - float(g["loss_full"])) < 1e-5 * float(g["loss_full"])
+    assert abs(float(orc.com_mag_mse_loss(y, label, [20, 13])) - float(g["loss_ragged"])) < 1e-5 * float(g["loss_ragged"])
+
+
+@pytest.mark.parametrize("M,name", [(1, "e2e_M1_B1_T10.npz"), (9, "e2e_M9_B1_T10.npz")])
+def test_e2e_other_mic_counts(M, name):
+    g = load(name)
+    P = torch_params(M, int(g["param_seed"]))
+    x = torch.from_numpy(paramgen.make_spec_input(1, 10, 161, M, int(g["input_seed"])))
+    with torch.no_grad():
+        y = orc.eabnet_forward(P, x)
+        if M == 1:
+            assert torch.equal(orc.eabnet_forward(P, x[..., 0, :]), y)     # 4-D input path
+    assert_close(y.numpy(), g["out"], TOL_ORACLE)
+
+
+def test_c1_full_size():
+    g = load("c1_M8_T401.npz")
+    P = torch_params(8, int(g["param_seed"]))
+    wav = torch.from_numpy(paramgen.make_wave(1, 8, 64000, int(g["wave_seed"])))
+    with torch.no_grad():
+        ns, ts = orc.prepare_data_oracle(wav, wav[:, :1])
+        y = orc.eabnet_forward(P, ns, fast_lstm=True)
+    assert ns.shape == (1, 401, 161, 8, 2)
+    assert_compressed_close(ns[:, g["stft_probe_t"].tolist()].numpy(), g["stft_probe"], TOL_ORACLE)
+    assert abs(float(torch.linalg.vector_norm(ns.double())) - float(g["stft_l2"])) < 1e-6 * float(g["stft_l2"])
+    assert abs(float(torch.linalg.vector_norm(ts.double())) - float(g["target_l2"])) < 1e-6 * float(g["target_l2"])
+    assert_close(y.numpy(), g["out"], TOL_ORACLE)
