@@ -1,0 +1,15 @@
+"""eabnet_amd -- MI355X (gfx950) implementation of EaBNet's per-frame causal
+beamforming hot path behind the reference's Python call surface.
+
+    from eabnet_amd import EaBNet, prepare_data, numParams, com_mag_mse_loss
+
+Importing the package does not touch the GPU; the HIP library
+(eabnet_amd/lib/libeabnet_hip.so) is loaded on first use and its absence is an
+error, never a fallback.
+"""
+from .spec import NetConfig, param_specs  # noqa: F401
+from .model import (EaBNet, prepare_data, stft_compress, filter_and_sum, numParams,  # noqa: F401
+                    com_mag_mse_loss)
+
+__all__ = ["EaBNet", "prepare_data", "stft_compress", "filter_and_sum", "numParams", "com_mag_mse_loss",
+           "NetConfig", "param_specs"]

@@ -1,0 +1,108 @@
+// K13: complex filter-and-sum  Y = sum_m W_m * X_m  (reference EaBNet.py:114-117),
+// and K12b+K13 fused: second Linear of w_dnn + filter-and-sum (EaBNet.py:596,613-117).
+#include "common.h"
+
+// one thread per TF bin; W and X rows are M*2 contiguous floats (64 B at M=8).
+__global__ __launch_bounds__(256) void filter_sum_kernel(const float* __restrict__ w, const float* __restrict__ x,
+                                                         float* __restrict__ y, int T, int F, int M, long long bins) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < bins;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float2* wp = reinterpret_cast<const float2*>(w) + i * M;
+        const float2* xp = reinterpret_cast<const float2*>(x) + i * M;
+        float yr = 0.0f, yi = 0.0f;
+        for (int m = 0; m < M; ++m) {
+            float2 a = wp[m], c = xp[m];
+            yr += a.x * c.x - a.y * c.y;
+            yi += a.x * c.y + a.y * c.x;
+        }
+        long long f = i % F, bt = i / F, t = bt % T, b = bt / T;
+        y[((b * 2 + 0) * T + t) * F + f] = yr;
+        y[((b * 2 + 1) * T + t) * F + f] = yi;
+    }
+}
+
+extern "C" int eab_filter_sum_f32(const float* w, const float* x, float* y, int B, int T, int F, int M,
+                                  eab_stream_t stream) {
+    EAB_CHECK_ARG(w && x && y && B > 0 && T > 0 && F > 0 && M > 0);
+    long long bins = (long long)B * T * F;
+    int grid = (int)((bins + 255) / 256 < 8192 ? (bins + 255) / 256 : 8192);
+    hipLaunchKernelGGL(filter_sum_kernel, dim3(grid), dim3(256), 0, eab_stream(stream), w, x, y, T, F, M, bins);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
+// ---------------------------------------------------------------------------
+// bfw_filter_sum: 64 TF bins per workgroup.  The 64x64 activation tile and the
+// (2M)x64 weight matrix are staged in LDS; 4 lanes share a bin, lane p of the
+// quad computes mics p, p+4, ... (both re and im weights), multiplies with the
+// bin's X and the quad is reduced with two xor-shuffles.
+// ---------------------------------------------------------------------------
+#define BFW_ROWS 64
+#define BFW_K 64
+#define BFW_MAXM 32
+
+__global__ __launch_bounds__(256) void bfw_filter_sum_kernel(
+    const float* __restrict__ y1, const float* __restrict__ w2, const float* __restrict__ b2,
+    const float* __restrict__ x, float* __restrict__ out, float* __restrict__ bfw, int T, int F, int M,
+    long long bins) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* ytile = smem;                            // [BFW_ROWS][BFW_K + 4]
+    float* wl = smem + BFW_ROWS * (BFW_K + 4);      // [2M][BFW_K + 4]
+    const int tid = threadIdx.x;
+    const long long row0 = (long long)blockIdx.x * BFW_ROWS;
+    // stage weights and activations (float4, coalesced)
+    for (int e = tid; e < 2 * M * (BFW_K / 4); e += 256) {
+        int r = e / (BFW_K / 4), c4 = e % (BFW_K / 4);
+        *reinterpret_cast<f32x4*>(&wl[r * (BFW_K + 4) + c4 * 4]) =
+            *reinterpret_cast<const f32x4*>(&w2[(size_t)r * BFW_K + c4 * 4]);
+    }
+    for (int e = tid; e < BFW_ROWS * (BFW_K / 4); e += 256) {
+        int r = e / (BFW_K / 4), c4 = e % (BFW_K / 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row0 + r < bins) v = *reinterpret_cast<const f32x4*>(&y1[(size_t)(row0 + r) * BFW_K + c4 * 4]);
+        *reinterpret_cast<f32x4*>(&ytile[r * (BFW_K + 4) + c4 * 4]) = v;
+    }
+    __syncthreads();
+    const int r = tid >> 2, p = tid & 3;
+    const long long bin = row0 + r;
+    const bool valid = bin < bins;
+    const float* yr_ = &ytile[r * (BFW_K + 4)];
+    float accr = 0.0f, acci = 0.0f;
+    for (int m = p; m < M; m += 4) {
+        const float* wr_ = &wl[(2 * m) * (BFW_K + 4)];
+        const float* wi_ = &wl[(2 * m + 1) * (BFW_K + 4)];
+        float wr = b2[2 * m], wi = b2[2 * m + 1];
+#pragma unroll 4
+        for (int k = 0; k < BFW_K; k += 4) {
+            f32x4 a = *reinterpret_cast<const f32x4*>(&yr_[k]);
+            f32x4 u = *reinterpret_cast<const f32x4*>(&wr_[k]);
+            f32x4 v = *reinterpret_cast<const f32x4*>(&wi_[k]);
+            wr += a[0] * u[0] + a[1] * u[1] + a[2] * u[2] + a[3] * u[3];
+            wi += a[0] * v[0] + a[1] * v[1] + a[2] * v[2] + a[3] * v[3];
+        }
+        if (valid) {
+            float2 xv = reinterpret_cast<const float2*>(x)[bin * M + m];
+            accr += wr * xv.x - wi * xv.y;
+            acci += wr * xv.y + wi * xv.x;
+            if (bfw) reinterpret_cast<float2*>(bfw)[bin * M + m] = make_float2(wr, wi);
+        }
+    }
+    accr += __shfl_xor(accr, 1); acci += __shfl_xor(acci, 1);
+    accr += __shfl_xor(accr, 2); acci += __shfl_xor(acci, 2);
+    if (valid && p == 0) {
+        long long f = bin % F, bt = bin / F, t = bt % T, b = bt / T;
+        out[((b * 2 + 0) * T + t) * F + f] = accr;
+        out[((b * 2 + 1) * T + t) * F + f] = acci;
+    }
+}
+
+extern "C" int eab_bfw_filter_sum_f32(const float* y1, const float* w2, const float* b2, const float* x, float* out,
+                                      float* bfw, int B, int T, int F, int M, eab_stream_t stream) {
+    EAB_CHECK_ARG(y1 && w2 && b2 && x && out && B > 0 && T > 0 && F > 0 && M > 0 && M <= BFW_MAXM);
+    long long bins = (long long)B * T * F;
+    long long grid = (bins + BFW_ROWS - 1) / BFW_ROWS;
+    EAB_CHECK_ARG(grid < (1ll << 31));
+    size_t shmem = (size_t)(BFW_ROWS + 2 * M) * (BFW_K + 4) * sizeof(float);
+    hipLaunchKernelGGL(bfw_filter_sum_kernel, dim3((unsigned)grid), dim3(256), shmem, eab_stream(stream), y1, w2, b2, x,
+                       out, bfw, T, F, M, bins);
+    EAB_RETURN_LAUNCH_STATUS();
+}

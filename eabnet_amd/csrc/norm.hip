@@ -1,0 +1,105 @@
+// K8: InstanceNorm(affine) statistics finalisation and the fused
+// affine + PReLU (+ residual) apply.  Reference: nn.InstanceNorm{1,2}d
+// (EaBNet.py:684,686; eps 1e-5, biased variance, statistics over the whole
+// utterance), nn.PReLU(c), En_unet_module's residual add (EaBNet.py:386).
+#include "common.h"
+
+// grid = B * nsets, block = 256: 4 tile-slices x 64 channels per pass.
+__global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restrict__ stats, int C, int nsets,
+                                                          int stat_tiles, double inv_count, float eps,
+                                                          const float* __restrict__ gamma0,
+                                                          const float* __restrict__ beta0, float* __restrict__ xf0,
+                                                          const float* __restrict__ gamma1,
+                                                          const float* __restrict__ beta1, float* __restrict__ xf1) {
+    __shared__ double red[2][4][64];
+    const int b = blockIdx.x / nsets, s = blockIdx.x % nsets;
+    const float* gamma = s == 0 ? gamma0 : gamma1;
+    const float* beta = s == 0 ? beta0 : beta1;
+    float* xf = s == 0 ? xf0 : xf1;
+    const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + cl;
+        double sum = 0.0, sq = 0.0;
+        if (c < C) {
+            for (int t = slice; t < stat_tiles; t += 4) {
+                const float2 v =
+                    *reinterpret_cast<const float2*>(&stats[((((size_t)b * stat_tiles + t) * nsets + s) * C + c) * 2]);
+                sum += (double)v.x;
+                sq += (double)v.y;
+            }
+        }
+        red[0][slice][cl] = sum;
+        red[1][slice][cl] = sq;
+        __syncthreads();
+        if (slice == 0 && c < C) {
+            sum = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+            sq = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+            const double mean = sum * inv_count;
+            double var = sq * inv_count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const double scale = (double)gamma[c] / sqrt(var + (double)eps);
+            const double shift = (double)beta[c] - mean * scale;
+            *reinterpret_cast<float2*>(&xf[((size_t)b * C + c) * 2]) = make_float2((float)scale, (float)shift);
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int eab_in_finalize_f32(const float* stats, int B, int C, int nsets, int stat_tiles, int count, float eps,
+                                   const float* gamma0, const float* beta0, float* xf0, const float* gamma1,
+                                   const float* beta1, float* xf1, eab_stream_t stream) {
+    EAB_CHECK_ARG(stats && B > 0 && C > 0 && stat_tiles > 0 && count > 0);
+    EAB_CHECK_ARG(nsets == 1 || nsets == 2);
+    EAB_CHECK_ARG(gamma0 && beta0 && xf0);
+    EAB_CHECK_ARG(nsets == 1 || (gamma1 && beta1 && xf1));
+    hipLaunchKernelGGL(in_finalize_kernel, dim3(B * nsets), dim3(256), 0, eab_stream(stream), stats, C, nsets,
+                       stat_tiles, 1.0 / (double)count, eps, gamma0, beta0, xf0, gamma1, beta1, xf1);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
+// out = prelu(a*sa + ha) [+ prelu(b*sb + hb)], float4 per thread, grid-stride.
+__global__ __launch_bounds__(256) void norm_act_kernel(const float* __restrict__ a, const float* __restrict__ xfa,
+                                                       const float* __restrict__ sla, const float* __restrict__ bb,
+                                                       const float* __restrict__ xfb, const float* __restrict__ slb,
+                                                       float* __restrict__ out, int P, int C, long long total4) {
+    const int C4 = C >> 2;
+    const long long per_b = (long long)P * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / per_b);
+        const int c = (int)(i % C4) * 4;
+        const f32x4 va = reinterpret_cast<const f32x4*>(a)[i];
+        const float* xp = xfa + ((size_t)b * C + c) * 2;
+        const f32x4 s01 = *reinterpret_cast<const f32x4*>(xp), s23 = *reinterpret_cast<const f32x4*>(xp + 4);
+        const f32x4 sl = *reinterpret_cast<const f32x4*>(sla + c);
+        f32x4 r;
+        r[0] = eab_prelu(fmaf(va[0], s01[0], s01[1]), sl[0]);
+        r[1] = eab_prelu(fmaf(va[1], s01[2], s01[3]), sl[1]);
+        r[2] = eab_prelu(fmaf(va[2], s23[0], s23[1]), sl[2]);
+        r[3] = eab_prelu(fmaf(va[3], s23[2], s23[3]), sl[3]);
+        if (bb) {
+            const f32x4 vb = reinterpret_cast<const f32x4*>(bb)[i];
+            const float* yp = xfb + ((size_t)b * C + c) * 2;
+            const f32x4 t01 = *reinterpret_cast<const f32x4*>(yp), t23 = *reinterpret_cast<const f32x4*>(yp + 4);
+            const f32x4 tl = *reinterpret_cast<const f32x4*>(slb + c);
+            r[0] += eab_prelu(fmaf(vb[0], t01[0], t01[1]), tl[0]);
+            r[1] += eab_prelu(fmaf(vb[1], t01[2], t01[3]), tl[1]);
+            r[2] += eab_prelu(fmaf(vb[2], t23[0], t23[1]), tl[2]);
+            r[3] += eab_prelu(fmaf(vb[3], t23[2], t23[3]), tl[3]);
+        }
+        reinterpret_cast<f32x4*>(out)[i] = r;
+    }
+}
+
+extern "C" int eab_norm_act_f32(const float* a, const float* xfa, const float* slopea, const float* b,
+                                const float* xfb, const float* slopeb, float* out, int B, int P, int C,
+                                eab_stream_t stream) {
+    EAB_CHECK_ARG(a && xfa && slopea && out && B > 0 && P > 0 && C > 0 && (C % 4) == 0);
+    EAB_CHECK_ARG(b == nullptr || (xfb && slopeb));
+    const long long total4 = (long long)B * P * (C / 4);
+    long long g = (total4 + 255) / 256;
+    if (g > 256 * 8) g = 256 * 8;   // <= 8 blocks per CU, grid-stride the rest
+    hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)g), dim3(256), 0, eab_stream(stream), a, xfa, slopea, b, xfb,
+                       slopeb, out, P, C, total4);
+    EAB_RETURN_LAUNCH_STATUS();
+}

@@ -1,0 +1,60 @@
+// Program runner + ABI housekeeping.  The op list is the whole
+// EaBNet.forward (reference EaBNet.py:88-117) lowered by eabnet_amd/program.py.
+#include "common.h"
+
+extern "C" int eab_abi_version(void) { return EAB_ABI_VERSION; }
+
+extern "C" const char* eab_error_string(int code) {
+    if (code == EAB_OK) return "ok";
+    if (code == EAB_EINVAL) return "invalid argument (shape, limit or null pointer) -- nothing was launched";
+    if (code == EAB_EUNSUPPORTED) return "configuration not built into libeabnet_hip";
+    if (code >= EAB_EHIP_BASE) return hipGetErrorString((hipError_t)(code - EAB_EHIP_BASE));
+    return "unknown eabnet_hip error";
+}
+
+extern "C" int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream) {
+    EAB_CHECK_ARG(ops && n_ops >= 0);
+    for (int k = 0; k < n_ops; ++k) {
+        const eab_op& o = ops[k];
+        int rc;
+        switch (o.kind) {
+            case EAB_OP_CONV:
+                rc = eab_conv_f32(&o.conv, stream);
+                break;
+            case EAB_OP_IN_FINALIZE:
+                rc = eab_in_finalize_f32((const float*)o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.f[0],
+                                         (const float*)o.p[1], (const float*)o.p[2], (float*)o.p[3],
+                                         (const float*)o.p[4], (const float*)o.p[5], (float*)o.p[6], stream);
+                break;
+            case EAB_OP_NORM_ACT:
+                rc = eab_norm_act_f32((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
+                                      (const float*)o.p[3], (const float*)o.p[4], (const float*)o.p[5],
+                                      (float*)o.p[6], o.i[0], o.i[1], o.i[2], stream);
+                break;
+            case EAB_OP_LSTM64:
+                rc = eab_lstm64_f32((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2], o.f[0],
+                                    (const float*)o.p[3], (const float*)o.p[4], (float*)o.p[5], o.i[0], o.i[1], o.i[2],
+                                    stream);
+                break;
+            case EAB_OP_BFW_FS:
+                rc = eab_bfw_filter_sum_f32((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
+                                            (const float*)o.p[3], (float*)o.p[4], (float*)o.p[5], o.i[0], o.i[1],
+                                            o.i[2], o.i[3], stream);
+                break;
+            case EAB_OP_MEMSET0: {
+                const size_t bytes = ((size_t)(uint32_t)o.i[1] << 32) | (uint32_t)o.i[0];
+                rc = o.p[0] ? eab_hip_status(hipMemsetAsync(const_cast<void*>(o.p[0]), 0, bytes, eab_stream(stream)))
+                            : EAB_EINVAL;
+                break;
+            }
+            default:
+                rc = EAB_EINVAL;
+        }
+        if (rc != EAB_OK) return rc;
+    }
+    return EAB_OK;
+}
+
+// struct-layout handshake for the ctypes mirror (eabnet_amd/_lib.py)
+extern "C" int eab_sizeof_conv_desc(void) { return (int)sizeof(eab_conv_desc); }
+extern "C" int eab_sizeof_op(void) { return (int)sizeof(eab_op); }

@@ -1,0 +1,118 @@
+// K1+K2+K3: fused STFT front end  (reference train_distributed.py:80-92).
+//
+// One workgroup per (b, t): all M microphones of one frame, because the output
+// tensor (B,T,F,M,2) keeps the M*2 values of a TF bin contiguous -- the
+// workgroup's output is ONE contiguous F*M*2 block (coalesced stores), and the
+// twiddle pair of (bin f, sample n) is read once and used for all M mics.
+//
+// Round-1 arithmetic: direct DFT against an exact (host, fp64-rounded) twiddle
+// table; frame samples sit in LDS as [n][Mpad] so one broadcast ds_read_b128
+// feeds four mics.  The 320-point FFT (radix 4*4*4*5) that makes this kernel
+// HBM-bound is the next step for this row.
+#include "common.h"
+
+#define STFT_MAX_NFFT 512
+#define STFT_THREADS 256
+#define STFT_MC 8  // mics per pass held in registers
+
+// reflect_pad(x, P)[i] for i in [0, L + 2P): index into the un-padded wave.
+__device__ __forceinline__ int reflect_index(int i, int P, int L) {
+    int j = i - P;
+    if (j < 0) j = -j;
+    if (j >= L) j = 2 * (L - 1) - j;
+    return j;
+}
+
+__global__ __launch_bounds__(STFT_THREADS) void stft_compress_kernel(
+    const float* __restrict__ wav, const float* __restrict__ window, const float* __restrict__ twiddle,
+    float* __restrict__ out, int M, int L, int n_fft, int hop, int T, int layout) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float2* tw = reinterpret_cast<float2*>(smem);           // [n_fft] (cos, sin)
+    float* fr = smem + 2 * n_fft;                           // [n_fft][STFT_MC]
+    const int F = n_fft / 2 + 1;
+    const int b = blockIdx.x / T, t = blockIdx.x % T;
+    const int tid = threadIdx.x;
+
+    for (int k = tid; k < n_fft; k += STFT_THREADS) tw[k] = reinterpret_cast<const float2*>(twiddle)[k];
+
+    for (int m0 = 0; m0 < M; m0 += STFT_MC) {
+        __syncthreads();   // previous pass done with fr (and tw visible on first pass)
+        // gather + window: fr[n][mm] = window[n] * wav[b][m0+mm][reflect(t*hop + n)]
+        for (int e = tid; e < n_fft * STFT_MC; e += STFT_THREADS) {
+            int mm = e / n_fft, n = e - mm * n_fft;        // consecutive threads -> consecutive samples
+            float v = 0.0f;
+            if (m0 + mm < M) {
+                int j = reflect_index(t * hop + n, n_fft / 2, L);
+                v = window[n] * wav[((size_t)b * M + m0 + mm) * L + j];
+            }
+            fr[n * STFT_MC + mm] = v;
+        }
+        __syncthreads();
+        for (int f = tid; f < F; f += STFT_THREADS) {
+            float re[STFT_MC], im[STFT_MC];
+#pragma unroll
+            for (int mm = 0; mm < STFT_MC; ++mm) re[mm] = im[mm] = 0.0f;
+            int idx = 0;                                    // (f*n) mod n_fft
+            for (int n = 0; n < n_fft; ++n) {
+                float2 cs = tw[idx];
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(&fr[n * STFT_MC]);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(&fr[n * STFT_MC + 4]);
+                float x[STFT_MC] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+                for (int mm = 0; mm < STFT_MC; ++mm) {
+                    re[mm] = fmaf(x[mm], cs.x, re[mm]);     // X = sum x * exp(-i 2 pi f n / N)
+                    im[mm] = fmaf(-x[mm], cs.y, im[mm]);
+                }
+                idx += f;
+                if (idx >= n_fft) idx -= n_fft;
+            }
+#pragma unroll
+            for (int mm = 0; mm < STFT_MC; ++mm) {
+                if (m0 + mm >= M) break;
+                // sqrt-magnitude compression with the phase kept: X * |X|^-1/2, 0 -> 0
+                float mag = sqrtf(re[mm] * re[mm] + im[mm] * im[mm]);
+                float s = mag > 0.0f ? 1.0f / sqrtf(mag) : 0.0f;
+                float yr = re[mm] * s, yi = im[mm] * s;
+                if (layout == EAB_STFT_LAYOUT_BTFM2) {
+                    size_t o = ((((size_t)b * T + t) * F + f) * M + (m0 + mm)) * 2;
+                    *reinterpret_cast<float2*>(&out[o]) = make_float2(yr, yi);
+                } else {                                    // (B,2,T,F), M == 1
+                    out[(((size_t)b * 2 + 0) * T + t) * F + f] = yr;
+                    out[(((size_t)b * 2 + 1) * T + t) * F + f] = yi;
+                }
+            }
+        }
+    }
+}
+
+__global__ void stft_frames_kernel(const float* __restrict__ wav, float* __restrict__ frames, int L, int n_fft,
+                                   int hop, int T) {
+    const int n = blockIdx.x / T, t = blockIdx.x % T;
+    for (int k = threadIdx.x; k < n_fft; k += blockDim.x)
+        frames[((size_t)n * T + t) * n_fft + k] = wav[(size_t)n * L + reflect_index(t * hop + k, n_fft / 2, L)];
+}
+
+extern "C" int eab_stft_compress_f32(const float* wav, const float* window, const float* twiddle, float* out,
+                                     int B, int M, int L, int n_fft, int hop, int layout, eab_stream_t stream) {
+    EAB_CHECK_ARG(wav && window && twiddle && out);
+    EAB_CHECK_ARG(B > 0 && M > 0 && hop > 0);
+    EAB_CHECK_ARG(n_fft >= 2 && n_fft <= STFT_MAX_NFFT && (n_fft % 2) == 0);
+    EAB_CHECK_ARG(L > n_fft / 2);                           // reflect padding needs pad < L (as torch.stft)
+    EAB_CHECK_ARG(layout == EAB_STFT_LAYOUT_BTFM2 || (layout == EAB_STFT_LAYOUT_B2TF && M == 1));
+    const int T = 1 + L / hop;
+    EAB_CHECK_ARG((long long)B * T < (1ll << 31));
+    size_t shmem = (size_t)(2 * n_fft + n_fft * STFT_MC) * sizeof(float);
+    hipLaunchKernelGGL(stft_compress_kernel, dim3(B * T), dim3(STFT_THREADS), shmem, eab_stream(stream), wav,
+                       window, twiddle, out, M, L, n_fft, hop, T, layout);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int eab_stft_frames_f32(const float* wav, float* frames, int N, int L, int n_fft, int hop,
+                                   eab_stream_t stream) {
+    EAB_CHECK_ARG(wav && frames && N > 0 && hop > 0 && n_fft >= 2 && (n_fft % 2) == 0 && L > n_fft / 2);
+    const int T = 1 + L / hop;
+    EAB_CHECK_ARG((long long)N * T < (1ll << 31));
+    hipLaunchKernelGGL(stft_frames_kernel, dim3(N * T), dim3(256), 0, eab_stream(stream), wav, frames, L, n_fft, hop,
+                       T);
+    EAB_RETURN_LAUNCH_STATUS();
+}

@@ -1,0 +1,311 @@
+"""Drop-in boundary: ``EaBNet`` (reference EaBNet.py:9-125), ``prepare_data``
+(reference train_distributed.py:68-95), ``numParams`` (EaBNet.py:653-659) and
+``com_mag_mse_loss`` (EaBNet.py:627-640) with the reference's names, argument
+meaning and tensor signatures, executing on libeabnet_hip.so.
+
+The module owns ordinary ``nn.Parameter``s under the reference's state-dict
+keys (eabnet_amd/spec.py), so reference checkpoints load with
+``strict=True``.  ``forward`` lowers the network once per (B, T, parameter
+version) to an op program (eabnet_amd/program.py), binds it to device
+addresses and replays it with ONE foreign call per forward.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import program as prg
+from .spec import NetConfig, ParamSpec, param_specs
+
+
+# ----------------------------------------------------------------------------
+# parameter container with the reference's dotted names
+# ----------------------------------------------------------------------------
+class _Scope(nn.Module):
+    """Anonymous container: only exists so that ``state_dict()`` produces the
+    dotted keys of the reference's module tree."""
+
+
+def _default_init(spec: ParamSpec) -> torch.Tensor:
+    """PyTorch's default initialisers for the layer types the reference uses."""
+    t = torch.empty(spec.shape, dtype=torch.float32)
+    k = spec.kind
+    if k in ("conv_w", "convT_w", "lin_w", "bias", "lstm"):
+        a = 1.0 / math.sqrt(max(spec.fan_in, 1))      # kaiming_uniform(a=sqrt 5) == U(-1/sqrt(fan_in), +)
+        return t.uniform_(-a, a)
+    if k in ("norm_w", "ln_w"):
+        return t.fill_(1.0)
+    if k in ("norm_b", "ln_b"):
+        return t.zero_()
+    if k == "prelu":
+        return t.fill_(0.25)
+    raise ValueError(k)
+
+
+def _attach(root: nn.Module, dotted: str, p: nn.Parameter) -> None:
+    node = root
+    parts = dotted.split(".")
+    for name in parts[:-1]:
+        child = node._modules.get(name)
+        if child is None:
+            child = _Scope()
+            node.add_module(name, child)
+        node = child
+    node.register_parameter(parts[-1], p)
+
+
+# ----------------------------------------------------------------------------
+# bound program
+# ----------------------------------------------------------------------------
+class _Bound:
+    """A lowered program with device arenas and the ctypes op array."""
+
+    def __init__(self, prog: prg.Program, device: torch.device):
+        self.prog = prog
+        self.device = device
+        self.weights = torch.from_numpy(prog.weights).to(device)
+        self.acts = torch.empty(max(prog.act_floats, 1), dtype=torch.float32, device=device)
+        self.ops = (_lib.Op * len(prog.ops))()
+        self._in_ptr = None
+        self._out_ptr = None
+
+    def update_weights(self, flat: np.ndarray) -> None:
+        self.weights.copy_(torch.from_numpy(flat), non_blocking=False)
+
+    def _addr(self, ref: Optional[prg.Ref], bases) -> Optional[int]:
+        if ref is None:
+            return None
+        return bases[ref.arena] + 4 * ref.off
+
+    def bind(self, in_ptr: int, out_ptr: int) -> None:
+        if (in_ptr, out_ptr) == (self._in_ptr, self._out_ptr):
+            return
+        bases = {"w": self.weights.data_ptr(), "a": self.acts.data_ptr(), "in": in_ptr, "out": out_ptr}
+        A = lambda r: self._addr(r, bases)  # noqa: E731
+        for k, op in enumerate(self.prog.ops):
+            o = self.ops[k]
+            o.kind = op.kind
+            if op.kind == prg.OP_CONV:
+                d = o.conv
+                for f in ("src0", "src1", "xf0", "xf1", "slope0", "slope1", "w", "bias", "aux", "dst", "dst_acc",
+                          "stats", "stat_slope0", "stat_slope1"):
+                    setattr(d, f, A(getattr(op, f)))
+                for f in ("C0", "C1", "xf_mode", "N", "Kpad", "B", "T", "Fin", "Fout", "No", "ostride", "ophase",
+                          "istride", "epi", "Cout", "nsets", "stat_tiles", "stat_tile0", "bm"):
+                    setattr(d, f, int(getattr(op, f)))
+                d.ntaps = len(op.dt)
+                for j in range(_lib.MAX_TAPS):
+                    d.dt[j] = op.dt[j] if j < len(op.dt) else 0
+                    d.ioff[j] = op.ioff[j] if j < len(op.ioff) else 0
+            elif op.kind == prg.OP_IN_FINALIZE:
+                o.i[0:5] = [op.B, op.C, op.nsets, op.stat_tiles, op.count]
+                o.f[0] = op.eps
+                for j, r in enumerate((op.stats, op.gamma0, op.beta0, op.xf0, op.gamma1, op.beta1, op.xf1)):
+                    o.p[j] = A(r)
+            elif op.kind == prg.OP_NORM_ACT:
+                o.i[0:3] = [op.B, op.P, op.C]
+                for j, r in enumerate((op.a, op.xfa, op.slopea, op.b, op.xfb, op.slopeb, op.out)):
+                    o.p[j] = A(r)
+            elif op.kind == prg.OP_LSTM64:
+                o.i[0:3] = [op.B, op.T, op.F]
+                o.f[0] = op.ln_eps
+                for j, r in enumerate((op.x, op.ln_g, op.ln_b, op.wcat, op.bias, op.h_out)):
+                    o.p[j] = A(r)
+            elif op.kind == prg.OP_BFW_FS:
+                o.i[0:4] = [op.B, op.T, op.F, op.M]
+                for j, r in enumerate((op.y1, op.w2, op.b2, op.x, op.out, op.bfw)):
+                    o.p[j] = A(r)
+            elif op.kind == prg.OP_MEMSET0:
+                nbytes = 4 * op.nfloats
+                o.i[0] = C.c_int32(nbytes & 0xFFFFFFFF).value
+                o.i[1] = nbytes >> 32
+                o.p[0] = A(op.ptr)
+            else:
+                raise ValueError(op.kind)
+        self._in_ptr, self._out_ptr = in_ptr, out_ptr
+
+    def run(self, stream: int, first: int = 0, count: Optional[int] = None) -> None:
+        n = len(self.prog.ops) - first if count is None else count
+        ops = C.cast(C.byref(self.ops, first * C.sizeof(_lib.Op)), C.POINTER(_lib.Op))
+        _lib.check(_lib.load().eab_run_program(ops, n, C.c_void_p(stream)), "eab_run_program")
+
+    def view(self, act: prg.Act) -> torch.Tensor:
+        """Debug view of a named activation as (B, T, F, C)."""
+        p = self.prog
+        n = p.B * p.T * act.F * act.C
+        assert act.ref.arena == "a"
+        return self.acts[act.ref.off:act.ref.off + n].view(p.B, p.T, act.F, act.C)
+
+
+# ----------------------------------------------------------------------------
+# the module
+# ----------------------------------------------------------------------------
+class EaBNet(nn.Module):
+    """MI355X implementation of the reference ``EaBNet`` (EaBNet.py:9-125).
+
+    Same constructor keywords and defaults, same ``forward`` signature:
+    ``inpt`` (B, T, F, M, 2) [or (B, T, F, 2) for one microphone] ->
+    (B, 2, T, F), same state-dict keys.  Inference only in this round:
+    calling ``forward`` with autograd enabled on parameters that require grad
+    raises (SURVEY §8 row C4 "training" is not built yet).
+    """
+
+    def __init__(self, k1: tuple = (2, 3), k2: tuple = (1, 3), c: int = 64, M: int = 9, embed_dim: int = 64,
+                 kd1: int = 5, cd1: int = 64, d_feat: int = 256, p: int = 6, q: int = 3, is_causal: bool = True,
+                 is_u2: bool = True, bf_type: str = "lstm", topo_type: str = "mimo", intra_connect: str = "cat",
+                 norm_type: str = "IN"):
+        super().__init__()
+        self.k1, self.k2, self.c, self.M, self.embed_dim = tuple(k1), tuple(k2), c, M, embed_dim
+        self.kd1, self.cd1, self.d_feat, self.p, self.q = kd1, cd1, d_feat, p, q
+        self.is_causal, self.is_u2, self.bf_type = is_causal, is_u2, bf_type
+        self.topo_type, self.intra_connect, self.norm_type = topo_type, intra_connect, norm_type
+        self.cfg = NetConfig(k1=tuple(k1), k2=tuple(k2), c=c, M=M, embed_dim=embed_dim, kd1=kd1, cd1=cd1,
+                             d_feat=d_feat, p=p, q=q, is_causal=is_causal, is_u2=is_u2, bf_type=bf_type,
+                             topo_type=topo_type, intra_connect=intra_connect, norm_type=norm_type)
+        self._specs = param_specs(self.cfg)          # raises NotImplementedError for unsupported topologies
+        for key, spec in self._specs.items():
+            _attach(self, key, nn.Parameter(_default_init(spec)))
+        self._bound: Dict[Tuple[int, int, int, str], _Bound] = {}
+        self._packed_version: Dict[Tuple[int, int, int, str], tuple] = {}
+        self.dump_bfw = False                         # tests: also emit the (B,T,F,M,2) beam-forming weights
+
+    # -- program cache -----------------------------------------------------------
+    def _param_fingerprint(self) -> tuple:
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _numpy_params(self) -> Dict[str, np.ndarray]:
+        sd = self.state_dict()
+        return {k: sd[k].detach().to("cpu", torch.float32).numpy() for k in self._specs}
+
+    def _program(self, B: int, T: int, F: int, device: torch.device) -> _Bound:
+        key = (B, T, F, str(device))
+        fp = self._param_fingerprint()
+        bound = self._bound.get(key)
+        if bound is None or ("bf_w" in bound.prog.taps) != self.dump_bfw:
+            prog = prg.lower(self.cfg, self._numpy_params(), B, T, F, dump_bfw=self.dump_bfw)
+            bound = _Bound(prog, device)
+            self._bound = {key: bound}                # keep one shape resident (activations can be GBs)
+            self._packed_version = {key: fp}
+        elif self._packed_version.get(key) != fp:
+            prog = prg.lower(self.cfg, self._numpy_params(), B, T, F, dump_bfw=self.dump_bfw)
+            bound.update_weights(prog.weights)
+            self._packed_version[key] = fp
+        return bound
+
+    # -- forward -------------------------------------------------------------------
+    def forward(self, inpt: torch.Tensor) -> torch.Tensor:
+        """:param inpt: (B, T, F, M, 2) compressed multichannel spectrogram
+        :return: beamformed estimate (B, 2, T, F)   (reference EaBNet.py:88-117)"""
+        if inpt.ndim == 4:
+            inpt = inpt.unsqueeze(-2)
+        if inpt.ndim != 5 or inpt.shape[-1] != 2 or inpt.shape[-2] != self.M:
+            raise ValueError(f"expected (B,T,F,{self.M},2), got {tuple(inpt.shape)}")
+        if not inpt.is_cuda:
+            raise _lib.EabError("eabnet_amd.EaBNet runs on MI355X only: move the input (and module) to 'cuda'. "
+                                "There is no CPU fallback by design.")
+        if torch.is_grad_enabled() and (inpt.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError(
+                "eabnet_amd.EaBNet is inference-only in this round (backward kernels: DESIGN.md, 'next'). "
+                "Wrap the call in torch.no_grad().")
+        _lib.load()
+        B, T, F, M, _ = inpt.shape
+        x = inpt.detach().to(torch.float32).contiguous()
+        out = torch.empty((B, 2, T, F), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            bound = self._program(B, T, F, x.device)
+            bound.bind(x.data_ptr(), out.data_ptr())
+            bound.run(torch.cuda.current_stream().cuda_stream)
+        self._last = (bound, x)                       # keep the input alive until the stream has consumed it
+        return out.to(inpt.dtype)
+
+
+# ----------------------------------------------------------------------------
+# front end and helpers
+# ----------------------------------------------------------------------------
+_TWIDDLE: Dict[Tuple[int, str], torch.Tensor] = {}
+
+
+def _twiddle(n_fft: int, device: torch.device) -> torch.Tensor:
+    key = (n_fft, str(device))
+    if key not in _TWIDDLE:
+        k = np.arange(n_fft, dtype=np.float64)
+        tw = np.stack([np.cos(2 * np.pi * k / n_fft), np.sin(2 * np.pi * k / n_fft)], axis=1).astype(np.float32)
+        _TWIDDLE[key] = torch.from_numpy(tw).to(device)
+    return _TWIDDLE[key]
+
+
+def stft_compress(wav: torch.Tensor, n_fft: int, hop: int, window: torch.Tensor, layout: int = 0) -> torch.Tensor:
+    """(B, M, L) -> (B, T, F, M, 2)  [layout 0]  or (B, 1, L) -> (B, 2, T, F)  [layout 1]."""
+    if not wav.is_cuda:
+        raise _lib.EabError("stft_compress needs a CUDA (ROCm) tensor; there is no CPU fallback by design.")
+    lib = _lib.load()
+    B, M, L = wav.shape
+    T, F = 1 + L // hop, n_fft // 2 + 1
+    wav = wav.to(torch.float32).contiguous()
+    window = window.to(device=wav.device, dtype=torch.float32).contiguous()
+    out = torch.empty((B, T, F, M, 2) if layout == 0 else (B, 2, T, F), dtype=torch.float32, device=wav.device)
+    with torch.cuda.device(wav.device):
+        tw = _twiddle(n_fft, wav.device)
+        _lib.check(lib.eab_stft_compress_f32(wav.data_ptr(), window.data_ptr(), tw.data_ptr(), out.data_ptr(),
+                                             B, M, L, n_fft, hop, layout,
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   "eab_stft_compress_f32")
+    return out
+
+
+def prepare_data(x: torch.Tensor, target: torch.Tensor, device, args):
+    """Reference train_distributed.py:68-95.  ``args`` provides mics, sr,
+    wav_len, win_size, win_shift (seconds) and fft_num.
+    x (B, M, L), target (B, 1, L) -> noisy_stft (B, T, F, M, 2), target_stft (B, 2, T, F)."""
+    sr = args.sr
+    win_size = int(args.win_size * sr)
+    win_shift = int(args.win_shift * sr)
+    fft_num = args.fft_num
+    if win_size != fft_num:
+        raise NotImplementedError("the HIP front end implements win_size == fft_num (the reference's 320/320)")
+    batch_size = x.shape[0]
+    noisy_wav = x.to(device).contiguous().view(batch_size, args.mics, -1)
+    target_wav = target.to(device).reshape(batch_size, 1, -1)
+    window = torch.hann_window(win_size)
+    noisy_stft = stft_compress(noisy_wav, fft_num, win_shift, window, 0)
+    target_stft = stft_compress(target_wav, fft_num, win_shift, window, 1)
+    return noisy_stft, target_stft
+
+
+def filter_and_sum(w: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """Stand-alone K13 (reference EaBNet.py:114-117): (B,T,F,M,2)^2 -> (B,2,T,F)."""
+    if not (w.is_cuda and x.is_cuda):
+        raise _lib.EabError("filter_and_sum needs CUDA (ROCm) tensors; there is no CPU fallback by design.")
+    lib = _lib.load()
+    B, T, F, M, _ = x.shape
+    w = w.to(torch.float32).contiguous()
+    x = x.to(torch.float32).contiguous()
+    y = torch.empty((B, 2, T, F), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.eab_filter_sum_f32(w.data_ptr(), x.data_ptr(), y.data_ptr(), B, T, F, M,
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "eab_filter_sum_f32")
+    return y
+
+
+def numParams(net: nn.Module) -> int:
+    """Reference EaBNet.py:653-659."""
+    return sum(int(np.prod(p.size())) for p in net.parameters() if p.requires_grad)
+
+
+def com_mag_mse_loss(esti: torch.Tensor, label: torch.Tensor, frame_list) -> torch.Tensor:
+    """Reference EaBNet.py:627-640: 0.5*(masked magnitude MSE + masked complex MSE)."""
+    B, _, T, F = esti.shape
+    mask = torch.zeros((B, T, F), dtype=esti.dtype, device=esti.device)
+    for i, n in enumerate(frame_list):
+        mask[i, :n] = 1.0
+    com_mask = torch.stack((mask, mask), dim=1)
+    mag_e, mag_l = torch.norm(esti, dim=1), torch.norm(label, dim=1)
+    loss1 = (((mag_e - mag_l) ** 2.0) * mask).sum() / mask.sum()
+    loss2 = (((esti - label) ** 2.0) * com_mask).sum() / com_mask.sum()
+    return 0.5 * (loss1 + loss2)

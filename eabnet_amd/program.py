@@ -1,0 +1,518 @@
+"""Lowering of EaBNet.forward (reference EaBNet.py:88-117) to the op program
+that libeabnet_hip.so executes (include/eabnet_hip.h, eab_run_program).
+
+Everything here is host logic on numpy: weight re-packing, convolution
+geometry (taps, phases of the transposed convolutions), the layer schedule and
+the workspace plan.  Pointers are symbolic (arena, float offset) until
+``bind()`` turns them into device addresses, so the whole lowering can be
+checked on a machine without a GPU (tests/test_program_emulated.py interprets
+the same program with numpy against the oracle).
+
+Data layout: activations are channels-last
+``[B][T][F][C]`` fp32.  Consequences folded into the packed weights:
+  * network input (B,T,F,M,2) is read in place as C = 2M channels with memory
+    channel m*2+ri, while the reference feeds channel ri*M+m (EaBNet.py:96-97)
+    -> the first conv's input channels are permuted;
+  * the bottleneck (B,256,T) of EaBNet.py:100 has channel c*4+f; here it is the
+    same memory as the encoder output [B][T][4][64], i.e. channel f*64+c
+    -> S-TCM in_conv columns / out_conv rows are permuted, and the two
+    transposes of EaBNet.py:100,106 disappear.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .spec import NetConfig, param_specs
+
+# mirrors of the C enums (include/eabnet_hip.h)
+XF_NONE, XF_NORM_PRELU, XF_PRELU_NORM = 0, 1, 2
+EPI_LINEAR, EPI_GLU, EPI_RELU, EPI_MULSIG, EPI_ADD = 0, 1, 2, 3, 4
+OP_CONV, OP_IN_FINALIZE, OP_NORM_ACT, OP_LSTM64, OP_BFW_FS, OP_MEMSET0 = 1, 2, 3, 4, 5, 6
+MAX_TAPS = 16
+EPS_IN = 1e-5      # nn.InstanceNorm*d default (reference EaBNet.py:684,686)
+EPS_LN = 1e-5      # nn.LayerNorm default (reference EaBNet.py:598)
+ALIGN = 64         # floats: every arena allocation starts on a 256-byte boundary
+CUS = 256
+
+
+@dataclass(frozen=True)
+class Ref:
+    """Symbolic device pointer: float offset into one of the arenas
+    'w' (packed weights), 'a' (activations/workspace), 'in', 'out'."""
+    arena: str
+    off: int = 0
+
+
+@dataclass
+class Act:
+    """A channels-last activation [B][T][F][C].  If ``xf`` is set the tensor in
+    memory is RAW (pre-norm) and consumers apply f = (scale,shift) table +
+    PReLU slope in mode ``mode`` while loading it."""
+    ref: Ref
+    F: int
+    C: int
+    xf: Optional[Ref] = None
+    slope: Optional[Ref] = None
+    mode: int = XF_NONE
+
+
+@dataclass
+class ConvOp:
+    src0: Ref
+    src1: Optional[Ref]
+    xf0: Optional[Ref]
+    xf1: Optional[Ref]
+    slope0: Optional[Ref]
+    slope1: Optional[Ref]
+    C0: int
+    C1: int
+    xf_mode: int
+    w: Ref
+    bias: Optional[Ref]
+    N: int
+    Kpad: int
+    B: int
+    T: int
+    Fin: int
+    Fout: int
+    No: int
+    ostride: int
+    ophase: int
+    istride: int
+    dt: List[int]
+    ioff: List[int]
+    epi: int
+    aux: Optional[Ref]
+    dst: Ref
+    dst_acc: Optional[Ref]
+    Cout: int
+    stats: Optional[Ref]
+    nsets: int
+    stat_slope0: Optional[Ref]
+    stat_slope1: Optional[Ref]
+    stat_tiles: int
+    stat_tile0: int
+    bm: int
+    name: str = ""
+    kind: int = OP_CONV
+
+
+@dataclass
+class FinalizeOp:
+    stats: Ref
+    B: int
+    C: int
+    nsets: int
+    stat_tiles: int
+    count: int
+    eps: float
+    gamma0: Ref
+    beta0: Ref
+    xf0: Ref
+    gamma1: Optional[Ref] = None
+    beta1: Optional[Ref] = None
+    xf1: Optional[Ref] = None
+    name: str = ""
+    kind: int = OP_IN_FINALIZE
+
+
+@dataclass
+class NormActOp:
+    a: Ref
+    xfa: Ref
+    slopea: Ref
+    b: Optional[Ref]
+    xfb: Optional[Ref]
+    slopeb: Optional[Ref]
+    out: Ref
+    B: int
+    P: int
+    C: int
+    name: str = ""
+    kind: int = OP_NORM_ACT
+
+
+@dataclass
+class LstmOp:
+    x: Ref
+    ln_g: Optional[Ref]
+    ln_b: Optional[Ref]
+    ln_eps: float
+    wcat: Ref
+    bias: Ref
+    h_out: Ref
+    B: int
+    T: int
+    F: int
+    name: str = ""
+    kind: int = OP_LSTM64
+
+
+@dataclass
+class BfwOp:
+    y1: Ref
+    w2: Ref
+    b2: Ref
+    x: Ref
+    out: Ref
+    bfw: Optional[Ref]
+    B: int
+    T: int
+    F: int
+    M: int
+    name: str = ""
+    kind: int = OP_BFW_FS
+
+
+@dataclass
+class MemsetOp:
+    ptr: Ref
+    nfloats: int
+    name: str = ""
+    kind: int = OP_MEMSET0
+
+
+def conv_tiles(T: int, No: int, bm: int) -> int:
+    return (T * No + bm - 1) // bm
+
+
+# ----------------------------------------------------------------------------
+# weight packing
+# ----------------------------------------------------------------------------
+def glu_row_order(N: int) -> np.ndarray:
+    """packed row r -> original row, so that a wave's two 32-column MFMA tiles
+    hold value and gate of the same 32 channels (include/eabnet_hip.h)."""
+    r = np.arange(N)
+    return (r % 64 // 32) * (N // 2) + (r // 64) * 32 + r % 32
+
+
+def pack_taps(w_nck: np.ndarray, taps_k: Sequence[int]) -> np.ndarray:
+    """w_nck: [N][C][ntaps_all] (taps flattened); taps_k: which flattened taps,
+    in kernel order.  Returns [N][len(taps_k)*UPT*16] with unit layout
+    (tap, 16-channel block), zero padded."""
+    N, C, _ = w_nck.shape
+    upt = (C + 15) // 16
+    out = np.zeros((N, len(taps_k), upt * 16), dtype=np.float32)
+    for j, k in enumerate(taps_k):
+        out[:, j, :C] = w_nck[:, :, k]
+    return out.reshape(N, -1)
+
+
+class WeightArena:
+    """Flat fp32 buffer of packed parameters + name -> Ref table."""
+
+    def __init__(self):
+        self.chunks: List[np.ndarray] = []
+        self.size = 0
+        self.index: Dict[str, Ref] = {}
+
+    def add(self, name: str, arr: np.ndarray) -> Ref:
+        if name in self.index:
+            return self.index[name]
+        flat = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
+        pad = (-flat.size) % ALIGN
+        ref = Ref("w", self.size)
+        self.chunks.append(flat)
+        if pad:
+            self.chunks.append(np.zeros(pad, dtype=np.float32))
+        self.size += flat.size + pad
+        self.index[name] = ref
+        return ref
+
+    def flat(self) -> np.ndarray:
+        return np.concatenate(self.chunks) if self.chunks else np.zeros(0, np.float32)
+
+
+# ----------------------------------------------------------------------------
+# the lowering
+# ----------------------------------------------------------------------------
+@dataclass
+class Program:
+    cfg: NetConfig
+    B: int
+    T: int
+    F: int
+    ops: list
+    weights: np.ndarray            # packed parameter arena (fp32)
+    act_floats: int                # workspace arena size (floats)
+    taps: Dict[str, Act]           # named materialised activations (debug / tests)
+    flops: int = 0                 # MAC*2 of all MFMA ops (algorithmic, un-padded)
+
+
+class Lowering:
+    def __init__(self, cfg: NetConfig, params: Dict[str, np.ndarray], B: int, T: int, F: int = 161,
+                 dump_bfw: bool = False):
+        cfg.check_supported()
+        specs = param_specs(cfg)
+        missing = [k for k in specs if k not in params]
+        if missing:
+            raise KeyError(f"missing parameters: {missing[:4]} ...")
+        for k, s in specs.items():
+            if tuple(params[k].shape) != tuple(s.shape):
+                raise ValueError(f"{k}: shape {tuple(params[k].shape)} != {tuple(s.shape)}")
+        self.cfg, self.P, self.B, self.T, self.F = cfg, params, B, T, F
+        self.W = WeightArena()
+        self.ops: list = []
+        self.act_size = 0
+        self.taps: Dict[str, Act] = {}
+        self.flops = 0
+        self.dump_bfw = dump_bfw
+
+    # -- arenas ---------------------------------------------------------------
+    def alloc(self, nfloats: int) -> Ref:
+        ref = Ref("a", self.act_size)
+        self.act_size += nfloats + ((-nfloats) % ALIGN)
+        return ref
+
+    def alloc_act(self, F: int, C: int) -> Ref:
+        return self.alloc(self.B * self.T * F * C)
+
+    def vec(self, key: str) -> Ref:
+        return self.W.add(key, self.P[key])
+
+    # -- generic conv emission -----------------------------------------------------
+    def pick_bm(self, No: int) -> int:
+        return 128 if self.B * conv_tiles(self.T, No, 128) >= 2 * CUS else 64
+
+    def emit_conv(self, name: str, srcs: Sequence[Act], w: Ref, bias: Optional[Ref], N: int, Kpad: int,
+                  Fout: int, No: int, ostride: int, ophase: int, istride: int, dt, ioff, epi: int,
+                  dst: Ref, stats: Optional[Ref] = None, nsets: int = 0, stat_slopes=(None, None),
+                  stat_tiles: int = 0, stat_tile0: int = 0, bm: Optional[int] = None, aux: Optional[Ref] = None,
+                  dst_acc: Optional[Ref] = None) -> ConvOp:
+        assert 1 <= len(srcs) <= 2 and len(dt) == len(ioff) <= MAX_TAPS
+        s0 = srcs[0]
+        s1 = srcs[1] if len(srcs) == 2 else None
+        modes = {s.mode for s in srcs if s.xf is not None}
+        assert len(modes) <= 1, "both concat sources must use the same transform order"
+        mode = modes.pop() if modes else XF_NONE
+        if s1 is not None:
+            assert s0.F == s1.F and s0.C % 16 == 0
+        C0, C1 = s0.C, (s1.C if s1 else 0)
+        upt = (C0 + C1 + 15) // 16
+        assert Kpad == len(dt) * upt * 16
+        bm = bm or self.pick_bm(No)
+        op = ConvOp(src0=s0.ref, src1=s1.ref if s1 else None, xf0=s0.xf, xf1=s1.xf if s1 else None,
+                    slope0=s0.slope, slope1=s1.slope if s1 else None, C0=C0, C1=C1, xf_mode=mode, w=w, bias=bias,
+                    N=N, Kpad=Kpad, B=self.B, T=self.T, Fin=s0.F, Fout=Fout, No=No, ostride=ostride, ophase=ophase,
+                    istride=istride, dt=list(dt), ioff=list(ioff), epi=epi, aux=aux, dst=dst, dst_acc=dst_acc,
+                    Cout=N // 2 if epi == EPI_GLU else N, stats=stats, nsets=nsets, stat_slope0=stat_slopes[0],
+                    stat_slope1=stat_slopes[1], stat_tiles=stat_tiles, stat_tile0=stat_tile0, bm=bm, name=name)
+        self.ops.append(op)
+        self.flops += 2 * self.B * self.T * No * N * len(dt) * (C0 + C1)
+        return op
+
+    def emit_finalize(self, name, stats, C, nsets, stat_tiles, count, norms: Sequence[str]) -> List[Ref]:
+        xfs = [self.alloc(self.B * C * 2) for _ in range(nsets)]
+        g = [self.vec(f"{n}.norm.weight") for n in norms]
+        b = [self.vec(f"{n}.norm.bias") for n in norms]
+        self.ops.append(FinalizeOp(stats=stats, B=self.B, C=C, nsets=nsets, stat_tiles=stat_tiles, count=count,
+                                   eps=EPS_IN, gamma0=g[0], beta0=b[0], xf0=xfs[0],
+                                   gamma1=g[1] if nsets == 2 else None, beta1=b[1] if nsets == 2 else None,
+                                   xf1=xfs[1] if nsets == 2 else None, name=name))
+        return xfs
+
+    # -- 2-D units -------------------------------------------------------------------
+    def conv2d_fwd(self, name: str, srcs: Sequence[Act], wkey: str, glu: bool, norm: str, act: str,
+                   in_perm: Optional[np.ndarray] = None) -> Act:
+        """Strided causal Conv2d [(kt,kf), stride (1,2)] (+GLU) -> raw output with
+        InstanceNorm+PReLU pending.  Reference GateConv2d EaBNet.py:434-460 /
+        Conv2dunit :391-407."""
+        w = self.P[f"{wkey}.weight"]                       # (N, Cin, kt, kf)
+        N, Cin, kt, kf = w.shape
+        if in_perm is not None:
+            w = w[:, in_perm]
+        Fin = srcs[0].F
+        Fout = (Fin - kf) // 2 + 1
+        order = glu_row_order(N) if glu else np.arange(N)
+        taps = [(a, c) for a in range(kt) for c in range(kf)]
+        wp = pack_taps(w.reshape(N, Cin, kt * kf)[order], [a * kf + c for a, c in taps])
+        wref = self.W.add(f"{wkey}.weight#packed", wp)
+        bref = self.W.add(f"{wkey}.bias#packed", self.P[f"{wkey}.bias"][order])
+        Cout = N // 2 if glu else N
+        dst = self.alloc_act(Fout, Cout)
+        bm = self.pick_bm(Fout)
+        tiles = conv_tiles(self.T, Fout, bm)
+        stats = self.alloc(self.B * tiles * Cout * 2)
+        self.emit_conv(name, srcs, wref, bref, N, wp.shape[1], Fout, Fout, 1, 0, 2,
+                       [a - (kt - 1) for a, _ in taps], [c for _, c in taps],
+                       EPI_GLU if glu else EPI_LINEAR, dst, stats, 1, (None, None), tiles, 0, bm)
+        xf, = self.emit_finalize(name + ".in", stats, Cout, 1, tiles, self.T * Fout, [norm])
+        return Act(dst, Fout, Cout, xf, self.vec(f"{act}.weight"), XF_NORM_PRELU)
+
+    def conv2d_transposed(self, name: str, srcs: Sequence[Act], wkey: str, glu: bool, norm: str, act: str) -> Act:
+        """ConvTranspose2d [(kt,kf), stride (1,2)] + drop of the last kt-1 rows
+        (+GLU) as two gather-form launches, one per output-column parity:
+          out[t][2o+ph] = sum_{kt} sum_{kf = ph, ph+2, ..} W[kt][kf] . in[t-kt][o-(kf-ph)/2]
+        Reference GateConvTranspose2d EaBNet.py:463-490 + Chomp_T :617-624 /
+        Deconv2dunit :410-431."""
+        w = self.P[f"{wkey}.weight"]                       # (Cin, N, kt, kf)
+        Cin, N, kt, kf = w.shape
+        assert Cin == sum(s.C for s in srcs)
+        Fin = srcs[0].F
+        Fout = (Fin - 1) * 2 + kf
+        order = glu_row_order(N) if glu else np.arange(N)
+        wn = np.ascontiguousarray(w.transpose(1, 0, 2, 3)).reshape(N, Cin, kt * kf)[order]
+        bref = self.W.add(f"{wkey}.bias#packed", self.P[f"{wkey}.bias"][order])
+        Cout = N // 2 if glu else N
+        dst = self.alloc_act(Fout, Cout)
+        No = [(Fout + 1) // 2, Fout // 2]
+        bm = self.pick_bm(No[0])
+        tiles = [conv_tiles(self.T, n, bm) for n in No]
+        stats = self.alloc(self.B * sum(tiles) * Cout * 2)
+        for ph in (0, 1):
+            taps = [(a, c) for a in range(kt) for c in range(ph, kf, 2)]
+            wp = pack_taps(wn, [a * kf + c for a, c in taps])
+            wref = self.W.add(f"{wkey}.weight#packed.ph{ph}", wp)
+            self.emit_conv(f"{name}.ph{ph}", srcs, wref, bref, N, wp.shape[1], Fout, No[ph], 2, ph, 1,
+                           [-a for a, _ in taps], [-(c - ph) // 2 for _, c in taps],
+                           EPI_GLU if glu else EPI_LINEAR, dst, stats, 1, (None, None), sum(tiles),
+                           0 if ph == 0 else tiles[0], bm)
+        xf, = self.emit_finalize(name + ".in", stats, Cout, 1, sum(tiles), self.T * Fout, [norm])
+        return Act(dst, Fout, Cout, xf, self.vec(f"{act}.weight"), XF_NORM_PRELU)
+
+    def materialise(self, name: str, a: Act, b: Optional[Act] = None) -> Act:
+        """out = f_a(a) [+ f_b(b)]: the En_unet_module residual (EaBNet.py:386)
+        or a plain norm+PReLU apply where the tensor must exist in memory."""
+        assert a.xf is not None and a.mode == XF_NORM_PRELU
+        out = self.alloc_act(a.F, a.C)
+        self.ops.append(NormActOp(a=a.ref, xfa=a.xf, slopea=a.slope, b=b.ref if b else None,
+                                  xfb=b.xf if b else None, slopeb=b.slope if b else None, out=out, B=self.B,
+                                  P=self.T * a.F, C=a.C, name=name))
+        act = Act(out, a.F, a.C)
+        self.taps[name] = act
+        return act
+
+    def unet_module(self, pre: str, srcs: Sequence[Act], scale: int, transposed: bool,
+                    in_perm: Optional[np.ndarray] = None) -> Act:
+        """En_unet_module.forward, reference EaBNet.py:372-388."""
+        if transposed:
+            g = self.conv2d_transposed(f"{pre}.in_conv", srcs, f"{pre}.in_conv.0.conv.0", True,
+                                       f"{pre}.in_conv.1", f"{pre}.in_conv.2")
+        else:
+            g = self.conv2d_fwd(f"{pre}.in_conv", srcs, f"{pre}.in_conv.0.conv.1", True,
+                                f"{pre}.in_conv.1", f"{pre}.in_conv.2", in_perm)
+        y = g
+        downs = []
+        for j in range(scale):
+            q = f"{pre}.enco.{j}.conv"
+            y = self.conv2d_fwd(q, [y], f"{q}.0", False, f"{q}.1", f"{q}.2")
+            downs.append(y)
+        for j in range(scale):
+            q = f"{pre}.deco.{j}.deconv"
+            ins = [y] if j == 0 else [y, downs[-(j + 1)]]
+            y = self.conv2d_transposed(q, ins, f"{q}.0", False, f"{q}.1", f"{q}.2")
+        return self.materialise(pre, g, y)
+
+    # -- squeezed TCM --------------------------------------------------------------------
+    def tcm(self, pre: str, x: Act, dilation: int, x_acc: Optional[Ref], perm: np.ndarray) -> Act:
+        """SqueezedTCM.forward, reference EaBNet.py:572-578, on [B][T][1][256]."""
+        cfg, T, B = self.cfg, self.T, self.B
+        D, cd, kd = cfg.d_feat, cfg.cd1, cfg.kd1
+        bm = 64
+        tiles = conv_tiles(T, 1, bm)
+        # in_conv 1x1 (no bias); statistics of BOTH branch PReLUs of its output
+        w_in = self.P[f"{pre}.in_conv.weight"][:, perm, :]               # (cd, D, 1)
+        wref = self.W.add(f"{pre}.in_conv.weight#packed", pack_taps(w_in, [0]))
+        y = self.alloc_act(1, cd)
+        st = self.alloc(B * tiles * 2 * cd * 2)
+        slL, slR = self.vec(f"{pre}.left_conv.0.weight"), self.vec(f"{pre}.right_conv.0.weight")
+        self.emit_conv(f"{pre}.in_conv", [x], wref, None, cd, D, 1, 1, 1, 0, 1, [0], [0], EPI_LINEAR, y,
+                       st, 2, (slL, slR), tiles, 0, bm)
+        xfL, xfR = self.emit_finalize(f"{pre}.in_conv.in", st, cd, 2, tiles, T,
+                                      [f"{pre}.left_conv.1", f"{pre}.right_conv.1"])
+        dts = [-(kd - 1 - j) * dilation for j in range(kd)]
+        zeros = [0] * kd
+        kp = kd * ((cd + 15) // 16) * 16
+        # left branch -> raw; right branch gates it: z = left * sigmoid(right)
+        wl = self.W.add(f"{pre}.left_conv.3.weight#packed", pack_taps(self.P[f"{pre}.left_conv.3.weight"], range(kd)))
+        wr = self.W.add(f"{pre}.right_conv.3.weight#packed", pack_taps(self.P[f"{pre}.right_conv.3.weight"], range(kd)))
+        left = self.alloc_act(1, cd)
+        self.emit_conv(f"{pre}.left_conv", [Act(y, 1, cd, xfL, slL, XF_PRELU_NORM)], wl, None, cd, kp, 1, 1, 1, 0, 1,
+                       dts, zeros, EPI_LINEAR, left, bm=bm)
+        z = self.alloc_act(1, cd)
+        st2 = self.alloc(B * tiles * cd * 2)
+        slO = self.vec(f"{pre}.out_conv.0.weight")
+        self.emit_conv(f"{pre}.right_conv", [Act(y, 1, cd, xfR, slR, XF_PRELU_NORM)], wr, None, cd, kp, 1, 1, 1, 0, 1,
+                       dts, zeros, EPI_MULSIG, z, st2, 1, (slO, None), tiles, 0, bm, aux=left)
+        xfZ, = self.emit_finalize(f"{pre}.out_conv.in", st2, cd, 1, tiles, T, [f"{pre}.out_conv.1"])
+        w_out = self.P[f"{pre}.out_conv.2.weight"][perm]                  # (D, cd, 1), rows permuted
+        wo = self.W.add(f"{pre}.out_conv.2.weight#packed", pack_taps(w_out, [0]))
+        xn = self.alloc_act(1, D)
+        self.emit_conv(f"{pre}.out_conv", [Act(z, 1, cd, xfZ, slO, XF_PRELU_NORM)], wo, None, D, cd, 1, 1, 1, 0, 1,
+                       [0], [0], EPI_ADD, xn, bm=bm, aux=x.ref, dst_acc=x_acc)
+        return Act(xn, 1, D)
+
+    # -- whole network ----------------------------------------------------------------------
+    def build(self) -> Program:
+        cfg, B, T, F = self.cfg, self.B, self.T, self.F
+        M, c = cfg.M, cfg.c
+        x_in = Act(Ref("in"), F, 2 * M)
+        # memory channel m*2+ri  <-  reference channel ri*M+m
+        mem = np.arange(2 * M)
+        in_perm = (mem % 2) * M + mem // 2
+
+        skips: List[Act] = []
+        x = x_in
+        for i in range(4):
+            x = self.unet_module(f"en.meta_unet_list.{i}", [x], 4 - i, False, in_perm if i == 0 else None)
+            skips.append(x)
+        g = self.conv2d_fwd("en.last_conv", [x], "en.last_conv.0.conv.1", True, "en.last_conv.1", "en.last_conv.2")
+        x = self.materialise("en.last_conv", g)
+        skips.append(x)
+        assert x.F * x.C == cfg.d_feat, "bottleneck width must equal d_feat"
+
+        # S-TCN on the same memory viewed as [B][T][1][256]; channel f*64+c <- reference c*4+f
+        Fb = x.F
+        k = np.arange(cfg.d_feat)
+        perm = (k % c) * Fb + k // c
+        xt = Act(x.ref, 1, cfg.d_feat)
+        x_acc = self.alloc_act(1, cfg.d_feat)
+        self.ops.append(MemsetOp(x_acc, B * T * cfg.d_feat, name="stcns.acc0"))
+        for gi in range(cfg.q):
+            for i in range(cfg.p):
+                xt = self.tcm(f"stcns.{gi}.tcm_list.{i}", xt, 2 ** i, x_acc if i == cfg.p - 1 else None, perm)
+                if gi == 0 and i == 0:
+                    self.taps["stcns.0.0"] = xt
+        x = Act(x_acc, Fb, c)
+        self.taps["stcns"] = x
+
+        for i in range(4):
+            x = self.unet_module(f"de.meta_unet_list.{i}", [x, skips[-(i + 1)]], i + 1, True)
+        g = self.conv2d_transposed("de.last_conv", [x, skips[0]], "de.last_conv.0.conv.0", True,
+                                   "de.last_conv.1", "de.last_conv.2")
+        e = self.materialise("de.last_conv", g)
+        assert e.F == F and e.C == cfg.embed_dim == 64
+
+        # LSTM_BF (EaBNet.py:600-614)
+        h = e
+        for li, nm in enumerate(("rnn1", "rnn2")):
+            p = f"bf_map.{nm}"
+            wcat = np.concatenate([self.P[f"{p}.weight_ih_l0"], self.P[f"{p}.weight_hh_l0"]], axis=1)
+            bias = self.P[f"{p}.bias_ih_l0"] + self.P[f"{p}.bias_hh_l0"]
+            out = self.alloc_act(F, 64)
+            self.ops.append(LstmOp(x=h.ref, ln_g=self.vec("bf_map.norm.weight") if li == 0 else None,
+                                   ln_b=self.vec("bf_map.norm.bias") if li == 0 else None, ln_eps=EPS_LN,
+                                   wcat=self.W.add(f"{p}#wcat", wcat), bias=self.W.add(f"{p}#bias", bias),
+                                   h_out=out, B=B, T=T, F=F, name=p))
+            self.flops += 2 * B * T * F * 256 * 128
+            h = Act(out, F, 64)
+            self.taps[p] = h
+        w1 = self.W.add("bf_map.w_dnn.0.weight#packed", pack_taps(self.P["bf_map.w_dnn.0.weight"][:, :, None], [0]))
+        y1 = self.alloc_act(F, 64)
+        self.emit_conv("bf_map.w_dnn.0", [h], w1, self.vec("bf_map.w_dnn.0.bias"), 64, 64, F, F, 1, 0, 1, [0], [0],
+                       EPI_RELU, y1)
+        bfw = self.alloc(B * T * F * 2 * M) if self.dump_bfw else None
+        if bfw is not None:
+            self.taps["bf_w"] = Act(bfw, F, 2 * M)
+        self.ops.append(BfwOp(y1=y1, w2=self.vec("bf_map.w_dnn.2.weight"), b2=self.vec("bf_map.w_dnn.2.bias"),
+                              x=Ref("in"), out=Ref("out"), bfw=bfw, B=B, T=T, F=F, M=M, name="bf_map.w_dnn.2+fs"))
+        self.flops += 2 * B * T * F * 64 * 2 * M
+        return Program(cfg, B, T, F, self.ops, self.W.flat(), self.act_size, self.taps, self.flops)
+
+
+def lower(cfg: NetConfig, params: Dict[str, np.ndarray], B: int, T: int, F: int = 161,
+          dump_bfw: bool = False) -> Program:
+    return Lowering(cfg, params, B, T, F, dump_bfw).build()

@@ -1,0 +1,238 @@
+/*
+ * eabnet_hip.h -- C ABI of libeabnet_hip.so, the MI355X (gfx950) implementation
+ * of EaBNet's per-frame beamforming hot path.
+ *
+ * The reference (Ezreal11/EaBNet) has no FFI layer: its "operator API" is the
+ * Python class EaBNet and the free function prepare_data, and every device op
+ * is an ATen call.  Each entry point below therefore names the reference
+ * call-site(s) it replaces (file:line into the reference tree).  The Python
+ * side (eabnet_amd/) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers to fp32 unless stated otherwise; the
+ *     caller (PyTorch) owns every buffer, the library allocates nothing;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); all work
+ *     is enqueued on it, no entry point synchronises, all are graph-capturable;
+ *   - return value: 0 on success, otherwise an EAB_E* code / hipError_t + 1000;
+ *     eab_error_string() describes it.  Arguments are validated BEFORE any
+ *     launch (shape/limit violations never reach a kernel);
+ *   - activation layout inside the library is channels-last:
+ *     [B][T][F][C] fp32, C contiguous.  The two boundary tensors keep the
+ *     reference's layouts: input (B,T,F,M,2), output (B,2,T,F).
+ */
+#ifndef EABNET_HIP_H
+#define EABNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EAB_ABI_VERSION 1
+
+#define EAB_OK          0
+#define EAB_EINVAL      1   /* bad argument (shape, alignment, limit) */
+#define EAB_EUNSUPPORTED 2  /* valid but not built (e.g. N not in {64,128,256}) */
+#define EAB_EHIP_BASE   1000 /* 1000 + hipError_t */
+
+typedef void* eab_stream_t;
+
+int         eab_abi_version(void);
+const char* eab_error_string(int code);
+
+/* --------------------------------------------------------------------------
+ * K1+K2+K3  STFT front end, fused.
+ * Replaces train_distributed.py:80,83,86,89,91 (noisy branch) and
+ * :81,84,87,90,92 (target branch): view(B*M,L) -> torch.stft(n_fft, hop,
+ * win=n_fft, window, center=True, reflect, onesided) -> permute -> sqrt-magnitude
+ * compression X*|X|^-1/2.
+ *   wav     [B][M][L]
+ *   window  [n_fft]          the caller's torch.hann_window(win) (values are
+ *                            taken, not recomputed: ATen's fp32 window is not
+ *                            the double-rounded formula)
+ *   twiddle [n_fft][2]       (cos, sin)(2 pi k / n_fft), k = 0..n_fft-1
+ *   out     layout 0: [B][T][F][M][2]   (noisy_stft handed to EaBNet.forward)
+ *           layout 1: [B][2][T][F]      (target_stft; requires M == 1)
+ *   T = 1 + L/hop, F = n_fft/2 + 1.  Limits: n_fft <= 512, even; L > n_fft/2.
+ * ------------------------------------------------------------------------ */
+#define EAB_STFT_LAYOUT_BTFM2 0
+#define EAB_STFT_LAYOUT_B2TF  1
+int eab_stft_compress_f32(const float* wav, const float* window, const float* twiddle,
+                          float* out, int B, int M, int L, int n_fft, int hop,
+                          int layout, eab_stream_t stream);
+
+/* Debug/verification twin of the framing step only (bit-exact contract for
+ * "STFT frame indexing"): frames[n][t][k] = reflect_pad(wav[n], n_fft/2)[t*hop + k].
+ *   wav [N][L] -> frames [N][T][n_fft] */
+int eab_stft_frames_f32(const float* wav, float* frames, int N, int L, int n_fft, int hop,
+                        eab_stream_t stream);
+
+/* --------------------------------------------------------------------------
+ * K13  complex filter-and-sum, stand-alone.   Replaces EaBNet.py:114-117.
+ *   w, x [B][T][F][M][2] -> y [B][2][T][F];  Y = sum_m W_m * X_m (no conjugate)
+ * ------------------------------------------------------------------------ */
+int eab_filter_sum_f32(const float* w, const float* x, float* y, int B, int T, int F, int M,
+                       eab_stream_t stream);
+
+/* --------------------------------------------------------------------------
+ * K4-K7, K9, K12(first Linear)  gather-GEMM convolution on fp32 MFMA.
+ * One launch computes, for every output position (b, t, fo = o*ostride+ophase),
+ *     acc[n] = bias[n] + sum_{tap j, channel c} W[n][j][c] * f(src[b][t+dt_j][o*istride+ioff_j][c])
+ * with zeros where t+dt_j < 0 or the frequency index leaves [0, Fin), f an
+ * optional fused InstanceNorm-affine/PReLU, src an optional channel
+ * concatenation of two tensors, followed by a fused epilogue and optional
+ * per-(b,channel) sum / sum-of-squares partials for the NEXT InstanceNorm.
+ * Covers
+ *   GateConv2d           EaBNet.py:449-450,459-460   (pad + Conv2d + GLU)
+ *   GateConvTranspose2d  EaBNet.py:478-480,489-490   (two launches: even / odd fo)
+ *   Conv2dunit conv      EaBNet.py:402               Deconv2dunit deconv  :423,425
+ *   torch.cat skips      EaBNet.py:275,277,502       (src0|src1)
+ *   SqueezedTCM convs    EaBNet.py:549,558,564,570,575,577
+ *   w_dnn[0] + ReLU      EaBNet.py:594-595
+ * ------------------------------------------------------------------------ */
+#define EAB_MAX_TAPS 16
+
+#define EAB_XF_NONE       0   /* f(x) = x                                   */
+#define EAB_XF_NORM_PRELU 1   /* f(x) = prelu(x*scale + shift)   (2-D units) */
+#define EAB_XF_PRELU_NORM 2   /* f(x) = prelu(x)*scale + shift   (S-TCM)     */
+
+#define EAB_EPI_LINEAR  0     /* out = acc                                   */
+#define EAB_EPI_GLU     1     /* out[c] = acc[c] * sigmoid(acc[N/2 + c])     */
+#define EAB_EPI_RELU    2     /* out = max(acc, 0)                           */
+#define EAB_EPI_MULSIG  3     /* out = aux * sigmoid(acc)    (S-TCM gate)    */
+#define EAB_EPI_ADD     4     /* out = acc + aux             (residual)      */
+
+typedef struct eab_conv_desc {
+    /* sources, channels-last [B][T][Fin][C*]; src1 == NULL when there is no concat */
+    const float* src0;
+    const float* src1;
+    const float* xf0;       /* [B][C0][2] (scale, shift) or NULL */
+    const float* xf1;       /* [B][C1][2] or NULL */
+    const float* slope0;    /* [C0] PReLU slope or NULL (required with xf*) */
+    const float* slope1;
+    int32_t C0, C1;         /* C1 = 0 without src1; with src1, C0 % 16 == 0 */
+    int32_t xf_mode;        /* EAB_XF_* applied to sources that have a table */
+    /* weights, packed by the host: w[n][u*16 + i], unit u = tap*UPT + c/16,
+     * UPT = ceil((C0+C1)/16), zero padded; Kpad = ntaps*UPT*16.
+     * For EAB_EPI_GLU rows are interleaved in 32-row groups:
+     * packed row r -> original row (r%64/32)*(N/2) + (r/64)*32 + r%32. */
+    const float* w;
+    const float* bias;      /* [N] in packed row order, or NULL */
+    int32_t N, Kpad;
+    /* geometry */
+    int32_t B, T, Fin, Fout;
+    int32_t No;             /* output columns per time row computed by this launch */
+    int32_t ostride, ophase, istride;
+    int32_t ntaps;
+    int32_t dt[EAB_MAX_TAPS];    /* <= 0 */
+    int32_t ioff[EAB_MAX_TAPS];
+    /* epilogue */
+    int32_t epi;
+    const float* aux;       /* [B][T][Fout][Cout], EAB_EPI_MULSIG / EAB_EPI_ADD */
+    float* dst;             /* [B][T][Fout][Cout] */
+    float* dst_acc;         /* optional running sum: dst_acc += out (same layout) */
+    int32_t Cout;           /* N/2 for GLU, else N */
+    /* statistics for the consumer's InstanceNorm: per tile, per set s, per
+     * channel c: (sum g_s(out), sum g_s(out)^2), g_s = PReLU(stat_slope[s]) or id.
+     * stats[((b*stat_tiles + stat_tile0 + tile)*nsets + s)*Cout + c][2] */
+    float* stats;
+    int32_t nsets;          /* 0, 1 or 2 */
+    const float* stat_slope0;
+    const float* stat_slope1;
+    int32_t stat_tiles;     /* tiles per batch element over ALL launches feeding this norm */
+    int32_t stat_tile0;     /* first tile index of this launch */
+    int32_t bm;             /* rows per tile: 64 or 128 (host's choice, see eab_conv_tiles) */
+} eab_conv_desc;
+
+/* number of tiles per batch element a launch with this geometry produces */
+int eab_conv_tiles(int T, int No, int bm);
+int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream);
+
+/* --------------------------------------------------------------------------
+ * K8 (statistics half)  InstanceNorm finalisation.  Replaces the reduction in
+ * nn.InstanceNorm{1,2}d(affine=True), EaBNet.py:684,686 (eps 1e-5, biased var).
+ * Reduces the partials written by eab_conv_f32 (fp64 accumulation, fixed order
+ * => bit-reproducible) and emits, per set s, xf_s[b][c] = (scale, shift) with
+ *   scale = gamma_s[c] / sqrt(var + eps), shift = beta_s[c] - mean*scale.
+ * ------------------------------------------------------------------------ */
+int eab_in_finalize_f32(const float* stats, int B, int C, int nsets, int stat_tiles,
+                        int count /* T*F positions per (b,c) */, float eps,
+                        const float* gamma0, const float* beta0, float* xf0,
+                        const float* gamma1, const float* beta1, float* xf1,
+                        eab_stream_t stream);
+
+/* --------------------------------------------------------------------------
+ * K8 (apply half) + K14 residual.  out = prelu(a*sa+ha) [+ prelu(b*sb+hb)].
+ * Replaces the affine+PReLU of EaBNet.py:187-188,356-357 and the residual add
+ * of En_unet_module.forward, EaBNet.py:386, where the sum must be materialised.
+ *   a, b, out [B][P][C] (P = T*F positions); b may be NULL.
+ * ------------------------------------------------------------------------ */
+int eab_norm_act_f32(const float* a, const float* xfa, const float* slopea,
+                     const float* b, const float* xfb, const float* slopeb,
+                     float* out, int B, int P, int C, eab_stream_t stream);
+
+/* --------------------------------------------------------------------------
+ * K10+K11  LayerNorm + one LSTM layer over time for B*F independent sequences.
+ * Replaces EaBNet.py:608 (permute + LayerNorm(64)) and one nn.LSTM(64->64,
+ * batch_first, zero initial state) of EaBNet.py:610-611.
+ *   x      [B][T][F][64]   sequence (b,f) reads x[b][t][f][:]
+ *   ln_g/b [64] or NULL    (NULL: no LayerNorm -- second layer)
+ *   wcat   [256][128]      row g*64+u (gate order i,f,g,o) = [W_ih[row][0:64] | W_hh[row][0:64]]
+ *   bias   [256]           b_ih + b_hh
+ *   h_out  [B][T][F][64]
+ * Hidden size and input size are fixed at 64 (reference default hid_node).
+ * ------------------------------------------------------------------------ */
+int eab_lstm64_f32(const float* x, const float* ln_g, const float* ln_b, float ln_eps,
+                   const float* wcat, const float* bias, float* h_out,
+                   int B, int T, int F, eab_stream_t stream);
+
+/* --------------------------------------------------------------------------
+ * K12(second Linear)+K13  beam-forming weights + filter-and-sum, fused.
+ * Replaces w_dnn[2] (EaBNet.py:596,613) and EaBNet.py:114-117.  The per-bin
+ * weights never reach HBM.
+ *   y1 [B][T][F][64]  (ReLU output of w_dnn[0]), w2 [2M][64], b2 [2M],
+ *   x [B][T][F][M][2] (the network input), out [B][2][T][F].
+ *   bfw: optional [B][T][F][M][2] dump of the weights (NULL in production).
+ * ------------------------------------------------------------------------ */
+int eab_bfw_filter_sum_f32(const float* y1, const float* w2, const float* b2, const float* x,
+                           float* out, float* bfw, int B, int T, int F, int M,
+                           eab_stream_t stream);
+
+/* --------------------------------------------------------------------------
+ * Program runner: the whole EaBNet.forward (EaBNet.py:88-117) as ONE call.
+ * The host builds the op list once per (weights, B, T); replaying it costs one
+ * FFI crossing and no Python per layer, and can be captured in a hipGraph.
+ * ------------------------------------------------------------------------ */
+#define EAB_OP_CONV        1
+#define EAB_OP_IN_FINALIZE 2
+#define EAB_OP_NORM_ACT    3
+#define EAB_OP_LSTM64      4
+#define EAB_OP_BFW_FS      5
+#define EAB_OP_MEMSET0     6
+
+typedef struct eab_op {
+    int32_t kind;
+    int32_t i[8];
+    float   f[2];
+    const void* p[10];
+    eab_conv_desc conv;     /* EAB_OP_CONV only */
+} eab_op;
+/* field use per kind:
+ *  IN_FINALIZE i = {B, C, nsets, stat_tiles, count}       f = {eps}
+ *              p = {stats, gamma0, beta0, xf0, gamma1, beta1, xf1}
+ *  NORM_ACT    i = {B, P, C}  p = {a, xfa, slopea, b, xfb, slopeb, out}
+ *  LSTM64      i = {B, T, F}  f = {ln_eps}  p = {x, ln_g, ln_b, wcat, bias, h_out}
+ *  BFW_FS      i = {B, T, F, M}  p = {y1, w2, b2, x, out, bfw}
+ *  MEMSET0     p = {ptr}  i = {bytes_lo, bytes_hi}
+ */
+int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream);
+
+/* struct-layout handshake for foreign-function mirrors of the structs above */
+int eab_sizeof_conv_desc(void);
+int eab_sizeof_op(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EABNET_HIP_H */

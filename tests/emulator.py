@@ -1,0 +1,172 @@
+"""numpy interpreter of an eabnet_amd.program.Program  (TEST INFRASTRUCTURE).
+
+Executes the SAME op list, packed-weight arena and workspace plan that
+libeabnet_hip.so receives, following the semantics documented in
+include/eabnet_hip.h, so the host-side lowering (weight packing, taps/phases of
+the transposed convolutions, channel permutations, schedule, buffer plan) can
+be verified against the oracle on a machine without a GPU.  It deliberately
+mirrors the kernels' tiling of the InstanceNorm partial sums.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from eabnet_amd import program as prg
+
+
+def _sig(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def _prelu(x, a):
+    return np.where(x > 0, x, a * x)
+
+
+class Emulator:
+    def __init__(self, prog: prg.Program, x_in: np.ndarray):
+        self.p = prog
+        B, T, F = prog.B, prog.T, prog.F
+        self.arena = {
+            "w": prog.weights.astype(np.float32),
+            "a": np.full(prog.act_floats, np.nan, dtype=np.float32),   # NaN-poisoned: reads of unwritten memory show
+            "in": np.ascontiguousarray(x_in, dtype=np.float32).reshape(-1),
+            "out": np.full(B * 2 * T * F, np.nan, dtype=np.float32),
+        }
+
+    def v(self, ref, shape):
+        if ref is None:
+            return None
+        n = int(np.prod(shape))
+        return self.arena[ref.arena][ref.off:ref.off + n].reshape(shape)
+
+    # ------------------------------------------------------------------ ops
+    def conv(self, op: prg.ConvOp):
+        B, T, Fin, No = op.B, op.T, op.Fin, op.No
+        srcs = []
+        for ref, xf, sl, Cs in ((op.src0, op.xf0, op.slope0, op.C0), (op.src1, op.xf1, op.slope1, op.C1)):
+            if ref is None:
+                continue
+            x = self.v(ref, (B, T, Fin, Cs)).astype(np.float32)
+            if xf is not None and op.xf_mode != prg.XF_NONE:
+                tab = self.v(xf, (B, Cs, 2))
+                s, h = tab[:, None, None, :, 0], tab[:, None, None, :, 1]
+                a = self.v(sl, (Cs,))
+                x = _prelu(x * s + h, a) if op.xf_mode == prg.XF_NORM_PRELU else _prelu(x, a) * s + h
+            srcs.append(x)
+        X = np.concatenate(srcs, axis=-1)
+        Ct = X.shape[-1]
+        upt = (Ct + 15) // 16
+        ntaps = len(op.dt)
+        assert op.Kpad == ntaps * upt * 16
+        W = self.v(op.w, (op.N, ntaps, upt * 16))
+        assert not np.any(W[:, :, Ct:]), "padding columns of the packed weights must be zero"
+        acc = np.zeros((B, T, No, op.N), dtype=np.float32)
+        if op.bias is not None:
+            acc += self.v(op.bias, (op.N,))
+        o = np.arange(No)
+        for j in range(ntaps):
+            dt, fi = op.dt[j], o * op.istride + op.ioff[j]
+            assert dt <= 0
+            ok = (fi >= 0) & (fi < Fin)
+            G = np.zeros((B, T, No, Ct), dtype=np.float32)
+            tv = T + dt
+            if tv > 0:
+                G[:, -dt:, ok] = X[:, :tv][:, :, fi[ok]]
+            acc += G @ W[:, j, :Ct].T
+        if op.epi == prg.EPI_GLU:
+            c = np.arange(op.N // 2)
+            rv = (c // 32) * 64 + c % 32
+            out = acc[..., rv] * _sig(acc[..., rv + 32])
+        else:
+            out = acc
+        Cout = out.shape[-1]
+        assert Cout == op.Cout
+        dst = self.v(op.dst, (B, T, op.Fout, Cout))
+        fo = o * op.ostride + op.ophase
+        if op.epi == prg.EPI_RELU:
+            out = np.maximum(out, 0)
+        elif op.epi == prg.EPI_MULSIG:
+            out = self.v(op.aux, (B, T, op.Fout, Cout))[:, :, fo] * _sig(out)
+        elif op.epi == prg.EPI_ADD:
+            out = out + self.v(op.aux, (B, T, op.Fout, Cout))[:, :, fo]
+        dst[:, :, fo] = out
+        if op.dst_acc is not None:
+            self.v(op.dst_acc, (B, T, op.Fout, Cout))[:, :, fo] += out
+        if op.stats is not None:
+            st = self.v(op.stats, (B, op.stat_tiles, op.nsets, Cout, 2))
+            rows = out.reshape(B, T * No, Cout)
+            tiles = prg.conv_tiles(T, No, op.bm)
+            for s, slr in enumerate((op.stat_slope0, op.stat_slope1)[:op.nsets]):
+                g = rows if slr is None else _prelu(rows, self.v(slr, (Cout,)))
+                for t in range(tiles):
+                    blk = g[:, t * op.bm:(t + 1) * op.bm].astype(np.float32)
+                    st[:, op.stat_tile0 + t, s, :, 0] = blk.sum(1)
+                    st[:, op.stat_tile0 + t, s, :, 1] = (blk * blk).sum(1)
+
+    def finalize(self, op: prg.FinalizeOp):
+        st = self.v(op.stats, (op.B, op.stat_tiles, op.nsets, op.C, 2)).astype(np.float64)
+        assert not np.isnan(st).any(), f"{op.name}: statistics partials not fully written"
+        for s, (g, b, xf) in enumerate(((op.gamma0, op.beta0, op.xf0), (op.gamma1, op.beta1, op.xf1))[:op.nsets]):
+            tot = st[:, :, s].sum(1)
+            mean = tot[..., 0] / op.count
+            var = np.maximum(tot[..., 1] / op.count - mean * mean, 0)
+            scale = self.v(g, (op.C,)) / np.sqrt(var + op.eps)
+            shift = self.v(b, (op.C,)) - mean * scale
+            out = self.v(xf, (op.B, op.C, 2))
+            out[..., 0], out[..., 1] = scale, shift
+
+    def norm_act(self, op: prg.NormActOp):
+        def f(ref, xf, sl):
+            tab = self.v(xf, (op.B, op.C, 2))
+            return _prelu(self.v(ref, (op.B, op.P, op.C)) * tab[:, None, :, 0] + tab[:, None, :, 1], self.v(sl, (op.C,)))
+        r = f(op.a, op.xfa, op.slopea)
+        if op.b is not None:
+            r = r + f(op.b, op.xfb, op.slopeb)
+        self.v(op.out, (op.B, op.P, op.C))[:] = r
+
+    def lstm(self, op: prg.LstmOp):
+        B, T, F = op.B, op.T, op.F
+        x = self.v(op.x, (B, T, F, 64)).astype(np.float32)
+        if op.ln_g is not None:
+            mu = x.mean(-1, keepdims=True)
+            var = ((x - mu) ** 2).mean(-1, keepdims=True)
+            x = (x - mu) / np.sqrt(var + op.ln_eps) * self.v(op.ln_g, (64,)) + self.v(op.ln_b, (64,))
+        W, bias = self.v(op.wcat, (256, 128)), self.v(op.bias, (256,))
+        h = np.zeros((B, F, 64), np.float32)
+        c = np.zeros((B, F, 64), np.float32)
+        out = self.v(op.h_out, (B, T, F, 64))
+        for t in range(T):
+            g = np.concatenate([x[:, t], h], -1) @ W.T + bias
+            i, f, gg, o = np.split(g, 4, -1)
+            c = _sig(f) * c + _sig(i) * np.tanh(gg)
+            h = (_sig(o) * np.tanh(c)).astype(np.float32)
+            out[:, t] = h
+
+    def bfw(self, op: prg.BfwOp):
+        B, T, F, M = op.B, op.T, op.F, op.M
+        y1 = self.v(op.y1, (B, T, F, 64))
+        w = y1 @ self.v(op.w2, (2 * M, 64)).T + self.v(op.b2, (2 * M,))
+        w = w.reshape(B, T, F, M, 2)
+        if op.bfw is not None:
+            self.v(op.bfw, (B, T, F, M, 2))[:] = w
+        x = self.v(op.x, (B, T, F, M, 2))
+        out = self.v(op.out, (B, 2, T, F))
+        out[:, 0] = (w[..., 0] * x[..., 0] - w[..., 1] * x[..., 1]).sum(-1)
+        out[:, 1] = (w[..., 0] * x[..., 1] + w[..., 1] * x[..., 0]).sum(-1)
+
+    def step(self, op):
+        with np.errstate(over="ignore"):
+            {prg.OP_CONV: self.conv, prg.OP_IN_FINALIZE: self.finalize, prg.OP_NORM_ACT: self.norm_act,
+             prg.OP_LSTM64: self.lstm, prg.OP_BFW_FS: self.bfw,
+             prg.OP_MEMSET0: lambda o: self.v(o.ptr, (o.nfloats,)).fill(0)}[op.kind](op)
+
+    def run(self):
+        for op in self.p.ops:
+            self.step(op)
+        p = self.p
+        return self.arena["out"].reshape(p.B, 2, p.T, p.F)
+
+    def act(self, a: prg.Act) -> np.ndarray:
+        """Named activation as NCHW (B, C, T, F) like the reference's hooks."""
+        p = self.p
+        return self.v(a.ref, (p.B, p.T, a.F, a.C)).transpose(0, 3, 1, 2)

@@ -1,0 +1,84 @@
+"""Host-side lowering (eabnet_amd/program.py) checked on CPU: the op program is
+interpreted with numpy (tests/emulator.py) and compared with the oracle and the
+reference fixtures.  Covers weight packing, transposed-conv phases, channel
+permutations, the schedule and the workspace plan -- everything except the
+device code itself (that is tests/test_hip_parity.py, -m gpu)."""
+import numpy as np
+import pytest
+import torch
+
+import paramgen
+from eabnet_amd import program as prg
+from eabnet_amd.spec import NetConfig, param_specs
+from emulator import Emulator
+from oracle import eabnet_oracle as orc
+from util import assert_close, load
+
+TOL_EMU = 1e-4     # same bar as the HIP path (BASELINE.json north_star)
+
+
+def _params(M, seed, **kw):
+    return paramgen.make_params(param_specs(NetConfig(M=M, **kw)), seed)
+
+
+def test_emulated_program_matches_reference_taps():
+    g = load("e2e_M8_B1_T12_taps.npz")
+    P = _params(8, int(g["param_seed"]))
+    x = paramgen.make_spec_input(1, 12, 161, 8, int(g["input_seed"]))
+    prog = prg.lower(NetConfig(M=8), P, 1, 12, 161, dump_bfw=True)
+    emu = Emulator(prog, x)
+    y = emu.run()
+    names = {"en.0": "en.meta_unet_list.0", "en.1": "en.meta_unet_list.1", "en.2": "en.meta_unet_list.2",
+             "en.3": "en.meta_unet_list.3", "en.4": "en.last_conv", "de.0": "de.meta_unet_list.0",
+             "de.1": "de.meta_unet_list.1", "de.2": "de.meta_unet_list.2", "de.3": "de.meta_unet_list.3",
+             "de.4": "de.last_conv"}
+    for ref_name, mine in names.items():
+        assert_close(emu.act(prog.taps[mine]), g["tap/" + ref_name], TOL_EMU, ref_name)
+    # S-TCM output: reference layout (B, 256, T) with channel c*4+f; ours [B][T][f*64+c]
+    t0 = emu.v(prog.taps["stcns.0.0"].ref, (1, 12, 4, 64)).transpose(0, 3, 2, 1).reshape(1, 256, 12)
+    assert_close(t0, g["tap/stcns.0.0"], TOL_EMU, "stcns.0.0")
+    for nm in ("rnn1", "rnn2"):
+        h = emu.v(prog.taps[f"bf_map.{nm}"].ref, (1, 12, 161, 64)).transpose(0, 2, 1, 3).reshape(161, 12, 64)
+        assert_close(h, g["tap/" + nm], TOL_EMU, nm)
+    assert_close(emu.v(prog.taps["bf_w"].ref, (1, 12, 161, 8, 2)), g["tap/bf_w"], TOL_EMU, "bf_w")
+    assert_close(y, g["out"], TOL_EMU, "out")
+    assert not np.isnan(y).any()
+
+
+@pytest.mark.parametrize("M,name,T", [(9, "e2e_M9_B1_T10.npz", 10), (1, "e2e_M1_B1_T10.npz", 10)])
+def test_emulated_other_mic_counts(M, name, T):
+    g = load(name)
+    P = _params(M, int(g["param_seed"]))
+    x = paramgen.make_spec_input(1, T, 161, M, int(g["input_seed"]))
+    y = Emulator(prg.lower(NetConfig(M=M), P, 1, T, 161), x).run()
+    assert_close(y, g["out"], TOL_EMU)
+
+
+def test_emulated_batch2_small_pq_matches_oracle():
+    """batch > 1, T not a multiple of anything, p/q away from the defaults, tile
+    boundaries inside the utterance (T*No > 128)."""
+    cfg = NetConfig(M=4, p=3, q=2)
+    P = _params(4, 31, p=3, q=2)
+    x = paramgen.make_spec_input(2, 37, 161, 4, 32)
+    y = Emulator(prg.lower(cfg, P, 2, 37, 161), x).run()
+    with torch.no_grad():
+        ref = orc.eabnet_forward({k: torch.from_numpy(v) for k, v in P.items()}, torch.from_numpy(x), p=3, q=2)
+    assert_close(y, ref.numpy(), TOL_EMU)
+
+
+def test_flop_count_close_to_survey_formula():
+    """MAC/frame = 44,404,736 + 222,848*M (hooks over the reference).
+    The gather form also multiplies the structural zeros at the transposed convs'
+    edges, so the program's count is slightly higher, never lower."""
+    M, B, T = 8, 1, 16
+    prog = prg.lower(NetConfig(M=M), _params(M, 1), B, T, 161)
+    per_frame = prog.flops / (B * T)
+    ref = 2 * (44_404_736 + 222_848 * M)
+    assert ref <= per_frame <= 1.03 * ref, (per_frame, ref)
+
+
+def test_unsupported_topologies_raise():
+    for kw in (dict(norm_type="BN"), dict(is_u2=False), dict(bf_type="cnn"), dict(topo_type="miso"),
+               dict(intra_connect="add"), dict(is_causal=False)):
+        with pytest.raises(NotImplementedError):
+            param_specs(NetConfig(M=8, **kw))
