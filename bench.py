@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""Headline benchmark: enhanced STFT frames/s of the EaBNet hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of synthetic input that is
+already resident in HBM: (B, M, L) waves -> fused STFT/compression ->
+EaBNet.forward -> (B, 2, T, F).  Workload = BASELINE.json configs[1]/[2]
+(batch of 16 four-second 8-mic 16 kHz utterances per GPU, fp32, full
+hand-written HIP path).  Utterances are independent, so N GPUs run N
+independent shards (weak scaling, no data-path collective).
+
+Prints ONE JSON line on rank 0 (see the keys below); `roofline` is measured in
+an instrumented replay (HIP events around every op of the program, on the
+stream the kernels run on) right after the timed region, `cpu_baseline` times
+the oracle (oracle/eabnet_oracle.py, test infrastructure) on the host cores on
+a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import eabnet_amd  # noqa: E402
+from eabnet_amd import program as prg  # noqa: E402
+
+B_PER_GPU, MICS, SR, SECONDS = 16, 8, 16000, 4.0
+N_FFT, HOP = 320, 160
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak (= vector peak)
+PEAK_HBM_GBS = 8000.0
+
+
+def mac_per_frame(M: int) -> int:
+    """SURVEY §0 / BASELINE.md: conv + linear + LSTM-gate MACs per STFT frame."""
+    return 44_404_736 + 222_848 * M
+
+
+def conv_kernel_mac_per_frame(M: int) -> int:
+    """The share executed by conv_gemm_kernel: everything except the two LSTM
+    layers (2*161*256*128) and w_dnn[2] (161*64*2M)."""
+    return mac_per_frame(M) - 2 * 161 * 256 * 128 - 161 * 64 * 2 * M
+
+
+def make_model(M: int, device, seed: int = 0):
+    torch.manual_seed(seed)
+    net = eabnet_amd.EaBNet(M=M).eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():                      # norm / PReLU parameters away from 1 / 0 / 0.25
+        for n, p in net.named_parameters():
+            if n.endswith("norm.weight"):
+                p.copy_(torch.empty_like(p).uniform_(0.5, 1.5, generator=g))
+            elif n.endswith("norm.bias"):
+                p.copy_(torch.empty_like(p).uniform_(-0.3, 0.3, generator=g))
+    state = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    return net.to(device), state
+
+
+def synth_waves(B: int, M: int, L: int, seed: int) -> torch.Tensor:
+    g = torch.Generator().manual_seed(seed)
+    return 0.05 * torch.randn(B, M, L, generator=g)
+
+
+def instrumented_replay(net, ns, reps: int):
+    """Per-op device time with HIP events on the launch stream.  A spin kernel
+    keeps the GPU busy while the host enqueues, so that event timestamps bracket
+    kernels and not host latency."""
+    bound = net._last[0]
+    ops = bound.prog.ops
+    stream = torch.cuda.current_stream()
+    totals = np.zeros(len(ops))
+    for _ in range(reps):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(ops) + 1)]
+        torch.cuda._sleep(int(4e8))
+        for k in range(len(ops)):
+            evs[k].record(stream)
+            bound.run(stream.cuda_stream, k, 1)
+        evs[-1].record(stream)
+        torch.cuda.synchronize()
+        totals += np.array([evs[k].elapsed_time(evs[k + 1]) for k in range(len(ops))])
+    return ops, totals / reps            # ms per op
+
+
+def cpu_baseline(state, M: int, L: int, budget_s: float = 20.0):
+    """Oracle on the host cores (kind "port"): B=2 utterances of the same shape,
+    repeated until ~budget_s of CPU work, best pass reported."""
+    from oracle import eabnet_oracle as orc          # test infrastructure: checker / baseline only
+    Bc = 2
+    wav = synth_waves(Bc, M, L, 4321)
+    T = 1 + L // HOP
+    best, spent, passes = float("inf"), 0.0, 0
+    with torch.no_grad():
+        while passes < 2 or (spent < budget_s and passes < 8):
+            t0 = time.perf_counter()
+            ns, _ = orc.prepare_data_oracle(wav, None, N_FFT, HOP, N_FFT)
+            orc.eabnet_forward(state, ns, fast_lstm=True)
+            dt = time.perf_counter() - t0
+            best, spent, passes = min(best, dt), spent + dt, passes + 1
+    return {"value": Bc * T / best, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{Bc} utterances x {SECONDS:.0f} s x {M} mics (T={T}), best of {passes} passes, "
+                      f"{spent:.1f} s CPU total; oracle = PyTorch-CPU (ATen/oneDNN) restatement"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+    dist = world > 1
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if dist:
+        import torch.distributed as td
+        td.init_process_group("nccl", device_id=dev)       # RCCL; only barriers and one scalar MAX
+
+    L = int(SECONDS * SR)
+    T = 1 + L // HOP
+    net, state = make_model(MICS, dev)
+    wav = synth_waves(B_PER_GPU, MICS, L, 1234 + rank).to(dev)    # resident in HBM before timing
+    window = torch.hann_window(N_FFT)
+
+    def step():
+        ns = eabnet_amd.stft_compress(wav, N_FFT, HOP, window)
+        return net(ns), ns
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            y, ns = step()
+        torch.cuda.synchronize()
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            y, ns = step()
+        torch.cuda.synchronize()
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    assert torch.isfinite(y).all()
+    if dist:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    frames = world * B_PER_GPU * T * a.steps
+    out = {
+        "metric": "enhanced frames/sec (16 kHz, 8-mic) at 1/2/4/8 MI355X; RTF per utterance",
+        "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]/[2]: batch of 16 four-second 8-mic 16 kHz utterances per GPU, "
+                               "wave -> STFT+compress -> EaBNet.forward, inference, full hand-written HIP path",
+                   "batch_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU, "mics": MICS, "frames_per_utt": T,
+                   "freq_bins": N_FFT // 2 + 1, "parallelism": f"dp{world} (independent shards, no collective)"},
+        "rtf_per_utterance": elapsed / a.steps / (B_PER_GPU * SECONDS),
+        "gflop_per_step_algorithmic": 2e-9 * mac_per_frame(MICS) * B_PER_GPU * T,
+    }
+
+    if rank == 0 and not a.no_roofline:
+        with torch.no_grad():
+            ops, ms = instrumented_replay(net, ns, reps=3)
+        conv = [k for k, o in enumerate(ops) if o.kind == prg.OP_CONV]
+        conv_ms = float(ms[conv].sum())
+        conv_flop = 2.0 * conv_kernel_mac_per_frame(MICS) * B_PER_GPU * T
+        achieved = conv_flop / (conv_ms * 1e-3) / 1e12
+        by_kind = {}
+        for k, o in enumerate(ops):
+            nm = {prg.OP_CONV: "conv_gemm", prg.OP_IN_FINALIZE: "in_finalize", prg.OP_NORM_ACT: "norm_act",
+                  prg.OP_LSTM64: "lstm64", prg.OP_BFW_FS: "bfw_filter_sum", prg.OP_MEMSET0: "memset"}[o.kind]
+            by_kind[nm] = by_kind.get(nm, 0.0) + float(ms[k])
+        out["roofline"] = {
+            "kernel": "conv_gemm_kernel (all instances; gather-GEMM convolution on v_mfma_f32_32x32x2_f32)",
+            "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "launches_per_step": len(conv), "avg_launch_ms": conv_ms / len(conv),
+            "algorithmic_gflop_per_launch": conv_flop / len(conv) / 1e9,
+            "program_ms_by_kernel": {k: round(v, 4) for k, v in sorted(by_kind.items(), key=lambda kv: -kv[1])},
+            "program_ms_total": float(ms.sum()),
+            "note": "achieved = algorithmic conv FLOPs per step / summed conv launch time (HIP events per op, "
+                    "instrumented replay after the timed region)",
+        }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(state, MICS, L)
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out))
+    if dist:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
