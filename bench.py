@@ -97,6 +97,10 @@ def cpu_baseline(state, M: int, L: int, budget_s: float = 20.0):
     Bc = 2
     wav = synth_waves(Bc, M, L, 4321)
     T = 1 + L // HOP
+    # a 1-GPU box exposes every host CPU but the job's share is 16 cores
+    # (oversubscribing oneDNN with 128 threads ran 6x slower): use min(16, visible)
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(min(16, ncpu))
     best, spent, passes = float("inf"), 0.0, 0
     with torch.no_grad():
         while passes < 2 or (spent < budget_s and passes < 8):
@@ -105,9 +109,11 @@ def cpu_baseline(state, M: int, L: int, budget_s: float = 20.0):
             orc.eabnet_forward(state, ns, fast_lstm=True)
             dt = time.perf_counter() - t0
             best, spent, passes = min(best, dt), spent + dt, passes + 1
+            print(f"[bench] cpu_baseline pass {passes}: {dt:.2f} s", file=sys.stderr, flush=True)
     return {"value": Bc * T / best, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{Bc} utterances x {SECONDS:.0f} s x {M} mics (T={T}), best of {passes} passes, "
-                      f"{spent:.1f} s CPU total; oracle = PyTorch-CPU (ATen/oneDNN) restatement"}
+                      f"{spent:.1f} s CPU total; oracle = PyTorch-CPU (ATen/oneDNN) restatement; "
+                      f"{ncpu} CPUs visible, 16-core job share"}
 
 
 def main():
@@ -117,6 +123,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--per-op", type=str, default="", help="write the per-op timing table (instrumented replay) here")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,6 +191,15 @@ def main():
         conv_ms = float(ms[conv].sum())
         conv_flop = 2.0 * conv_kernel_mac_per_frame(MICS) * B_PER_GPU * T
         achieved = conv_flop / (conv_ms * 1e-3) / 1e12
+        if a.per_op:
+            with open(a.per_op, "w") as f:
+                f.write("idx kind ms gflop tflops name geometry\n")
+                for k, o in enumerate(ops):
+                    gf, geo = 0.0, ""
+                    if o.kind == prg.OP_CONV:
+                        gf = 2e-9 * o.B * o.T * o.No * o.N * len(o.dt) * (o.C0 + o.C1)
+                        geo = f"N={o.N} C={o.C0}+{o.C1} taps={len(o.dt)} Fin={o.Fin} No={o.No} bm={o.bm} xf={o.xf_mode} epi={o.epi} sets={o.nsets}"
+                    f.write(f"{k} {o.kind} {ms[k]:.4f} {gf:.3f} {gf / max(ms[k], 1e-9):.2f} {o.name} {geo}\n")
         by_kind = {}
         for k, o in enumerate(ops):
             nm = {prg.OP_CONV: "conv_gemm", prg.OP_IN_FINALIZE: "in_finalize", prg.OP_NORM_ACT: "norm_act",

@@ -9,45 +9,49 @@
 //   K       = taps x input channels, walked in "units" of 16 channels of one tap:
 //             a unit of one row is 64 contiguous bytes of a channels-last source.
 //
-// Workgroup = 4 waves (2x2), wave tile (32*MI) x (32*NI), BK = 16.
-// LDS tiles are [rows][16+4] floats: the +4 (one ds_read_b128 width) makes the
-// 16-byte-slot stride odd (5), so the 64 lanes' fragment reads are conflict free
-// (MI355X_MICROARCH §LDS).  Lane (i = l&31, h = l>>5) reads floats
-// [8g+4h, 8g+4h+4) of its row as ONE ds_read_b128 and feeds them to four
-// successive MFMA k-steps; A and B use the same k permutation, so the sum is
-// unchanged.
+// Workgroup = 4 waves (2x2), wave tile (32*MI) x (32*NI); KU units (16*KU of K)
+// per pipeline stage.  LDS tiles are [rows][16*KU+4] floats: the +4 (one
+// ds_read_b128 width) makes the 16-byte-slot stride odd, so the 64 lanes'
+// fragment reads are conflict free (MI355X_MICROARCH §LDS).  Lane (i = l&31,
+// h = l>>5) reads floats [8g+4h, 8g+4h+4) of its row as ONE ds_read_b128 and feeds
+// them to four successive MFMA k-steps; A and B use the same k permutation, so
+// the sum is unchanged.
 //
-// Pipeline: unit u+1 is fetched global->registers while unit u is multiplied;
-// the fused producer-side InstanceNorm affine + PReLU is applied on the way
-// registers->LDS; one barrier per unit, two LDS buffers.
+// Straight-line main loop: gathers are raw buffer loads whose descriptor spans
+// ONE batch element of the source; a tap that falls outside the tensor (t+dt < 0,
+// f outside [0,Fin), rows past the tile end) gets an out-of-range offset and the
+// hardware returns 0 -- no exec-mask branches, so the compiler can keep the
+// stage-(s+1) loads in flight across the MFMAs of stage s.  The producer's
+// InstanceNorm affine + PReLU (compile-time XF) is applied registers->LDS.
 //
 // fp32-in MFMA is exact fp32 (fmaf chain), 64 FLOP/clk/SIMD: one MFMA occupies
-// its SIMD for 64 cycles while the wave needs one A and one B VGPR for it, so
-// LDS and staging traffic are far below their limits and the kernel is bound by
-// the matrix pipe (roofline: "mfma", fp32 dense 157.3 TFLOP/s).
+// its SIMD for 64 cycles while needing one A and one B VGPR, so LDS and staging
+// traffic are far below their limits: roofline "mfma", fp32 dense 157.3 TFLOP/s.
 #include "common.h"
 
 #define CG_THREADS 256
-#define CG_BK 16
-#define CG_LDK 20   // padded LDS row (floats)
+#define CG_OOB 0x80000000u   // > any legal byte offset inside one batch element (host checks < 2^31)
 
-template <int MI, int NI>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int MI, int NI, int KU>
 struct CgSmem {
-    static constexpr int BM = 64 * MI, BN = 64 * NI;
-    float a[2][BM * CG_LDK];
-    float b[2][BN * CG_LDK];
+    static constexpr int BM = 64 * MI, BN = 64 * NI, LDK = 16 * KU + 4;
+    float a[2][BM * LDK];
+    float b[2][BN * LDK];
     int dt[EAB_MAX_TAPS];
     int ioff[EAB_MAX_TAPS];
 };
 
-__device__ __forceinline__ f32x4 cg_xform(f32x4 v, f32x4 sh01, f32x4 sh23, f32x4 sl, int mode) {
+template <int XF>
+__device__ __forceinline__ f32x4 cg_xform(f32x4 v, f32x4 sh01, f32x4 sh23, f32x4 sl) {
     // sh01 = (scale0, shift0, scale1, shift1), sh23 likewise for channels 2,3
     const float sc[4] = {sh01[0], sh01[2], sh23[0], sh23[2]};
     const float sf[4] = {sh01[1], sh01[3], sh23[1], sh23[3]};
     f32x4 r;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if (mode == EAB_XF_NORM_PRELU)
+        if (XF == EAB_XF_NORM_PRELU)
             r[j] = eab_prelu(fmaf(v[j], sc[j], sf[j]), sl[j]);
         else
             r[j] = fmaf(eab_prelu(v[j], sl[j]), sc[j], sf[j]);
@@ -55,10 +59,21 @@ __device__ __forceinline__ f32x4 cg_xform(f32x4 v, f32x4 sh01, f32x4 sh23, f32x4
     return r;
 }
 
-template <int MI, int NI, bool GLU>
+__device__ __forceinline__ float cg_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+// q / n for 0 <= q < 2^22 via the fp32 reciprocal, exact after one correction
+__device__ __forceinline__ int cg_div(int q, int n, float inv_n) {
+    int t = (int)((float)q * inv_n);
+    if (t * n > q) --t;
+    if ((t + 1) * n <= q) ++t;
+    return t;
+}
+
+template <int MI, int NI, int KU, bool GLU, int XF, bool VEC>
 __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_desc d) {
-    constexpr int BM = 64 * MI, BN = 64 * NI;
-    __shared__ __attribute__((aligned(16))) CgSmem<MI, NI> sm;
+    using Smem = CgSmem<MI, NI, KU>;
+    constexpr int BM = Smem::BM, BN = Smem::BN, LDK = Smem::LDK;
+    __shared__ __attribute__((aligned(16))) Smem sm;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -71,6 +86,7 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
     const int tile = blockIdx.x - b * tiles_per_b;
     const int q0 = tile * BM;
     const int n_blk = blockIdx.y * BN;
+    const float inv_no = 1.0f / (float)d.No;
 
     // constant indices keep the descriptor in the kernarg segment (a lane-indexed
     // read would force a scratch copy of the struct)
@@ -84,23 +100,30 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
     const int Ctot = d.C0 + d.C1;
     const int UPT = (Ctot + 15) >> 4;
     const int NU = d.ntaps * UPT;
-    const bool vec = ((d.C0 & 3) == 0) && ((d.C1 & 3) == 0);
+    const int NS = (NU + KU - 1) / KU;              // pipeline stages
 
-    // ---- per-thread staging coordinates --------------------------------------
+    // one buffer descriptor per source, spanning this workgroup's batch element
+    const unsigned bytes0 = (unsigned)d.T * d.Fin * d.C0 * 4u;
+    const unsigned bytes1 = (unsigned)d.T * d.Fin * d.C1 * 4u;
+    const __amdgpu_buffer_rsrc_t rs0 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.src0) + (size_t)b * d.T * d.Fin * d.C0, 0, bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(d.src1 ? d.src1 + (size_t)b * d.T * d.Fin * d.C1 : d.src0), 0, d.src1 ? bytes1 : 0u, 0x00020000);
+
+    // ---- per-thread staging coordinates ------------------------------------------
     const int srow = tid >> 2;      // 0..63
-    const int skq = tid & 3;        // which float4 of the 16-wide unit
-    int a_t[MI], a_f0[MI];
-    long long a_pos[MI];
+    const int skq = tid & 3;        // which float4 of a 16-wide unit
+    int a_t[MI], a_f0[MI], a_tf[MI];
     bool a_ok[MI];
 #pragma unroll
     for (int p = 0; p < MI; ++p) {
-        int q = q0 + srow + 64 * p;
+        const int q = q0 + srow + 64 * p;
         a_ok[p] = q < Q;
-        int t = a_ok[p] ? q / d.No : 0;
-        int o = a_ok[p] ? q - t * d.No : 0;
+        const int t = a_ok[p] ? cg_div(q, d.No, inv_no) : 0;
+        const int o = a_ok[p] ? q - t * d.No : 0;
         a_t[p] = t;
         a_f0[p] = o * d.istride;
-        a_pos[p] = ((long long)b * d.T + t) * d.Fin + o * d.istride;
+        a_tf[p] = t * d.Fin + o * d.istride;
     }
     const float* wrow[NI];
 #pragma unroll
@@ -110,82 +133,83 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
     // the transposed conv's implicit zeros come after norm+PReLU), so out-of-range
     // taps must stay exactly 0 through the fused transform: st_ok remembers which
     // staged rows are real.
-    f32x4 ra[MI], rb[NI], r_sh01, r_sh23, r_sl;
-    bool st_ok[MI];
-    bool r_xf = false;
+    f32x4 ra[KU][MI], rb[KU][NI], r_sh01[KU], r_sh23[KU], r_sl[KU];
+    bool st_ok[KU][MI];
 
     __syncthreads();   // tap tables visible
 
-    auto fetch = [&](int u) {
-        const int tap = u / UPT;
-        const int c0 = (u - tap * UPT) << 4;
-        const int dt = sm.dt[tap], io = sm.ioff[tap];
-        const bool second = (d.C1 > 0) && (c0 >= d.C0);
-        const float* src = second ? d.src1 : d.src0;
-        const float* xf = second ? d.xf1 : d.xf0;
-        const float* sl = second ? d.slope1 : d.slope0;
-        const int Cs = second ? d.C1 : d.C0;
-        const int c = (second ? c0 - d.C0 : c0) + skq * 4;
-        r_xf = (xf != nullptr) && (d.xf_mode != EAB_XF_NONE);
-        if (vec) {
-            const bool cok = c < Cs;        // Cs % 4 == 0: a float4 is all-in or all-out
+    auto fetch = [&](int stage) {
+#pragma unroll
+        for (int ku = 0; ku < KU; ++ku) {
+            const int u = stage * KU + ku;
+            const bool live = u < NU;                           // K tail of the last stage
+            const int uu = live ? u : 0;
+            const int tap = uu / UPT;
+            const int c0 = (uu - tap * UPT) << 4;
+            const int dt = sm.dt[tap], io = sm.ioff[tap];
+            const bool second = (d.C1 > 0) && (c0 >= d.C0);     // wave-uniform
+            const int Cs = second ? d.C1 : d.C0;
+            const int c = (second ? c0 - d.C0 : c0) + skq * 4;
+            const bool cok = live && (c < Cs);
 #pragma unroll
             for (int p = 0; p < MI; ++p) {
                 const int tt = a_t[p] + dt, fi = a_f0[p] + io;
                 const bool ok = a_ok[p] && cok && tt >= 0 && fi >= 0 && fi < d.Fin;
-                ra[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (ok) ra[p] = *reinterpret_cast<const f32x4*>(src + (a_pos[p] + (long long)dt * d.Fin + io) * Cs + c);
-                st_ok[p] = ok;
-            }
-            if (r_xf && cok) {
-                const float* xp = xf + ((size_t)b * Cs + c) * 2;
-                r_sh01 = *reinterpret_cast<const f32x4*>(xp);
-                r_sh23 = *reinterpret_cast<const f32x4*>(xp + 4);
-                r_sl = *reinterpret_cast<const f32x4*>(sl + c);
-            } else {
-                r_sh01 = r_sh23 = f32x4{1.f, 0.f, 1.f, 0.f};
-                r_sl = f32x4{1.f, 1.f, 1.f, 1.f};
-            }
-        } else {
-            // channel counts that are not multiples of 4 (odd microphone counts): scalar gathers
+                st_ok[ku][p] = ok;
+                const unsigned off = ok ? (unsigned)(((a_tf[p] + dt * d.Fin + io) * Cs + c) * 4) : CG_OOB;
+                if (VEC) {
+                    const u32x4 v = second ? __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0)
+                                           : __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0);
+                    ra[ku][p] = __builtin_bit_cast(f32x4, v);
+                } else {
+                    // channel counts that are not multiples of 4 (odd microphone counts): dword gathers
 #pragma unroll
-            for (int p = 0; p < MI; ++p) {
-                const int tt = a_t[p] + dt, fi = a_f0[p] + io;
-                const bool ok = a_ok[p] && tt >= 0 && fi >= 0 && fi < d.Fin;
-                st_ok[p] = ok;
-                const float* ptr = src + (a_pos[p] + (long long)dt * d.Fin + io) * Cs;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ra[p][j] = (ok && c + j < Cs) ? ptr[c + j] : 0.0f;
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned oj = (ok && c + j < Cs) ? off + 4u * j : CG_OOB;
+                        const unsigned v = second ? __builtin_amdgcn_raw_buffer_load_b32(rs1, oj, 0, 0)
+                                                  : __builtin_amdgcn_raw_buffer_load_b32(rs0, oj, 0, 0);
+                        ra[ku][p][j] = __builtin_bit_cast(float, v);
+                    }
+                }
             }
-            float sc[4], sf[4], sv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool cok = r_xf && (c + j < Cs);
-                sc[j] = cok ? xf[((size_t)b * Cs + c + j) * 2] : 1.0f;
-                sf[j] = cok ? xf[((size_t)b * Cs + c + j) * 2 + 1] : 0.0f;
-                sv[j] = cok ? sl[c + j] : 1.0f;
+            if (XF != EAB_XF_NONE) {
+                const float* xf = second ? d.xf1 : d.xf0;
+                const float* sl = second ? d.slope1 : d.slope0;
+                if (xf != nullptr) {                            // wave-uniform; sources without a table pass through
+                    const int cc = cok ? c : 0;
+                    const float* xp = xf + ((size_t)b * Cs + cc) * 2;
+                    r_sh01[ku] = *reinterpret_cast<const f32x4*>(xp);
+                    r_sh23[ku] = *reinterpret_cast<const f32x4*>(xp + 4);
+                    r_sl[ku] = *reinterpret_cast<const f32x4*>(sl + cc);
+                } else {
+                    r_sh01[ku] = r_sh23[ku] = f32x4{1.f, 0.f, 1.f, 0.f};
+                    r_sl[ku] = f32x4{1.f, 1.f, 1.f, 1.f};
+                }
             }
-            r_sh01 = f32x4{sc[0], sf[0], sc[1], sf[1]};
-            r_sh23 = f32x4{sc[2], sf[2], sc[3], sf[3]};
-            r_sl = f32x4{sv[0], sv[1], sv[2], sv[3]};
+#pragma unroll
+            for (int p = 0; p < NI; ++p) {
+                rb[ku][p] = *reinterpret_cast<const f32x4*>(wrow[p] + (size_t)uu * 16);
+                if (!live) rb[ku][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
-#pragma unroll
-        for (int p = 0; p < NI; ++p) rb[p] = *reinterpret_cast<const f32x4*>(wrow[p] + (size_t)u * CG_BK);
     };
 
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < MI; ++p) {
-            f32x4 v = ra[p];
-            if (r_xf) {
-                f32x4 x = cg_xform(v, r_sh01, r_sh23, r_sl, d.xf_mode);
-                v = st_ok[p] ? x : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            *reinterpret_cast<f32x4*>(&sm.a[buf][(srow + 64 * p) * CG_LDK + skq * 4]) = v;
-        }
+        for (int ku = 0; ku < KU; ++ku) {
 #pragma unroll
-        for (int p = 0; p < NI; ++p)
-            *reinterpret_cast<f32x4*>(&sm.b[buf][(srow + 64 * p) * CG_LDK + skq * 4]) = rb[p];
+            for (int p = 0; p < MI; ++p) {
+                f32x4 v = ra[ku][p];
+                if (XF != EAB_XF_NONE) {
+                    const f32x4 x = cg_xform<XF>(v, r_sh01[ku], r_sh23[ku], r_sl[ku]);
+                    v = st_ok[ku][p] ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                *reinterpret_cast<f32x4*>(&sm.a[buf][(srow + 64 * p) * LDK + ku * 16 + skq * 4]) = v;
+            }
+#pragma unroll
+            for (int p = 0; p < NI; ++p)
+                *reinterpret_cast<f32x4*>(&sm.b[buf][(srow + 64 * p) * LDK + ku * 16 + skq * 4]) = rb[ku][p];
+        }
     };
 
     f32x16 acc[MI][NI];
@@ -200,30 +224,30 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
     stash(0);
     __syncthreads();
 
-    const int a_base = (wm * MI * 32 + li) * CG_LDK + 4 * lh;
-    const int b_base = (wn * NI * 32 + li) * CG_LDK + 4 * lh;
+    const int a_base = (wm * MI * 32 + li) * LDK + 4 * lh;
+    const int b_base = (wn * NI * 32 + li) * LDK + 4 * lh;
 
-    for (int u = 0; u < NU; ++u) {
-        const int cur = u & 1;
-        if (u + 1 < NU) fetch(u + 1);
+    for (int s = 0; s < NS; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < NS) fetch(s + 1);
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < 2 * KU; ++g) {
             f32x4 af[MI], bf[NI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
-                af[mi] = *reinterpret_cast<const f32x4*>(&sm.a[cur][a_base + mi * 32 * CG_LDK + g * 8]);
+                af[mi] = *reinterpret_cast<const f32x4*>(&sm.a[cur][a_base + mi * 32 * LDK + g * 8]);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-                bf[ni] = *reinterpret_cast<const f32x4*>(&sm.b[cur][b_base + ni * 32 * CG_LDK + g * 8]);
+                bf[ni] = *reinterpret_cast<const f32x4*>(&sm.b[cur][b_base + ni * 32 * LDK + g * 8]);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][s], bf[ni][s], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][k], bf[ni][k], acc[mi][ni], 0, 0, 0);
         }
-        if (u + 1 < NU) stash(cur ^ 1);
+        if (s + 1 < NS) stash(cur ^ 1);
         __syncthreads();
     }
 
@@ -257,36 +281,48 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int c = 0; c < NC; ++c) ssum[s][c] = ssq[s][c] = 0.0f;
+    const bool two_sets = d.nsets == 2;
+    const size_t b_pos0 = (size_t)b * d.T * d.Fout;
 
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int q = q0 + m;
-            if (q >= Q) continue;
-            const int t = q / d.No, o = q - t * d.No;
-            const long long pos = ((long long)b * d.T + t) * d.Fout + o * d.ostride + d.ophase;
+        for (int r4 = 0; r4 < 4; ++r4) {
+            // rows r = 4*r4 + j, j = 0..3 are consecutive q: one division per group of four
+            const int qg = q0 + (wm * MI + mi) * 32 + 8 * r4 + 4 * lh;
+            int t = cg_div(qg < Q ? qg : 0, d.No, inv_no);
+            int o = qg - t * d.No;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                float v;
-                if (GLU) {
-                    v = (acc[mi][0][r] + bias_v[0]) * eab_sigmoid(acc[mi][1][r] + bias_v[1]);
-                } else {
-                    v = acc[mi][c][r] + bias_v[c];
-                }
-                const long long idx = pos * Cout + ch[c];
-                if (d.epi == EAB_EPI_RELU) v = fmaxf(v, 0.0f);
-                else if (d.epi == EAB_EPI_MULSIG) v = d.aux[idx] * eab_sigmoid(v);
-                else if (d.epi == EAB_EPI_ADD) v = v + d.aux[idx];
-                d.dst[idx] = v;
-                if (d.dst_acc) d.dst_acc[idx] += v;
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * r4 + j;
+                const bool rowok = qg + j < Q;
+                const size_t pos = b_pos0 + (size_t)t * d.Fout + o * d.ostride + d.ophase;
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const float g = eab_prelu(v, st_slope[s][c]);
-                    ssum[s][c] += g;
-                    ssq[s][c] = fmaf(g, g, ssq[s][c]);
+                for (int c = 0; c < NC; ++c) {
+                    float v;
+                    if (GLU) {
+                        v = (acc[mi][0][r] + bias_v[0]) * cg_sigmoid(acc[mi][1][r] + bias_v[1]);
+                    } else {
+                        v = acc[mi][c][r] + bias_v[c];
+                    }
+                    if (rowok) {
+                        const size_t idx = pos * Cout + ch[c];
+                        if (d.epi == EAB_EPI_RELU) v = fmaxf(v, 0.0f);
+                        else if (d.epi == EAB_EPI_MULSIG) v = d.aux[idx] * cg_sigmoid(v);
+                        else if (d.epi == EAB_EPI_ADD) v = v + d.aux[idx];
+                        d.dst[idx] = v;
+                        if (d.dst_acc) d.dst_acc[idx] += v;
+                        const float g0 = eab_prelu(v, st_slope[0][c]);
+                        ssum[0][c] += g0;
+                        ssq[0][c] = fmaf(g0, g0, ssq[0][c]);
+                        if (two_sets) {
+                            const float g1 = eab_prelu(v, st_slope[1][c]);
+                            ssum[1][c] += g1;
+                            ssq[1][c] = fmaf(g1, g1, ssq[1][c]);
+                        }
+                    }
                 }
+                if (++o == d.No) { o = 0; ++t; }
             }
         }
     }
@@ -337,13 +373,38 @@ extern "C" int eab_conv_tiles(int T, int No, int bm) {
     return (int)((q + bm - 1) / bm);
 }
 
-template <int MI, int NI, bool GLU>
+template <int MI, int NI, int KU, bool GLU, int XF, bool VEC>
 static int cg_launch(const eab_conv_desc* d, hipStream_t s) {
     constexpr int BM = 64 * MI, BN = 64 * NI;
     const int tiles = eab_conv_tiles(d->T, d->No, BM);
     dim3 grid((unsigned)(d->B * tiles), (unsigned)(d->N / BN));
-    hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, GLU>), grid, dim3(CG_THREADS), 0, s, *d);
+    hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, KU, GLU, XF, VEC>), grid, dim3(CG_THREADS), 0, s, *d);
     EAB_RETURN_LAUNCH_STATUS();
+}
+
+// K units per pipeline stage: big tiles keep three workgroups per CU resident
+// (41 KB of LDS each) with KU = 1; the small-M kernels of the S-TCN are latency
+// bound (one workgroup per CU, K = 256..320) and take four units per barrier.
+template <int MI, int NI, bool GLU, int XF, bool VEC>
+static int cg_pick_ku(const eab_conv_desc* d, hipStream_t s, int ku) {
+    if (ku == 4) {
+        if constexpr (MI == 1 && !GLU && VEC) return cg_launch<MI, NI, 4, GLU, XF, VEC>(d, s);
+        return EAB_EUNSUPPORTED;
+    }
+    if (ku == 2) {
+        if constexpr (VEC) return cg_launch<MI, NI, 2, GLU, XF, VEC>(d, s);
+        return EAB_EUNSUPPORTED;
+    }
+    return cg_launch<MI, NI, 1, GLU, XF, VEC>(d, s);
+}
+
+static int cg_ku_override() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("EAB_CG_KU");      // tuning knob, not part of the ABI
+        v = e ? atoi(e) : 0;
+    }
+    return v;
 }
 
 extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
@@ -357,6 +418,10 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
     const int upt = (d->C0 + d->C1 + 15) / 16;
     EAB_CHECK_ARG(d->Kpad == d->ntaps * upt * 16);
     for (int j = 0; j < d->ntaps; ++j) EAB_CHECK_ARG(d->dt[j] <= 0 && d->dt[j] > -(1 << 20));
+    // one batch element of a source must be addressable with a 31-bit byte offset,
+    // and rows per batch element must stay exact in the fp32-reciprocal division
+    const long long per_b = (long long)d->T * d->Fin * (d->C0 > d->C1 ? d->C0 : d->C1) * 4;
+    EAB_CHECK_ARG(per_b < (1ll << 31) && (long long)d->T * d->No < (1ll << 22));
     EAB_CHECK_ARG(d->xf_mode >= EAB_XF_NONE && d->xf_mode <= EAB_XF_PRELU_NORM);
     if (d->xf_mode != EAB_XF_NONE) {
         EAB_CHECK_ARG((d->xf0 == nullptr) == (d->slope0 == nullptr));
@@ -375,11 +440,23 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
     EAB_CHECK_ARG((long long)d->B * eab_conv_tiles(d->T, d->No, d->bm) < (1ll << 31));
     hipStream_t s = eab_stream(stream);
     const int mi = d->bm / 64;
+    const bool vec = (d->C0 % 4 == 0) && (d->C1 % 4 == 0);
+    const bool has_xf = d->xf_mode != EAB_XF_NONE && (d->xf0 || d->xf1);
+    const int xf = has_xf ? d->xf_mode : EAB_XF_NONE;
+    int ku = cg_ku_override();
+    if (ku == 0) ku = (mi == 1 && !glu && vec && d->Fin == 1) ? 4 : 1;
     if (glu) {
-        if (d->N != 128) return EAB_EUNSUPPORTED;
-        return mi == 2 ? cg_launch<2, 2, true>(d, s) : cg_launch<1, 2, true>(d, s);
+        if (d->N != 128 || xf != EAB_XF_NONE) return EAB_EUNSUPPORTED;
+        if (!vec) return mi == 2 ? cg_pick_ku<2, 2, true, 0, false>(d, s, 1) : cg_pick_ku<1, 2, true, 0, false>(d, s, 1);
+        return mi == 2 ? cg_pick_ku<2, 2, true, 0, true>(d, s, ku) : cg_pick_ku<1, 2, true, 0, true>(d, s, ku);
     }
-    if (d->N % 128 == 0) return mi == 2 ? cg_launch<2, 2, false>(d, s) : cg_launch<1, 2, false>(d, s);
-    if (d->N % 64 == 0) return mi == 2 ? cg_launch<2, 1, false>(d, s) : cg_launch<1, 1, false>(d, s);
+    if (!vec) return EAB_EUNSUPPORTED;          // only the first (gated) conv can see 2M % 4 != 0 channels
+#define CG_DISPATCH_XF(MI_, NI_)                                                        \
+    (xf == EAB_XF_NONE        ? cg_pick_ku<MI_, NI_, false, EAB_XF_NONE, true>(d, s, ku) \
+     : xf == EAB_XF_NORM_PRELU ? cg_pick_ku<MI_, NI_, false, EAB_XF_NORM_PRELU, true>(d, s, ku) \
+                               : cg_pick_ku<MI_, NI_, false, EAB_XF_PRELU_NORM, true>(d, s, ku))
+    if (d->N % 128 == 0) return mi == 2 ? CG_DISPATCH_XF(2, 2) : CG_DISPATCH_XF(1, 2);
+    if (d->N % 64 == 0) return mi == 2 ? CG_DISPATCH_XF(2, 1) : CG_DISPATCH_XF(1, 1);
+#undef CG_DISPATCH_XF
     return EAB_EUNSUPPORTED;
 }

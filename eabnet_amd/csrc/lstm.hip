@@ -3,47 +3,81 @@
 // initial state, gate order i,f,g,o, biases b_ih + b_hh).
 //
 // The B*F sequences are independent; the time loop is strictly sequential.
-// One workgroup (4 waves) owns 16 sequences for the whole utterance:
+// One workgroup (4 waves, one per SIMD) owns 16 sequences for the whole utterance:
 //   * wave w owns hidden units [16w, 16w+16): its four 16-column MFMA tiles are
 //     the i, f, g, o pre-activations of the SAME units, so the cell update is
 //     lane-local in the accumulator layout (col = lane&15 = unit,
 //     row = 4*(lane>>4)+r = sequence);
-//   * the [x_t | h_{t-1}] -> gates weights (K = 128, the wave's 64 columns) stay
-//     in 128 VGPRs for all T steps as MFMA B operands (v_mfma_f32_16x16x4_f32);
-//   * per step the A operand [16 seq][128] comes from a double-buffered LDS tile:
-//     x_{t+1} is loaded (one contiguous 4 KB block of the channels-last tensor),
-//     layer-normalised with 16-lane shuffles and stored while step t computes;
-//     h_t is written back by each lane; ONE barrier per step;
-//   * h_t leaves as one coalesced 4 KB store read back from that LDS tile.
-// Bound: the fp32 matrix pipe (128 MFMA x 32 cycles per step per SIMD).
+//   * the gate weights of the wave's 64 columns ([x | h] -> K = 128) stay in 128
+//     VGPRs for all T steps as MFMA B operands (v_mfma_f32_16x16x4_f32);
+//   * software pipeline over time.  The input half  W_x . x_{t+1}  does not depend
+//     on the recurrence; its 64 MFMAs fill the matrix pipe while the recurrence
+//     is latency bound.  A wave issues in order, so the order is pinned:
+//         H  : 64 MFMAs  acc = accx + W_h h_{t-1}          (critical path)
+//              + LayerNorm of x_{t+2} on the VALU (DPP row reductions, no LDS)
+//         X1 : first 32 MFMAs of accx' = b + W_x x_{t+1}, cell update of step t
+//              interleaved by the compiler (exp/rcp sigmoid, tanh)
+//         EX : h_t -> LDS, ONE barrier, h_t fragments -> registers
+//         X2 : last 32 MFMAs of accx' -- they run while the barrier resolves
+//     so the pipe holds 128 MFMA x 32 cycles per step back to back.
+//   * x is fetched from HBM four steps ahead (one contiguous 4 KB block of the
+//     channels-last tensor per workgroup); h_t leaves as one coalesced 4 KB store.
+// Bound: fp32 matrix pipe.
 #include "common.h"
+#include <type_traits>
 
 #define LS_H 64
-#define LS_K 128
 #define LS_SEQ 16
-#define LS_LD (LS_K + 4)   // odd 16-byte-slot stride (33): conflict-free b128 fragment reads
+#define LS_LD (LS_H + 4)   // 272-byte rows: odd 16-byte-slot stride -> conflict-free b128 fragment reads
 
+// sigmoid / tanh on the hardware exp and rcp (1 ulp class): abs error ~2e-7,
+// three orders of magnitude inside the 1e-4 parity bar, and short enough to hide
+// under the input-half MFMAs.
+__device__ __forceinline__ float ls_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ls_tanh(float x) { return fmaf(2.0f, ls_sigmoid(2.0f * x), -1.0f); }
+
+// sum over the 16 lanes of a DPP row; every lane ends with the total
+__device__ __forceinline__ float ls_row_sum(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
+    return v;
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define LS_OOB 0x80000000u   // byte offset outside every legal tensor (host checks < 2^31): loads give 0, stores drop
+
+template <bool LN>
 __global__ __launch_bounds__(256) void lstm64_kernel(const float* __restrict__ x, const float* __restrict__ ln_g,
                                                      const float* __restrict__ ln_b, float ln_eps,
                                                      const float* __restrict__ wcat, const float* __restrict__ bias,
                                                      float* __restrict__ h_out, int T, int F, int S) {
-    __shared__ __attribute__((aligned(16))) float xh[2][LS_SEQ * LS_LD];
+    __shared__ __attribute__((aligned(16))) float xs[2][LS_SEQ * LS_LD];
+    __shared__ __attribute__((aligned(16))) float hs[2][LS_SEQ * LS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ln = lane & 15, lk = lane >> 4;
     const int s0 = blockIdx.x * LS_SEQ;
 
-    // ---- stationary weights: wreg[g][4j+s] = Wcat[g*64 + 16w + ln][16j + 4*lk + s]
-    float wreg[4][32];
+    // ---- stationary weights: w?[g][4j+s] = Wcat[g*64 + 16w + ln][(x:0 | h:64) + 16j + 4*lk + s]
+    float wx[4][16], wh[4][16];
     float bia[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int row = g * LS_H + wave * 16 + ln;
         bia[g] = bias[row];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(&wcat[(size_t)row * LS_K + 16 * j + 4 * lk]);
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 vx = *reinterpret_cast<const f32x4*>(&wcat[(size_t)row * 128 + 16 * j + 4 * lk]);
+            const f32x4 vh = *reinterpret_cast<const f32x4*>(&wcat[(size_t)row * 128 + 64 + 16 * j + 4 * lk]);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) wreg[g][4 * j + s] = v[s];
+            for (int s = 0; s < 4; ++s) {
+                wx[g][4 * j + s] = vx[s];
+                wh[g][4 * j + s] = vh[s];
+            }
         }
     }
 
@@ -52,80 +86,146 @@ __global__ __launch_bounds__(256) void lstm64_kernel(const float* __restrict__ x
     const int sg = s0 + ls;                       // global sequence = b*F + f
     const bool sv = sg < S;
     const int sb = sv ? sg / F : 0, sf = sv ? sg - sb * F : 0;
-    const size_t seq_off = ((size_t)sb * T * F + sf) * LS_H + lc;   // + t*F*64
-    const size_t t_stride = (size_t)F * LS_H;
+    // bounds-checked buffer accesses instead of exec-mask branches (tail sequences, t >= T)
+    const unsigned total_bytes = (unsigned)S * (unsigned)T * (LS_H * 4u);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, total_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(h_out, 0, total_bytes, 0x00020000);
+    const unsigned seq_off = (unsigned)((((size_t)sb * T * F + sf) * LS_H + lc) * 4);   // bytes, + t*t_stride
+    const unsigned t_stride = (unsigned)F * LS_H * 4u;
     f32x4 g4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f};
-    if (ln_g) {
+    if (LN) {
         g4 = *reinterpret_cast<const f32x4*>(ln_g + lc);
         b4 = *reinterpret_cast<const f32x4*>(ln_b + lc);
     }
 
     auto load_x = [&](int t) -> f32x4 {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (sv) v = *reinterpret_cast<const f32x4*>(x + seq_off + (size_t)t * t_stride);
-        return v;
+        const unsigned off = (sv && t < T) ? seq_off + (unsigned)t * t_stride : LS_OOB;
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
     };
     auto norm_store = [&](f32x4 v, int buf) {
-        if (ln_g) {
+        if (LN) {
             // LayerNorm over the 64 channels = 16 lanes x 4, two-pass in registers
-            float s = (v[0] + v[1]) + (v[2] + v[3]);
-#pragma unroll
-            for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m);
-            const float mean = s * (1.0f / 64.0f);
+            const float mean = ls_row_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 64.0f);
             f32x4 dlt = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
-            float q = (dlt[0] * dlt[0] + dlt[1] * dlt[1]) + (dlt[2] * dlt[2] + dlt[3] * dlt[3]);
-#pragma unroll
-            for (int m = 1; m < 16; m <<= 1) q += __shfl_xor(q, m);
+            const float q = ls_row_sum((dlt[0] * dlt[0] + dlt[1] * dlt[1]) + (dlt[2] * dlt[2] + dlt[3] * dlt[3]));
             const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + ln_eps);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = dlt[j] * rstd * g4[j] + b4[j];
         }
-        *reinterpret_cast<f32x4*>(&xh[buf][ls * LS_LD + lc]) = v;
+        *reinterpret_cast<f32x4*>(&xs[buf][ls * LS_LD + lc]) = v;
     };
-
-    // h_{-1} = 0, c_{-1} = 0
-    *reinterpret_cast<f32x4*>(&xh[0][ls * LS_LD + LS_H + lc]) = f32x4{0.f, 0.f, 0.f, 0.f};
-    norm_store(load_x(0), 0);
-    float cst[4] = {0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
-
-    for (int t = 0; t < T; ++t) {
-        const int cur = t & 1, nxt = cur ^ 1;
-        f32x4 xn = {0.f, 0.f, 0.f, 0.f};
-        if (t + 1 < T) xn = load_x(t + 1);            // in flight during the MFMAs
-
-        f32x4 acc[4];
+    // fragments of a 16 x 64 LDS tile: lane (m = ln, kk = lk) holds floats [16j + 4kk, +4), j = 0..3
+    auto frags = [&](const float* tile, f32x4 (&a)[4]) {
+        const float* arow = tile + ln * LS_LD + 4 * lk;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = f32x4{bia[g], bia[g], bia[g], bia[g]};
-        const float* arow = &xh[cur][ln * LS_LD + 4 * lk];
+        for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const f32x4*>(arow + 16 * j);
+    };
+    // acc[g] += A[:, 16j..16j+15] . W[g]  for j in [J0, J1)   -- 16 MFMAs per j
+    auto mma = [&](const f32x4 (&a)[4], const float (&w)[4][16], f32x4 (&acc)[4], auto j0, auto j1) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * j);
+        for (int j = decltype(j0)::value; j < decltype(j1)::value; ++j)
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], wreg[g][4 * j + s], acc[g], 0, 0, 0);
-        }
-        // cell update: lane holds unit u = 16*wave + ln for sequences 4*lk + r
-        const int u = wave * 16 + ln;
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][s], w[g][4 * j + s], acc[g], 0, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I2 = std::integral_constant<int, 2>;
+    using I4 = std::integral_constant<int, 4>;
+
+    // prologue: h_{-1} = 0, c_{-1} = 0, x_0 and x_1 normalised in LDS, accx = b + W_x x_0
+    *reinterpret_cast<f32x4*>(&hs[0][ls * LS_LD + lc]) = f32x4{0.f, 0.f, 0.f, 0.f};
+    norm_store(load_x(0), 0);
+    norm_store(load_x(1), 1);
+    float cst[4] = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    f32x4 accx[4], hf[4], xf[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float ig = eab_sigmoid(acc[0][r]);
-            const float fg = eab_sigmoid(acc[1][r]);
-            const float gg = eab_tanh(acc[2][r]);
-            const float og = eab_sigmoid(acc[3][r]);
-            cst[r] = fg * cst[r] + ig * gg;
-            const float h = og * eab_tanh(cst[r]);
-            xh[nxt][(4 * lk + r) * LS_LD + LS_H + u] = h;
+    for (int g = 0; g < 4; ++g) accx[g] = f32x4{bia[g], bia[g], bia[g], bia[g]};
+    frags(xs[0], xf);
+    mma(xf, wx, accx, I0{}, I4{});
+    frags(hs[0], hf);
+    f32x4 xq = load_x(2), xr = load_x(3);               // x_{t+2}, x_{t+3}: raw, in registers
+
+    const int u = wave * 16 + ln;
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        const f32x4 xn = load_x(t + 4);                 // four steps ahead: two full steps of HBM latency cover
+
+        // ---- H: recurrent half (critical path) + LayerNorm of x_{t+2} on the VALU
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = accx[g];
+        mma(hf, wh, acc, I0{}, I4{});
+        norm_store(xq, cur);                            // x_{t+2} replaces x_t (consumed one step ago)
+        frags(xs[nxt], xf);                             // x_{t+1}
+        if (LN) {
+            // spread the LayerNorm's ~90 VALU ops through the 64 MFMAs instead of behind them
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // VALU
+            }
         }
-        if (t + 1 < T) norm_store(xn, nxt);
-        __syncthreads();
-        // coalesced write-back of h_t from the tile the next step reads
-        if (sv) {
-            const f32x4 hv = *reinterpret_cast<const f32x4*>(&xh[nxt][ls * LS_LD + LS_H + lc]);
-            *reinterpret_cast<f32x4*>(h_out + seq_off + (size_t)t * t_stride) = hv;
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- X1: first half of the next step's input MFMAs.  The cell update of step t
+        // (lane holds unit u for sequences 4*lk + r) is cut into 32 slices, one per MFMA
+        // gap: a 16x16x4 MFMA holds the issue port 8 of its 32 cycles, a plain VALU op
+        // costs 4, exp/rcp 8 (MI355X_MICROARCH cycle table), so <= 2 of each fit a gap.
+        // n = 4*gate + r;  stage A: e = exp(-k x)   (k = 2 for the tanh gate)
+        //                  stage B: s = 1/(1+e)     (tanh gate: 2s - 1)
+        //                  stage C: c = f c + i g, e_c = exp(-2c);  stage D: h = o (2/(1+e_c) - 1)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) accx[g] = f32x4{bia[g], bia[g], bia[g], bia[g]};
+        float ev[16], hval[4];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            {
+                const int j = i >> 4, k = (i >> 2) & 3, g = i & 3;
+                accx[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[j][k], wx[g][4 * j + k], accx[g], 0, 0, 0);
+            }
+            if (i < 8) {
+#pragma unroll
+                for (int n = 2 * i; n < 2 * i + 2; ++n) {
+                    const float v = acc[n >> 2][n & 3];
+                    ev[n] = __expf((n >> 2) == 2 ? -2.0f * v : -v);
+                }
+            } else if (i < 16) {
+#pragma unroll
+                for (int n = 2 * (i - 8); n < 2 * (i - 8) + 2; ++n) {
+                    const float sg = __builtin_amdgcn_rcpf(1.0f + ev[n]);
+                    ev[n] = (n >> 2) == 2 ? fmaf(2.0f, sg, -1.0f) : sg;
+                }
+            } else if (i < 20) {
+                const int r = i - 16;
+                cst[r] = fmaf(ev[4 + r], cst[r], ev[r] * ev[8 + r]);
+                hval[r] = __expf(-2.0f * cst[r]);
+            } else if (i < 24) {
+                const int r = i - 20;
+                hval[r] = ev[12 + r] * fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + hval[r]), -1.0f);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+
+        // ---- EX: exchange h_t through LDS
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hs[nxt][(4 * lk + r) * LS_LD + u] = hval[r];
+        // raw barrier: only the LDS writes have to land.  __syncthreads() would also wait
+        // vmcnt(0), i.e. drain the x prefetch and the previous h store every step.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        frags(hs[nxt], hf);
+        f32x4 hv = {0.f, 0.f, 0.f, 0.f};
+        hv = *reinterpret_cast<const f32x4*>(&hs[nxt][ls * LS_LD + lc]);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- X2: second half of the input MFMAs covers the barrier and the LDS latency
+        mma(xf, wx, accx, I2{}, I4{});
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), rh,
+                                               sv ? seq_off + (unsigned)t * t_stride : LS_OOB, 0, 0);   // coalesced 4 KB
+        xq = xr;
+        xr = xn;
     }
 }
 
@@ -134,9 +234,13 @@ extern "C" int eab_lstm64_f32(const float* x, const float* ln_g, const float* ln
     EAB_CHECK_ARG(x && wcat && bias && h_out && B > 0 && T > 0 && F > 0);
     EAB_CHECK_ARG((ln_g == nullptr) == (ln_b == nullptr));
     const long long S = (long long)B * F;
-    EAB_CHECK_ARG(S < (1ll << 30));
+    EAB_CHECK_ARG(S * T * LS_H * 4 < (1ll << 31));          // 31-bit byte offsets in the buffer descriptors
     const int grid = (int)((S + LS_SEQ - 1) / LS_SEQ);
-    hipLaunchKernelGGL(lstm64_kernel, dim3(grid), dim3(256), 0, eab_stream(stream), x, ln_g, ln_b, ln_eps, wcat, bias,
-                       h_out, T, F, (int)S);
+    if (ln_g)
+        hipLaunchKernelGGL(lstm64_kernel<true>, dim3(grid), dim3(256), 0, eab_stream(stream), x, ln_g, ln_b, ln_eps,
+                           wcat, bias, h_out, T, F, (int)S);
+    else
+        hipLaunchKernelGGL(lstm64_kernel<false>, dim3(grid), dim3(256), 0, eab_stream(stream), x, ln_g, ln_b, ln_eps,
+                           wcat, bias, h_out, T, F, (int)S);
     EAB_RETURN_LAUNCH_STATUS();
 }
