@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import eabnet_amd  # noqa: E402
+from eabnet_amd import dist  # noqa: E402
 from eabnet_amd import program as prg  # noqa: E402
 
 B_PER_GPU, MICS, SR, SECONDS = 16, 8, 16000, 4.0
@@ -126,18 +127,13 @@ def main():
     ap.add_argument("--per-op", type=str, default="", help="write the per-op timing table (instrumented replay) here")
     a = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
-    dist = world > 1
+    rank, world, local = dist.env_rank()
+    if world == 1 and a.gpus > 1:
+        sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                 "--master-addr 127.0.0.1 bench.py --gpus N")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if dist:
-        import torch.distributed as td
-        td.init_process_group("nccl", device_id=dev)       # RCCL; only barriers and one scalar MAX
+    is_dist = dist.init("nccl", dev)                        # RCCL; only barriers and one scalar MAX
 
     L = int(SECONDS * SR)
     T = 1 + L // HOP
@@ -153,22 +149,17 @@ def main():
         for _ in range(a.warmup):
             y, ns = step()
         torch.cuda.synchronize()
-        if dist:
-            td.barrier()
+        dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             y, ns = step()
         torch.cuda.synchronize()
-        if dist:
-            td.barrier()
+        dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
     assert torch.isfinite(y).all()
-    if dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        td.all_reduce(tmax, op=td.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = dist.max_over_ranks(elapsed, dev)
 
     frames = world * B_PER_GPU * T * a.steps
     out = {
@@ -221,9 +212,9 @@ def main():
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))
-    if dist:
-        td.barrier()
-        td.destroy_process_group()
+    if is_dist:
+        dist.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

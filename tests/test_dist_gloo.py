@@ -1,0 +1,76 @@
+"""N > 1 path on CPU: two gloo ranks shard a set of utterances the way bench.py
+shards them over GPUs, and the gathered result equals the single-process one
+(utterances are independent, so no data-path collective is needed)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import paramgen
+from eabnet_amd import dist
+from eabnet_amd.spec import NetConfig, param_specs
+
+
+def test_shard_partitions_exactly_once():
+    for n in (0, 1, 7, 16, 17):
+        for world in (1, 2, 3, 8):
+            seen = [i for r in range(world) for i in dist.shard(n, r, world)]
+            assert seen == list(range(n))
+            sizes = [len(dist.shard(n, r, world)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_utt, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from oracle import eabnet_oracle as orc           # checker standing in for the device path on CPU
+    assert dist.init("gloo")
+    cfg = NetConfig(M=2, p=1, q=1)
+    P = {k: torch.from_numpy(v) for k, v in paramgen.make_params(param_specs(cfg), 7).items()}
+    x = torch.from_numpy(paramgen.make_spec_input(n_utt, 6, 161, 2, 8))
+    mine = dist.shard(n_utt, rank, world)
+    dist.barrier()
+    with torch.no_grad():
+        y = orc.eabnet_forward(P, x[mine.start:mine.stop], p=1, q=1)
+    dist.barrier()
+    t = dist.max_over_ranks(1.0 + rank)
+    loss = dist.mean_over_ranks(torch.tensor(float(rank)))
+    q.put((rank, mine.start, y.numpy(), t, float(loss)))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_inference_matches_single_process():
+    from oracle import eabnet_oracle as orc
+    world, n_utt = 2, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_utt, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg = NetConfig(M=2, p=1, q=1)
+    P = {k: torch.from_numpy(v) for k, v in paramgen.make_params(param_specs(cfg), 7).items()}
+    x = torch.from_numpy(paramgen.make_spec_input(n_utt, 6, 161, 2, 8))
+    with torch.no_grad():
+        ref = orc.eabnet_forward(P, x, p=1, q=1).numpy()
+    out = np.zeros_like(ref)
+    for rank, start, y, t, loss in got:
+        out[start:start + y.shape[0]] = y
+        assert t == 2.0                  # MAX over ranks of (1 + rank)
+        assert abs(loss - 0.5) < 1e-12   # SUM / world_size
+    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-6 * np.abs(ref).max())
