@@ -33,6 +33,9 @@ class ConvDesc(C.Structure):
         ("stats", C.c_void_p), ("nsets", C.c_int32),
         ("stat_slope0", C.c_void_p), ("stat_slope1", C.c_void_p),
         ("stat_tiles", C.c_int32), ("stat_tile0", C.c_int32), ("bm", C.c_int32),
+        ("fin_stats", C.c_void_p), ("fin_gamma0", C.c_void_p), ("fin_beta0", C.c_void_p),
+        ("fin_gamma1", C.c_void_p), ("fin_beta1", C.c_void_p),
+        ("fin_tiles", C.c_int32), ("fin_nsets", C.c_int32), ("fin_count", C.c_int32), ("fin_eps", C.c_float),
     ]
 
 

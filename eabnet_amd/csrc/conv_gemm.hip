@@ -34,11 +34,19 @@
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int MI, int NI, int KU>
+#define CG_PLAIN 0
+#define CG_GLU 1     // value/gate columns of ONE GEMM (GateConv2d / GateConvTranspose2d)
+#define CG_DUAL 2    // value/gate columns see the SAME source through two transforms (S-TCM branches)
+#define CG_XFC 128   // max channels of a source that carries a fused transform
+
+template <int MI, int NI, int KU, int MODE>
 struct CgSmem {
     static constexpr int BM = 64 * MI, BN = 64 * NI, LDK = 16 * KU + 4;
-    float a[2][BM * LDK];
+    static constexpr int NA = MODE == CG_DUAL ? 2 : 1;
+    float a[NA][2][BM * LDK];
     float b[2][BN * LDK];
+    float xft[2][CG_XFC][2];     // (scale, shift) per channel: table 0 = src0 / left, 1 = src1 / right
+    float xsl[2][CG_XFC];        // PReLU slopes
     int dt[EAB_MAX_TAPS];
     int ioff[EAB_MAX_TAPS];
 };
@@ -69,9 +77,11 @@ __device__ __forceinline__ int cg_div(int q, int n, float inv_n) {
     return t;
 }
 
-template <int MI, int NI, int KU, bool GLU, int XF, bool VEC>
+template <int MI, int NI, int KU, int MODE, int XF, bool VEC>
 __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_desc d) {
-    using Smem = CgSmem<MI, NI, KU>;
+    constexpr bool GLU = MODE != CG_PLAIN;          // gated epilogue (value tile, gate tile per lane)
+    constexpr bool DUAL = MODE == CG_DUAL;
+    using Smem = CgSmem<MI, NI, KU, MODE>;
     constexpr int BM = Smem::BM, BN = Smem::BN, LDK = Smem::LDK;
     __shared__ __attribute__((aligned(16))) Smem sm;
 
@@ -96,6 +106,47 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
             sm.dt[j] = d.dt[j];
             sm.ioff[j] = d.ioff[j];
         }
+
+    if (XF != EAB_XF_NONE) {
+        // (scale, shift, slope) tables of this batch element -> LDS.  Either the host ran
+        // eab_in_finalize_f32 (xf0/xf1) or the producer left few enough tiles that every
+        // consumer workgroup reduces them itself (fin_stats; fp64, fixed order, so all
+        // workgroups and the stand-alone kernel agree bit for bit).
+        const int k = tid >> 7, c = tid & (CG_XFC - 1);
+        const int Ck = (k == 0 || DUAL) ? d.C0 : d.C1;
+        const float* xfk = k == 0 ? d.xf0 : d.xf1;
+        const float* slk = k == 0 ? d.slope0 : d.slope1;
+        float sc = 1.0f, sh = 0.0f, sl = 1.0f;
+        if (c < Ck) {
+            if (d.fin_stats && k < d.fin_nsets) {
+                const float* gm = k == 0 ? d.fin_gamma0 : d.fin_gamma1;
+                const float* bt = k == 0 ? d.fin_beta0 : d.fin_beta1;
+                double sum = 0.0, sq = 0.0;
+                for (int t = 0; t < d.fin_tiles; ++t) {
+                    const float2 v = *reinterpret_cast<const float2*>(
+                        &d.fin_stats[((((size_t)b * d.fin_tiles + t) * d.fin_nsets + k) * d.C0 + c) * 2]);
+                    sum += (double)v.x;
+                    sq += (double)v.y;
+                }
+                const double inv = 1.0 / (double)d.fin_count;
+                const double mean = sum * inv;
+                double var = sq * inv - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const double scale = (double)gm[c] / sqrt(var + (double)d.fin_eps);
+                sc = (float)scale;
+                sh = (float)((double)bt[c] - mean * scale);
+                sl = slk[c];
+            } else if (xfk) {
+                const float2 v = *reinterpret_cast<const float2*>(&xfk[((size_t)b * Ck + c) * 2]);
+                sc = v.x;
+                sh = v.y;
+                sl = slk[c];
+            }
+        }
+        sm.xft[k][c][0] = sc;
+        sm.xft[k][c][1] = sh;
+        sm.xsl[k][c] = sl;
+    }
 
     const int Ctot = d.C0 + d.C1;
     const int UPT = (Ctot + 15) >> 4;
@@ -133,7 +184,8 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
     // the transposed conv's implicit zeros come after norm+PReLU), so out-of-range
     // taps must stay exactly 0 through the fused transform: st_ok remembers which
     // staged rows are real.
-    f32x4 ra[KU][MI], rb[KU][NI], r_sh01[KU], r_sh23[KU], r_sl[KU];
+    f32x4 ra[KU][MI], rb[KU][NI];
+    int r_tc[KU];                   // (table << 8 | first channel) of the staged float4
     bool st_ok[KU][MI];
 
     __syncthreads();   // tap tables visible
@@ -172,20 +224,7 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
                     }
                 }
             }
-            if (XF != EAB_XF_NONE) {
-                const float* xf = second ? d.xf1 : d.xf0;
-                const float* sl = second ? d.slope1 : d.slope0;
-                if (xf != nullptr) {                            // wave-uniform; sources without a table pass through
-                    const int cc = cok ? c : 0;
-                    const float* xp = xf + ((size_t)b * Cs + cc) * 2;
-                    r_sh01[ku] = *reinterpret_cast<const f32x4*>(xp);
-                    r_sh23[ku] = *reinterpret_cast<const f32x4*>(xp + 4);
-                    r_sl[ku] = *reinterpret_cast<const f32x4*>(sl + cc);
-                } else {
-                    r_sh01[ku] = r_sh23[ku] = f32x4{1.f, 0.f, 1.f, 0.f};
-                    r_sl[ku] = f32x4{1.f, 1.f, 1.f, 1.f};
-                }
-            }
+            r_tc[ku] = ((second ? 1 : 0) << 8) | (cok ? c : 0);
 #pragma unroll
             for (int p = 0; p < NI; ++p) {
                 rb[ku][p] = *reinterpret_cast<const f32x4*>(wrow[p] + (size_t)uu * 16);
@@ -197,14 +236,28 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
     auto stash = [&](int buf) {
 #pragma unroll
         for (int ku = 0; ku < KU; ++ku) {
+            f32x4 sh01[2], sh23[2], sl[2];
+            if (XF != EAB_XF_NONE) {
+                const int cc = r_tc[ku] & 0xFF;
+#pragma unroll
+                for (int k = 0; k < (DUAL ? 2 : 1); ++k) {
+                    const int tb = DUAL ? k : (r_tc[ku] >> 8);
+                    sh01[k] = *reinterpret_cast<const f32x4*>(&sm.xft[tb][cc][0]);
+                    sh23[k] = *reinterpret_cast<const f32x4*>(&sm.xft[tb][cc + 2][0]);
+                    sl[k] = *reinterpret_cast<const f32x4*>(&sm.xsl[tb][cc]);
+                }
+            }
 #pragma unroll
             for (int p = 0; p < MI; ++p) {
-                f32x4 v = ra[ku][p];
-                if (XF != EAB_XF_NONE) {
-                    const f32x4 x = cg_xform<XF>(v, r_sh01[ku], r_sh23[ku], r_sl[ku]);
-                    v = st_ok[ku][p] ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < (DUAL ? 2 : 1); ++k) {
+                    f32x4 v = ra[ku][p];
+                    if (XF != EAB_XF_NONE) {
+                        const f32x4 x = cg_xform<XF>(v, sh01[k], sh23[k], sl[k]);
+                        v = st_ok[ku][p] ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    *reinterpret_cast<f32x4*>(&sm.a[k][buf][(srow + 64 * p) * LDK + ku * 16 + skq * 4]) = v;
                 }
-                *reinterpret_cast<f32x4*>(&sm.a[buf][(srow + 64 * p) * LDK + ku * 16 + skq * 4]) = v;
             }
 #pragma unroll
             for (int p = 0; p < NI; ++p)
@@ -232,10 +285,12 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
         if (s + 1 < NS) fetch(s + 1);
 #pragma unroll
         for (int g = 0; g < 2 * KU; ++g) {
-            f32x4 af[MI], bf[NI];
+            f32x4 af[Smem::NA][MI], bf[NI];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                af[mi] = *reinterpret_cast<const f32x4*>(&sm.a[cur][a_base + mi * 32 * LDK + g * 8]);
+            for (int k = 0; k < Smem::NA; ++k)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    af[k][mi] = *reinterpret_cast<const f32x4*>(&sm.a[k][cur][a_base + mi * 32 * LDK + g * 8]);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
                 bf[ni] = *reinterpret_cast<const f32x4*>(&sm.b[cur][b_base + ni * 32 * LDK + g * 8]);
@@ -245,7 +300,8 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][k], bf[ni][k], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[DUAL ? ni : 0][mi][k], bf[ni][k],
+                                                                           acc[mi][ni], 0, 0, 0);
         }
         if (s + 1 < NS) stash(cur ^ 1);
         __syncthreads();
@@ -282,47 +338,78 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
 #pragma unroll
         for (int c = 0; c < NC; ++c) ssum[s][c] = ssq[s][c] = 0.0f;
     const bool two_sets = d.nsets == 2;
-    const size_t b_pos0 = (size_t)b * d.T * d.Fout;
+    // Output-side tensors through bounds-checked descriptors spanning this batch element:
+    // rows past the tile end get an out-of-range offset (loads give 0, stores are dropped), and
+    // the aux / running-sum operands of a 32-row block are all in flight before the first use.
+    const unsigned out_bytes = (unsigned)d.T * d.Fout * Cout * 4u;
+    const size_t out_b = (size_t)b * d.T * d.Fout * Cout;
+    const bool need_aux = d.epi == EAB_EPI_MULSIG || d.epi == EAB_EPI_ADD;
+    const __amdgpu_buffer_rsrc_t r_dst = __builtin_amdgcn_make_buffer_rsrc(d.dst + out_b, 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_aux = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(need_aux ? d.aux + out_b : d.dst + out_b), 0, need_aux ? out_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_acc = __builtin_amdgcn_make_buffer_rsrc(
+        d.dst_acc ? d.dst_acc + out_b : d.dst + out_b, 0, d.dst_acc ? out_bytes : 0u, 0x00020000);
 
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
+        unsigned off[16];
+        bool rowok[16];
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
             // rows r = 4*r4 + j, j = 0..3 are consecutive q: one division per group of four
             const int qg = q0 + (wm * MI + mi) * 32 + 8 * r4 + 4 * lh;
             int t = cg_div(qg < Q ? qg : 0, d.No, inv_no);
-            int o = qg - t * d.No;
+            int o = (qg < Q ? qg : 0) - t * d.No;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = 4 * r4 + j;
-                const bool rowok = qg + j < Q;
-                const size_t pos = b_pos0 + (size_t)t * d.Fout + o * d.ostride + d.ophase;
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    float v;
-                    if (GLU) {
-                        v = (acc[mi][0][r] + bias_v[0]) * cg_sigmoid(acc[mi][1][r] + bias_v[1]);
-                    } else {
-                        v = acc[mi][c][r] + bias_v[c];
-                    }
-                    if (rowok) {
-                        const size_t idx = pos * Cout + ch[c];
-                        if (d.epi == EAB_EPI_RELU) v = fmaxf(v, 0.0f);
-                        else if (d.epi == EAB_EPI_MULSIG) v = d.aux[idx] * cg_sigmoid(v);
-                        else if (d.epi == EAB_EPI_ADD) v = v + d.aux[idx];
-                        d.dst[idx] = v;
-                        if (d.dst_acc) d.dst_acc[idx] += v;
-                        const float g0 = eab_prelu(v, st_slope[0][c]);
-                        ssum[0][c] += g0;
-                        ssq[0][c] = fmaf(g0, g0, ssq[0][c]);
-                        if (two_sets) {
-                            const float g1 = eab_prelu(v, st_slope[1][c]);
-                            ssum[1][c] += g1;
-                            ssq[1][c] = fmaf(g1, g1, ssq[1][c]);
-                        }
-                    }
-                }
+                rowok[r] = qg + j < Q;
+                off[r] = rowok[r] ? (unsigned)((t * d.Fout + o * d.ostride + d.ophase) * Cout) * 4u : CG_OOB;
                 if (++o == d.No) { o = 0; ++t; }
+            }
+        }
+        float auxv[16][NC], accv[16][NC];
+        if (need_aux) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    auxv[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                               r_aux, rowok[r] ? off[r] + 4u * ch[c] : CG_OOB, 0, 0));
+        }
+        if (d.dst_acc) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    accv[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                               r_acc, rowok[r] ? off[r] + 4u * ch[c] : CG_OOB, 0, 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float v;
+                if (GLU) {
+                    v = (acc[mi][0][r] + bias_v[0]) * cg_sigmoid(acc[mi][1][r] + bias_v[1]);
+                } else {
+                    v = acc[mi][c][r] + bias_v[c];
+                }
+                if (d.epi == EAB_EPI_RELU) v = fmaxf(v, 0.0f);
+                else if (d.epi == EAB_EPI_MULSIG) v = auxv[r][c] * cg_sigmoid(v);
+                else if (d.epi == EAB_EPI_ADD) v = v + auxv[r][c];
+                const unsigned o4 = rowok[r] ? off[r] + 4u * ch[c] : CG_OOB;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_dst, o4, 0, 0);
+                if (d.dst_acc)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + accv[r][c]), r_acc, o4, 0, 0);
+                const float g0 = rowok[r] ? eab_prelu(v, st_slope[0][c]) : 0.0f;
+                ssum[0][c] += g0;
+                ssq[0][c] = fmaf(g0, g0, ssq[0][c]);
+                if (two_sets) {
+                    const float g1 = rowok[r] ? eab_prelu(v, st_slope[1][c]) : 0.0f;
+                    ssum[1][c] += g1;
+                    ssq[1][c] = fmaf(g1, g1, ssq[1][c]);
+                }
             }
         }
     }
@@ -330,7 +417,7 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
     if (d.stats) {
         // lanes l and l^32 hold the same columns; then the two wm waves; fixed
         // order everywhere => bit-reproducible partials.
-        float* red = &sm.a[0][0];               // staging LDS is free after the last barrier
+        float* red = &sm.a[0][0][0];               // staging LDS is free after the last barrier
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -373,29 +460,29 @@ extern "C" int eab_conv_tiles(int T, int No, int bm) {
     return (int)((q + bm - 1) / bm);
 }
 
-template <int MI, int NI, int KU, bool GLU, int XF, bool VEC>
+template <int MI, int NI, int KU, int MODE, int XF, bool VEC>
 static int cg_launch(const eab_conv_desc* d, hipStream_t s) {
     constexpr int BM = 64 * MI, BN = 64 * NI;
     const int tiles = eab_conv_tiles(d->T, d->No, BM);
     dim3 grid((unsigned)(d->B * tiles), (unsigned)(d->N / BN));
-    hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, KU, GLU, XF, VEC>), grid, dim3(CG_THREADS), 0, s, *d);
+    hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, KU, MODE, XF, VEC>), grid, dim3(CG_THREADS), 0, s, *d);
     EAB_RETURN_LAUNCH_STATUS();
 }
 
 // K units per pipeline stage: big tiles keep three workgroups per CU resident
 // (41 KB of LDS each) with KU = 1; the small-M kernels of the S-TCN are latency
 // bound (one workgroup per CU, K = 256..320) and take four units per barrier.
-template <int MI, int NI, bool GLU, int XF, bool VEC>
+template <int MI, int NI, int MODE, int XF, bool VEC>
 static int cg_pick_ku(const eab_conv_desc* d, hipStream_t s, int ku) {
     if (ku == 4) {
-        if constexpr (MI == 1 && !GLU && VEC) return cg_launch<MI, NI, 4, GLU, XF, VEC>(d, s);
+        if constexpr (MI == 1 && MODE != CG_GLU && VEC) return cg_launch<MI, NI, 4, MODE, XF, VEC>(d, s);
         return EAB_EUNSUPPORTED;
     }
     if (ku == 2) {
-        if constexpr (VEC) return cg_launch<MI, NI, 2, GLU, XF, VEC>(d, s);
+        if constexpr (VEC && MODE != CG_DUAL) return cg_launch<MI, NI, 2, MODE, XF, VEC>(d, s);
         return EAB_EUNSUPPORTED;
     }
-    return cg_launch<MI, NI, 1, GLU, XF, VEC>(d, s);
+    return cg_launch<MI, NI, 1, MODE, XF, VEC>(d, s);
 }
 
 static int cg_ku_override() {
@@ -418,18 +505,32 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
     const int upt = (d->C0 + d->C1 + 15) / 16;
     EAB_CHECK_ARG(d->Kpad == d->ntaps * upt * 16);
     for (int j = 0; j < d->ntaps; ++j) EAB_CHECK_ARG(d->dt[j] <= 0 && d->dt[j] > -(1 << 20));
-    // one batch element of a source must be addressable with a 31-bit byte offset,
-    // and rows per batch element must stay exact in the fp32-reciprocal division
-    const long long per_b = (long long)d->T * d->Fin * (d->C0 > d->C1 ? d->C0 : d->C1) * 4;
-    EAB_CHECK_ARG(per_b < (1ll << 31) && (long long)d->T * d->No < (1ll << 22));
-    EAB_CHECK_ARG(d->xf_mode >= EAB_XF_NONE && d->xf_mode <= EAB_XF_PRELU_NORM);
-    if (d->xf_mode != EAB_XF_NONE) {
-        EAB_CHECK_ARG((d->xf0 == nullptr) == (d->slope0 == nullptr));
-        EAB_CHECK_ARG((d->xf1 == nullptr) == (d->slope1 == nullptr));
-    }
-    EAB_CHECK_ARG(d->epi >= EAB_EPI_LINEAR && d->epi <= EAB_EPI_ADD);
+    EAB_CHECK_ARG(d->epi >= EAB_EPI_LINEAR && d->epi <= EAB_EPI_DUALGATE);
+    const bool dual = d->epi == EAB_EPI_DUALGATE;
     const bool glu = d->epi == EAB_EPI_GLU;
-    EAB_CHECK_ARG(d->Cout == (glu ? d->N / 2 : d->N));
+    EAB_CHECK_ARG(d->Cout == ((glu || dual) ? d->N / 2 : d->N));
+    // one batch element of a source / of the output must be addressable with a 31-bit byte
+    // offset, and rows per batch element must stay exact in the fp32-reciprocal division
+    const long long per_b = (long long)d->T * d->Fin * (d->C0 > d->C1 ? d->C0 : d->C1) * 4;
+    EAB_CHECK_ARG(per_b < (1ll << 31) && (long long)d->T * d->Fout * d->Cout * 4 < (1ll << 31));
+    EAB_CHECK_ARG((long long)d->T * d->No < (1ll << 22));
+    EAB_CHECK_ARG(d->xf_mode >= EAB_XF_NONE && d->xf_mode <= EAB_XF_PRELU_NORM);
+    const bool fin = d->fin_stats != nullptr;
+    if (fin) {
+        EAB_CHECK_ARG(d->xf_mode != EAB_XF_NONE && !d->xf0 && !d->xf1 && d->C1 == 0);
+        EAB_CHECK_ARG(d->fin_tiles > 0 && d->fin_tiles <= 64 && d->fin_count > 0);
+        EAB_CHECK_ARG(d->fin_nsets == (dual ? 2 : 1) || (!dual && d->fin_nsets == 2));
+        EAB_CHECK_ARG(d->fin_gamma0 && d->fin_beta0 && d->slope0);
+        EAB_CHECK_ARG(!dual || (d->fin_gamma1 && d->fin_beta1 && d->slope1));
+    }
+    if (d->xf_mode != EAB_XF_NONE) {
+        EAB_CHECK_ARG(fin || (d->xf0 == nullptr) == (d->slope0 == nullptr));
+        EAB_CHECK_ARG(fin || dual || (d->xf1 == nullptr) == (d->slope1 == nullptr));
+    }
+    if (dual) {
+        EAB_CHECK_ARG(d->C1 == 0 && d->xf_mode != EAB_XF_NONE && d->slope0 && d->slope1);
+        EAB_CHECK_ARG(fin || (d->xf0 && d->xf1));
+    }
     EAB_CHECK_ARG((d->epi != EAB_EPI_MULSIG && d->epi != EAB_EPI_ADD) || d->aux);
     EAB_CHECK_ARG(d->nsets >= 0 && d->nsets <= 2 && (d->nsets == 0) == (d->stats == nullptr));
     EAB_CHECK_ARG(d->bm == 64 || d->bm == 128);
@@ -441,20 +542,26 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
     hipStream_t s = eab_stream(stream);
     const int mi = d->bm / 64;
     const bool vec = (d->C0 % 4 == 0) && (d->C1 % 4 == 0);
-    const bool has_xf = d->xf_mode != EAB_XF_NONE && (d->xf0 || d->xf1);
+    const bool has_xf = d->xf_mode != EAB_XF_NONE && (d->xf0 || d->xf1 || fin);
     const int xf = has_xf ? d->xf_mode : EAB_XF_NONE;
+    if (xf != EAB_XF_NONE)   // transform tables live in LDS: CG_XFC channels per source
+        EAB_CHECK_ARG(d->C0 <= CG_XFC && d->C1 <= CG_XFC && vec);
     int ku = cg_ku_override();
     if (ku == 0) ku = (mi == 1 && !glu && vec && d->Fin == 1) ? 4 : 1;
+    if (dual) {
+        if (d->N != 128 || mi != 1 || xf != EAB_XF_PRELU_NORM) return EAB_EUNSUPPORTED;
+        return cg_pick_ku<1, 2, CG_DUAL, EAB_XF_PRELU_NORM, true>(d, s, ku == 2 ? 1 : ku);
+    }
     if (glu) {
         if (d->N != 128 || xf != EAB_XF_NONE) return EAB_EUNSUPPORTED;
-        if (!vec) return mi == 2 ? cg_pick_ku<2, 2, true, 0, false>(d, s, 1) : cg_pick_ku<1, 2, true, 0, false>(d, s, 1);
-        return mi == 2 ? cg_pick_ku<2, 2, true, 0, true>(d, s, ku) : cg_pick_ku<1, 2, true, 0, true>(d, s, ku);
+        if (!vec) return mi == 2 ? cg_pick_ku<2, 2, CG_GLU, 0, false>(d, s, 1) : cg_pick_ku<1, 2, CG_GLU, 0, false>(d, s, 1);
+        return mi == 2 ? cg_pick_ku<2, 2, CG_GLU, 0, true>(d, s, ku) : cg_pick_ku<1, 2, CG_GLU, 0, true>(d, s, ku);
     }
     if (!vec) return EAB_EUNSUPPORTED;          // only the first (gated) conv can see 2M % 4 != 0 channels
-#define CG_DISPATCH_XF(MI_, NI_)                                                        \
-    (xf == EAB_XF_NONE        ? cg_pick_ku<MI_, NI_, false, EAB_XF_NONE, true>(d, s, ku) \
-     : xf == EAB_XF_NORM_PRELU ? cg_pick_ku<MI_, NI_, false, EAB_XF_NORM_PRELU, true>(d, s, ku) \
-                               : cg_pick_ku<MI_, NI_, false, EAB_XF_PRELU_NORM, true>(d, s, ku))
+#define CG_DISPATCH_XF(MI_, NI_)                                                           \
+    (xf == EAB_XF_NONE        ? cg_pick_ku<MI_, NI_, CG_PLAIN, EAB_XF_NONE, true>(d, s, ku) \
+     : xf == EAB_XF_NORM_PRELU ? cg_pick_ku<MI_, NI_, CG_PLAIN, EAB_XF_NORM_PRELU, true>(d, s, ku) \
+                               : cg_pick_ku<MI_, NI_, CG_PLAIN, EAB_XF_PRELU_NORM, true>(d, s, ku))
     if (d->N % 128 == 0) return mi == 2 ? CG_DISPATCH_XF(2, 2) : CG_DISPATCH_XF(1, 2);
     if (d->N % 64 == 0) return mi == 2 ? CG_DISPATCH_XF(2, 1) : CG_DISPATCH_XF(1, 1);
 #undef CG_DISPATCH_XF

@@ -4,44 +4,58 @@
 // utterance), nn.PReLU(c), En_unet_module's residual add (EaBNet.py:386).
 #include "common.h"
 
-// grid = B * nsets, block = 256: 4 tile-slices x 64 channels per pass.
-__global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restrict__ stats, int C, int nsets,
-                                                          int stat_tiles, double inv_count, float eps,
-                                                          const float* __restrict__ gamma0,
-                                                          const float* __restrict__ beta0, float* __restrict__ xf0,
-                                                          const float* __restrict__ gamma1,
-                                                          const float* __restrict__ beta1, float* __restrict__ xf1) {
-    __shared__ double red[2][4][64];
+// grid = (B * nsets, C/64), block = 1024: 16 tile-slices x 64 channels, four
+// independent loads in flight per thread; fp64 accumulation in a fixed order.
+#define FIN_SLICES 16
+__global__ __launch_bounds__(1024) void in_finalize_kernel(const float* __restrict__ stats, int C, int nsets,
+                                                           int stat_tiles, double inv_count, float eps,
+                                                           const float* __restrict__ gamma0,
+                                                           const float* __restrict__ beta0, float* __restrict__ xf0,
+                                                           const float* __restrict__ gamma1,
+                                                           const float* __restrict__ beta1, float* __restrict__ xf1) {
+    __shared__ double red[2][FIN_SLICES][64];
     const int b = blockIdx.x / nsets, s = blockIdx.x % nsets;
     const float* gamma = s == 0 ? gamma0 : gamma1;
     const float* beta = s == 0 ? beta0 : beta1;
     float* xf = s == 0 ? xf0 : xf1;
     const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    for (int c0 = 0; c0 < C; c0 += 64) {
-        const int c = c0 + cl;
-        double sum = 0.0, sq = 0.0;
-        if (c < C) {
-            for (int t = slice; t < stat_tiles; t += 4) {
-                const float2 v =
-                    *reinterpret_cast<const float2*>(&stats[((((size_t)b * stat_tiles + t) * nsets + s) * C + c) * 2]);
-                sum += (double)v.x;
-                sq += (double)v.y;
-            }
+    const int c = blockIdx.y * 64 + cl;
+    double sum = 0.0, sq = 0.0;
+    if (c < C) {
+        const size_t stride = (size_t)nsets * C * 2;                         // floats between tiles
+        const float* p = stats + (((size_t)b * stat_tiles) * nsets + s) * C * 2 + (size_t)c * 2;
+        int t = slice;
+        for (; t + 3 * FIN_SLICES < stat_tiles; t += 4 * FIN_SLICES) {
+            const float2 v0 = *reinterpret_cast<const float2*>(p + (size_t)t * stride);
+            const float2 v1 = *reinterpret_cast<const float2*>(p + (size_t)(t + FIN_SLICES) * stride);
+            const float2 v2 = *reinterpret_cast<const float2*>(p + (size_t)(t + 2 * FIN_SLICES) * stride);
+            const float2 v3 = *reinterpret_cast<const float2*>(p + (size_t)(t + 3 * FIN_SLICES) * stride);
+            sum += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+            sq += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
         }
-        red[0][slice][cl] = sum;
-        red[1][slice][cl] = sq;
-        __syncthreads();
-        if (slice == 0 && c < C) {
-            sum = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
-            sq = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
-            const double mean = sum * inv_count;
-            double var = sq * inv_count - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const double scale = (double)gamma[c] / sqrt(var + (double)eps);
-            const double shift = (double)beta[c] - mean * scale;
-            *reinterpret_cast<float2*>(&xf[((size_t)b * C + c) * 2]) = make_float2((float)scale, (float)shift);
+        for (; t < stat_tiles; t += FIN_SLICES) {
+            const float2 v = *reinterpret_cast<const float2*>(p + (size_t)t * stride);
+            sum += (double)v.x;
+            sq += (double)v.y;
         }
-        __syncthreads();
+    }
+    red[0][slice][cl] = sum;
+    red[1][slice][cl] = sq;
+    __syncthreads();
+    if (slice == 0 && c < C) {
+        sum = 0.0;
+        sq = 0.0;
+#pragma unroll
+        for (int k = 0; k < FIN_SLICES; ++k) {
+            sum += red[0][k][cl];
+            sq += red[1][k][cl];
+        }
+        const double mean = sum * inv_count;
+        double var = sq * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double scale = (double)gamma[c] / sqrt(var + (double)eps);
+        const double shift = (double)beta[c] - mean * scale;
+        *reinterpret_cast<float2*>(&xf[((size_t)b * C + c) * 2]) = make_float2((float)scale, (float)shift);
     }
 }
 
@@ -52,8 +66,8 @@ extern "C" int eab_in_finalize_f32(const float* stats, int B, int C, int nsets, 
     EAB_CHECK_ARG(nsets == 1 || nsets == 2);
     EAB_CHECK_ARG(gamma0 && beta0 && xf0);
     EAB_CHECK_ARG(nsets == 1 || (gamma1 && beta1 && xf1));
-    hipLaunchKernelGGL(in_finalize_kernel, dim3(B * nsets), dim3(256), 0, eab_stream(stream), stats, C, nsets,
-                       stat_tiles, 1.0 / (double)count, eps, gamma0, beta0, xf0, gamma1, beta1, xf1);
+    hipLaunchKernelGGL(in_finalize_kernel, dim3(B * nsets, (C + 63) / 64), dim3(1024), 0, eab_stream(stream), stats, C,
+                       nsets, stat_tiles, 1.0 / (double)count, eps, gamma0, beta0, xf0, gamma1, beta1, xf1);
     EAB_RETURN_LAUNCH_STATUS();
 }
 

@@ -94,11 +94,14 @@ class _Bound:
             if op.kind == prg.OP_CONV:
                 d = o.conv
                 for f in ("src0", "src1", "xf0", "xf1", "slope0", "slope1", "w", "bias", "aux", "dst", "dst_acc",
-                          "stats", "stat_slope0", "stat_slope1"):
+                          "stats", "stat_slope0", "stat_slope1", "fin_stats", "fin_gamma0", "fin_beta0",
+                          "fin_gamma1", "fin_beta1"):
                     setattr(d, f, A(getattr(op, f)))
                 for f in ("C0", "C1", "xf_mode", "N", "Kpad", "B", "T", "Fin", "Fout", "No", "ostride", "ophase",
-                          "istride", "epi", "Cout", "nsets", "stat_tiles", "stat_tile0", "bm"):
+                          "istride", "epi", "Cout", "nsets", "stat_tiles", "stat_tile0", "bm", "fin_tiles",
+                          "fin_nsets", "fin_count"):
                     setattr(d, f, int(getattr(op, f)))
+                d.fin_eps = float(op.fin_eps)
                 d.ntaps = len(op.dt)
                 for j in range(_lib.MAX_TAPS):
                     d.dt[j] = op.dt[j] if j < len(op.dt) else 0

@@ -29,7 +29,7 @@ from .spec import NetConfig, param_specs
 
 # mirrors of the C enums (include/eabnet_hip.h)
 XF_NONE, XF_NORM_PRELU, XF_PRELU_NORM = 0, 1, 2
-EPI_LINEAR, EPI_GLU, EPI_RELU, EPI_MULSIG, EPI_ADD = 0, 1, 2, 3, 4
+EPI_LINEAR, EPI_GLU, EPI_RELU, EPI_MULSIG, EPI_ADD, EPI_DUALGATE = 0, 1, 2, 3, 4, 5
 OP_CONV, OP_IN_FINALIZE, OP_NORM_ACT, OP_LSTM64, OP_BFW_FS, OP_MEMSET0 = 1, 2, 3, 4, 5, 6
 MAX_TAPS = 16
 EPS_IN = 1e-5      # nn.InstanceNorm*d default (reference EaBNet.py:684,686)
@@ -96,6 +96,15 @@ class ConvOp:
     stat_tiles: int
     stat_tile0: int
     bm: int
+    fin_stats: Optional[Ref] = None      # in-kernel InstanceNorm finalisation (few producer tiles)
+    fin_gamma0: Optional[Ref] = None
+    fin_beta0: Optional[Ref] = None
+    fin_gamma1: Optional[Ref] = None
+    fin_beta1: Optional[Ref] = None
+    fin_tiles: int = 0
+    fin_nsets: int = 0
+    fin_count: int = 0
+    fin_eps: float = 0.0
     name: str = ""
     kind: int = OP_CONV
 
@@ -281,11 +290,14 @@ class Lowering:
                   Fout: int, No: int, ostride: int, ophase: int, istride: int, dt, ioff, epi: int,
                   dst: Ref, stats: Optional[Ref] = None, nsets: int = 0, stat_slopes=(None, None),
                   stat_tiles: int = 0, stat_tile0: int = 0, bm: Optional[int] = None, aux: Optional[Ref] = None,
-                  dst_acc: Optional[Ref] = None) -> ConvOp:
+                  dst_acc: Optional[Ref] = None, fin: Optional[dict] = None, slope1: Optional[Ref] = None) -> ConvOp:
+        """fin = dict(stats, tiles, nsets, count, norms=[...]) asks the kernel to reduce the
+        producer's InstanceNorm partials itself (single source, transform order from srcs[0].mode);
+        slope1 = second PReLU slope of the SAME source for EPI_DUALGATE."""
         assert 1 <= len(srcs) <= 2 and len(dt) == len(ioff) <= MAX_TAPS
         s0 = srcs[0]
         s1 = srcs[1] if len(srcs) == 2 else None
-        modes = {s.mode for s in srcs if s.xf is not None}
+        modes = {s.mode for s in srcs if s.xf is not None or (fin is not None and s.mode != XF_NONE)}
         assert len(modes) <= 1, "both concat sources must use the same transform order"
         mode = modes.pop() if modes else XF_NONE
         if s1 is not None:
@@ -294,12 +306,22 @@ class Lowering:
         upt = (C0 + C1 + 15) // 16
         assert Kpad == len(dt) * upt * 16
         bm = bm or self.pick_bm(No)
+        finkw = {}
+        if fin is not None:
+            assert s1 is None and s0.xf is None and mode != XF_NONE
+            g = [self.vec(f"{n}.norm.weight") for n in fin["norms"]]
+            b = [self.vec(f"{n}.norm.bias") for n in fin["norms"]]
+            finkw = dict(fin_stats=fin["stats"], fin_tiles=fin["tiles"], fin_nsets=fin["nsets"], fin_count=fin["count"],
+                         fin_eps=EPS_IN, fin_gamma0=g[0], fin_beta0=b[0],
+                         fin_gamma1=g[1] if len(g) > 1 else None, fin_beta1=b[1] if len(b) > 1 else None)
+        sl1 = slope1 if slope1 is not None else (s1.slope if s1 else None)
         op = ConvOp(src0=s0.ref, src1=s1.ref if s1 else None, xf0=s0.xf, xf1=s1.xf if s1 else None,
-                    slope0=s0.slope, slope1=s1.slope if s1 else None, C0=C0, C1=C1, xf_mode=mode, w=w, bias=bias,
+                    slope0=s0.slope, slope1=sl1, C0=C0, C1=C1, xf_mode=mode, w=w, bias=bias,
                     N=N, Kpad=Kpad, B=self.B, T=self.T, Fin=s0.F, Fout=Fout, No=No, ostride=ostride, ophase=ophase,
                     istride=istride, dt=list(dt), ioff=list(ioff), epi=epi, aux=aux, dst=dst, dst_acc=dst_acc,
-                    Cout=N // 2 if epi == EPI_GLU else N, stats=stats, nsets=nsets, stat_slope0=stat_slopes[0],
-                    stat_slope1=stat_slopes[1], stat_tiles=stat_tiles, stat_tile0=stat_tile0, bm=bm, name=name)
+                    Cout=N // 2 if epi in (EPI_GLU, EPI_DUALGATE) else N, stats=stats, nsets=nsets,
+                    stat_slope0=stat_slopes[0], stat_slope1=stat_slopes[1], stat_tiles=stat_tiles,
+                    stat_tile0=stat_tile0, bm=bm, name=name, **finkw)
         self.ops.append(op)
         self.flops += 2 * self.B * self.T * No * N * len(dt) * (C0 + C1)
         return op
@@ -408,11 +430,15 @@ class Lowering:
 
     # -- squeezed TCM --------------------------------------------------------------------
     def tcm(self, pre: str, x: Act, dilation: int, x_acc: Optional[Ref], perm: np.ndarray) -> Act:
-        """SqueezedTCM.forward, reference EaBNet.py:572-578, on [B][T][1][256]."""
+        """SqueezedTCM.forward, reference EaBNet.py:572-578, on [B][T][1][256], in three
+        launches: in_conv (+ statistics of both branch PReLUs) -> left*sigmoid(right) in ONE
+        dual-transform gated conv -> out_conv + residual.  T/64 tiles per utterance are few, so
+        each consumer reduces the InstanceNorm partials itself (no finalize launches)."""
         cfg, T, B = self.cfg, self.T, self.B
         D, cd, kd = cfg.d_feat, cfg.cd1, cfg.kd1
         bm = 64
         tiles = conv_tiles(T, 1, bm)
+        assert tiles <= 64, "in-kernel finalisation is sized for <= 64 partial tiles per utterance"
         # in_conv 1x1 (no bias); statistics of BOTH branch PReLUs of its output
         w_in = self.P[f"{pre}.in_conv.weight"][:, perm, :]               # (cd, D, 1)
         wref = self.W.add(f"{pre}.in_conv.weight#packed", pack_taps(w_in, [0]))
@@ -421,28 +447,24 @@ class Lowering:
         slL, slR = self.vec(f"{pre}.left_conv.0.weight"), self.vec(f"{pre}.right_conv.0.weight")
         self.emit_conv(f"{pre}.in_conv", [x], wref, None, cd, D, 1, 1, 1, 0, 1, [0], [0], EPI_LINEAR, y,
                        st, 2, (slL, slR), tiles, 0, bm)
-        xfL, xfR = self.emit_finalize(f"{pre}.in_conv.in", st, cd, 2, tiles, T,
-                                      [f"{pre}.left_conv.1", f"{pre}.right_conv.1"])
+        # z = left(y) * sigmoid(right(y)): columns [0,cd) see PReLU_L/IN_L(y), columns [cd,2cd) PReLU_R/IN_R(y)
         dts = [-(kd - 1 - j) * dilation for j in range(kd)]
-        zeros = [0] * kd
-        kp = kd * ((cd + 15) // 16) * 16
-        # left branch -> raw; right branch gates it: z = left * sigmoid(right)
-        wl = self.W.add(f"{pre}.left_conv.3.weight#packed", pack_taps(self.P[f"{pre}.left_conv.3.weight"], range(kd)))
-        wr = self.W.add(f"{pre}.right_conv.3.weight#packed", pack_taps(self.P[f"{pre}.right_conv.3.weight"], range(kd)))
-        left = self.alloc_act(1, cd)
-        self.emit_conv(f"{pre}.left_conv", [Act(y, 1, cd, xfL, slL, XF_PRELU_NORM)], wl, None, cd, kp, 1, 1, 1, 0, 1,
-                       dts, zeros, EPI_LINEAR, left, bm=bm)
+        wlr = np.concatenate([self.P[f"{pre}.left_conv.3.weight"], self.P[f"{pre}.right_conv.3.weight"]], axis=0)
+        wd = self.W.add(f"{pre}.lr_conv.weight#packed", pack_taps(wlr[glu_row_order(2 * cd)], range(kd)))
         z = self.alloc_act(1, cd)
         st2 = self.alloc(B * tiles * cd * 2)
         slO = self.vec(f"{pre}.out_conv.0.weight")
-        self.emit_conv(f"{pre}.right_conv", [Act(y, 1, cd, xfR, slR, XF_PRELU_NORM)], wr, None, cd, kp, 1, 1, 1, 0, 1,
-                       dts, zeros, EPI_MULSIG, z, st2, 1, (slO, None), tiles, 0, bm, aux=left)
-        xfZ, = self.emit_finalize(f"{pre}.out_conv.in", st2, cd, 1, tiles, T, [f"{pre}.out_conv.1"])
+        self.emit_conv(f"{pre}.lr_conv", [Act(y, 1, cd, None, slL, XF_PRELU_NORM)], wd, None, 2 * cd,
+                       kd * ((cd + 15) // 16) * 16, 1, 1, 1, 0, 1, dts, [0] * kd, EPI_DUALGATE, z, st2, 1, (slO, None),
+                       tiles, 0, bm, slope1=slR,
+                       fin=dict(stats=st, tiles=tiles, nsets=2, count=T,
+                                norms=[f"{pre}.left_conv.1", f"{pre}.right_conv.1"]))
         w_out = self.P[f"{pre}.out_conv.2.weight"][perm]                  # (D, cd, 1), rows permuted
         wo = self.W.add(f"{pre}.out_conv.2.weight#packed", pack_taps(w_out, [0]))
         xn = self.alloc_act(1, D)
-        self.emit_conv(f"{pre}.out_conv", [Act(z, 1, cd, xfZ, slO, XF_PRELU_NORM)], wo, None, D, cd, 1, 1, 1, 0, 1,
-                       [0], [0], EPI_ADD, xn, bm=bm, aux=x.ref, dst_acc=x_acc)
+        self.emit_conv(f"{pre}.out_conv", [Act(z, 1, cd, None, slO, XF_PRELU_NORM)], wo, None, D, cd, 1, 1, 1, 0, 1,
+                       [0], [0], EPI_ADD, xn, bm=bm, aux=x.ref, dst_acc=x_acc,
+                       fin=dict(stats=st2, tiles=tiles, nsets=1, count=T, norms=[f"{pre}.out_conv.1"]))
         return Act(xn, 1, D)
 
     # -- whole network ----------------------------------------------------------------------

@@ -102,6 +102,10 @@ int eab_filter_sum_f32(const float* w, const float* x, float* y, int B, int T, i
 #define EAB_EPI_RELU    2     /* out = max(acc, 0)                           */
 #define EAB_EPI_MULSIG  3     /* out = aux * sigmoid(acc)    (S-TCM gate)    */
 #define EAB_EPI_ADD     4     /* out = acc + aux             (residual)      */
+#define EAB_EPI_DUALGATE 5    /* S-TCM left*sigmoid(right) in ONE launch: N = 2*Cout, single source src0;
+                               * columns [0,Cout) see src0 through transform 0 (xf0/slope0), columns
+                               * [Cout,2Cout) through transform 1 (xf1/slope1) of the SAME tensor;
+                               * out[c] = acc[c] * sigmoid(acc[Cout + c]); rows interleaved as for GLU */
 
 typedef struct eab_conv_desc {
     /* sources, channels-last [B][T][Fin][C*]; src1 == NULL when there is no concat */
@@ -143,6 +147,17 @@ typedef struct eab_conv_desc {
     int32_t stat_tiles;     /* tiles per batch element over ALL launches feeding this norm */
     int32_t stat_tile0;     /* first tile index of this launch */
     int32_t bm;             /* rows per tile: 64 or 128 (host's choice, see eab_conv_tiles) */
+    /* optional in-kernel InstanceNorm finalisation (replaces eab_in_finalize_f32 + xf0[/xf1]
+     * when the producer wrote few tiles): fin_stats = the producer's partials
+     * [B][fin_tiles][fin_nsets][C0][2]; set 0 -> transform 0 with (fin_gamma0, fin_beta0),
+     * set 1 -> transform 1 (EAB_EPI_DUALGATE only).  xf0/xf1 must be NULL then. */
+    const float* fin_stats;
+    const float* fin_gamma0;
+    const float* fin_beta0;
+    const float* fin_gamma1;
+    const float* fin_beta1;
+    int32_t fin_tiles, fin_nsets, fin_count;
+    float fin_eps;
 } eab_conv_desc;
 
 /* number of tiles per batch element a launch with this geometry produces */

@@ -42,16 +42,36 @@ class Emulator:
     # ------------------------------------------------------------------ ops
     def conv(self, op: prg.ConvOp):
         B, T, Fin, No = op.B, op.T, op.Fin, op.No
-        srcs = []
-        for ref, xf, sl, Cs in ((op.src0, op.xf0, op.slope0, op.C0), (op.src1, op.xf1, op.slope1, op.C1)):
+        def xform(x, tab, a):
+            s, h = tab[:, None, None, :, 0], tab[:, None, None, :, 1]
+            return _prelu(x * s + h, a) if op.xf_mode == prg.XF_NORM_PRELU else _prelu(x, a) * s + h
+
+        dual = op.epi == prg.EPI_DUALGATE
+        fin_tabs = None
+        if op.fin_stats is not None:         # in-kernel InstanceNorm finalisation
+            st = self.v(op.fin_stats, (B, op.fin_tiles, op.fin_nsets, op.C0, 2)).astype(np.float64)
+            assert not np.isnan(st).any(), f"{op.name}: producer partials not fully written"
+            fin_tabs = []
+            for k, (g, bb) in enumerate(((op.fin_gamma0, op.fin_beta0), (op.fin_gamma1, op.fin_beta1))):
+                if g is None:
+                    break
+                tot = st[:, :, k].sum(1)
+                mean = tot[..., 0] / op.fin_count
+                var = np.maximum(tot[..., 1] / op.fin_count - mean * mean, 0)
+                scale = self.v(g, (op.C0,)) / np.sqrt(var + op.fin_eps)
+                fin_tabs.append(np.stack([scale, self.v(bb, (op.C0,)) - mean * scale], -1).astype(np.float32))
+        srcs, X2 = [], None
+        for i, (ref, xf, sl, Cs) in enumerate(((op.src0, op.xf0, op.slope0, op.C0), (op.src1, op.xf1, op.slope1, op.C1))):
             if ref is None:
                 continue
             x = self.v(ref, (B, T, Fin, Cs)).astype(np.float32)
-            if xf is not None and op.xf_mode != prg.XF_NONE:
-                tab = self.v(xf, (B, Cs, 2))
-                s, h = tab[:, None, None, :, 0], tab[:, None, None, :, 1]
-                a = self.v(sl, (Cs,))
-                x = _prelu(x * s + h, a) if op.xf_mode == prg.XF_NORM_PRELU else _prelu(x, a) * s + h
+            tab = fin_tabs[0] if (fin_tabs is not None and i == 0) else (self.v(xf, (B, Cs, 2)) if xf is not None else None)
+            if dual:
+                assert i == 0 and op.src1 is None
+                tab1 = fin_tabs[1] if fin_tabs is not None else self.v(op.xf1, (B, Cs, 2))
+                X2 = xform(x, tab1, self.v(op.slope1, (Cs,)))
+            if tab is not None and op.xf_mode != prg.XF_NONE:
+                x = xform(x, tab, self.v(sl, (Cs,)))
             srcs.append(x)
         X = np.concatenate(srcs, axis=-1)
         Ct = X.shape[-1]
@@ -72,8 +92,16 @@ class Emulator:
             tv = T + dt
             if tv > 0:
                 G[:, -dt:, ok] = X[:, :tv][:, :, fi[ok]]
-            acc += G @ W[:, j, :Ct].T
-        if op.epi == prg.EPI_GLU:
+            if not dual:
+                acc += G @ W[:, j, :Ct].T
+            else:                            # packed rows with (r % 64) < 32 are "left", the others "right"
+                G2 = np.zeros_like(G)
+                if tv > 0:
+                    G2[:, -dt:, ok] = X2[:, :tv][:, :, fi[ok]]
+                left = (np.arange(op.N) % 64) < 32
+                acc[..., left] += G @ W[left, j, :Ct].T
+                acc[..., ~left] += G2 @ W[~left, j, :Ct].T
+        if op.epi in (prg.EPI_GLU, prg.EPI_DUALGATE):
             c = np.arange(op.N // 2)
             rv = (c // 32) * 64 + c % 32
             out = acc[..., rv] * _sig(acc[..., rv + 32])
