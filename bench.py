@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--precision", choices=("f32", "f16x3"), default="f32",
+                    help="MFMA arithmetic of the timed path (DESIGN.md §4.4)")
     ap.add_argument("--per-op", type=str, default="", help="write the per-op timing table (instrumented replay) here")
     a = ap.parse_args()
 
@@ -138,6 +140,7 @@ def main():
     L = int(SECONDS * SR)
     T = 1 + L // HOP
     net, state = make_model(MICS, dev)
+    net.precision = a.precision
     wav = synth_waves(B_PER_GPU, MICS, L, 1234 + rank).to(dev)    # resident in HBM before timing
     window = torch.hann_window(N_FFT)
 

@@ -36,6 +36,7 @@ class ConvDesc(C.Structure):
         ("fin_stats", C.c_void_p), ("fin_gamma0", C.c_void_p), ("fin_beta0", C.c_void_p),
         ("fin_gamma1", C.c_void_p), ("fin_beta1", C.c_void_p),
         ("fin_tiles", C.c_int32), ("fin_nsets", C.c_int32), ("fin_count", C.c_int32), ("fin_eps", C.c_float),
+        ("precision", C.c_int32),
     ]
 
 
@@ -59,6 +60,7 @@ _SIGS = {
     "eab_in_finalize_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_float] + [C.c_void_p] * 6 + [C.c_void_p]),
     "eab_norm_act_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 3 + [C.c_void_p]),
     "eab_lstm64_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_float] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
+    "eab_lstm64_prec_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_float] + [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
     "eab_bfw_filter_sum_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p]),
     "eab_run_program": (C.c_int, [C.POINTER(Op), C.c_int, C.c_void_p]),
     "eab_sizeof_conv_desc": (C.c_int, []),

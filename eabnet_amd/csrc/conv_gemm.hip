@@ -77,8 +77,21 @@ __device__ __forceinline__ int cg_div(int q, int n, float inv_n) {
     return t;
 }
 
-template <int MI, int NI, int KU, int MODE, int XF, bool VEC>
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
+
+// x = hi + lo with hi = x truncated to fp16 and lo = fp16(x - hi), two elements at a time
+// (v_cvt_pkrtz_f16_f32; fp16 subnormals are honoured by the f16 MFMA, probed on gfx950).
+__device__ __forceinline__ void cg_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const h16x2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    const h16x2 l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+template <int MI, int NI, int KU, int MODE, int XF, bool VEC, int PREC>
 __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_desc d) {
+    constexpr bool H3 = PREC == EAB_PREC_F16X3;
     constexpr bool GLU = MODE != CG_PLAIN;          // gated epilogue (value tile, gate tile per lane)
     constexpr bool DUAL = MODE == CG_DUAL;
     using Smem = CgSmem<MI, NI, KU, MODE>;
@@ -184,13 +197,16 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
     // the transposed conv's implicit zeros come after norm+PReLU), so out-of-range
     // taps must stay exactly 0 through the fused transform: st_ok remembers which
     // staged rows are real.
-    f32x4 ra[KU][MI], rb[KU][NI];
-    int r_tc[KU];                   // (table << 8 | first channel) of the staged float4
-    bool st_ok[KU][MI];
+    struct Stage {                  // one pipeline stage in flight in registers
+        f32x4 ra[KU][MI], rb[KU][NI];
+        int r_tc[KU];               // (table << 8 | first channel) of the staged float4
+        bool st_ok[KU][MI];
+    };
+    Stage sa;                       // stage s+1 in flight while stage s is multiplied
 
     __syncthreads();   // tap tables visible
 
-    auto fetch = [&](int stage) {
+    auto fetch = [&](int stage, Stage& rg) {
 #pragma unroll
         for (int ku = 0; ku < KU; ++ku) {
             const int u = stage * KU + ku;
@@ -207,12 +223,12 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
             for (int p = 0; p < MI; ++p) {
                 const int tt = a_t[p] + dt, fi = a_f0[p] + io;
                 const bool ok = a_ok[p] && cok && tt >= 0 && fi >= 0 && fi < d.Fin;
-                st_ok[ku][p] = ok;
+                rg.st_ok[ku][p] = ok;
                 const unsigned off = ok ? (unsigned)(((a_tf[p] + dt * d.Fin + io) * Cs + c) * 4) : CG_OOB;
                 if (VEC) {
                     const u32x4 v = second ? __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0)
                                            : __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0);
-                    ra[ku][p] = __builtin_bit_cast(f32x4, v);
+                    rg.ra[ku][p] = __builtin_bit_cast(f32x4, v);
                 } else {
                     // channel counts that are not multiples of 4 (odd microphone counts): dword gathers
 #pragma unroll
@@ -220,28 +236,28 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
                         const unsigned oj = (ok && c + j < Cs) ? off + 4u * j : CG_OOB;
                         const unsigned v = second ? __builtin_amdgcn_raw_buffer_load_b32(rs1, oj, 0, 0)
                                                   : __builtin_amdgcn_raw_buffer_load_b32(rs0, oj, 0, 0);
-                        ra[ku][p][j] = __builtin_bit_cast(float, v);
+                        rg.ra[ku][p][j] = __builtin_bit_cast(float, v);
                     }
                 }
             }
-            r_tc[ku] = ((second ? 1 : 0) << 8) | (cok ? c : 0);
+            rg.r_tc[ku] = ((second ? 1 : 0) << 8) | (cok ? c : 0);
 #pragma unroll
             for (int p = 0; p < NI; ++p) {
-                rb[ku][p] = *reinterpret_cast<const f32x4*>(wrow[p] + (size_t)uu * 16);
-                if (!live) rb[ku][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+                rg.rb[ku][p] = *reinterpret_cast<const f32x4*>(wrow[p] + (size_t)uu * 16);
+                if (!live) rg.rb[ku][p] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
     };
 
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, const Stage& rg) {
 #pragma unroll
         for (int ku = 0; ku < KU; ++ku) {
             f32x4 sh01[2], sh23[2], sl[2];
             if (XF != EAB_XF_NONE) {
-                const int cc = r_tc[ku] & 0xFF;
+                const int cc = rg.r_tc[ku] & 0xFF;
 #pragma unroll
                 for (int k = 0; k < (DUAL ? 2 : 1); ++k) {
-                    const int tb = DUAL ? k : (r_tc[ku] >> 8);
+                    const int tb = DUAL ? k : (rg.r_tc[ku] >> 8);
                     sh01[k] = *reinterpret_cast<const f32x4*>(&sm.xft[tb][cc][0]);
                     sh23[k] = *reinterpret_cast<const f32x4*>(&sm.xft[tb][cc + 2][0]);
                     sl[k] = *reinterpret_cast<const f32x4*>(&sm.xsl[tb][cc]);
@@ -251,17 +267,35 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
             for (int p = 0; p < MI; ++p) {
 #pragma unroll
                 for (int k = 0; k < (DUAL ? 2 : 1); ++k) {
-                    f32x4 v = ra[ku][p];
+                    f32x4 v = rg.ra[ku][p];
                     if (XF != EAB_XF_NONE) {
                         const f32x4 x = cg_xform<XF>(v, sh01[k], sh23[k], sl[k]);
-                        v = st_ok[ku][p] ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+                        v = rg.st_ok[ku][p] ? x : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
-                    *reinterpret_cast<f32x4*>(&sm.a[k][buf][(srow + 64 * p) * LDK + ku * 16 + skq * 4]) = v;
+                    float* arow = &sm.a[k][buf][(srow + 64 * p) * LDK + ku * 16];
+                    if (H3) {
+                        // unit layout in LDS (64 B): 16 fp16 hi | 16 fp16 lo; this thread owns channels 4*skq..+3
+                        unsigned h01, l01, h23, l23;
+                        cg_split2(v[0], v[1], h01, l01);
+                        cg_split2(v[2], v[3], h23, l23);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(arow) + skq * 8) = make_uint2(h01, h23);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(arow) + 32 + skq * 8) = make_uint2(l01, l23);
+                    } else {
+                        *reinterpret_cast<f32x4*>(arow + skq * 4) = v;
+                    }
                 }
             }
 #pragma unroll
-            for (int p = 0; p < NI; ++p)
-                *reinterpret_cast<f32x4*>(&sm.b[buf][(srow + 64 * p) * LDK + ku * 16 + skq * 4]) = rb[ku][p];
+            for (int p = 0; p < NI; ++p) {
+                float* brow = &sm.b[buf][(srow + 64 * p) * LDK + ku * 16];
+                if (H3) {   // global: [4 hi | 4 lo] per 4-channel group  ->  LDS: [16 hi | 16 lo] per unit
+                    const u32x4 w = __builtin_bit_cast(u32x4, rg.rb[ku][p]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(brow) + skq * 8) = make_uint2(w[0], w[1]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(brow) + 32 + skq * 8) = make_uint2(w[2], w[3]);
+                } else {
+                    *reinterpret_cast<f32x4*>(brow + skq * 4) = rg.rb[ku][p];
+                }
+            }
         }
     };
 
@@ -273,16 +307,48 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
-    fetch(0);
-    stash(0);
-    __syncthreads();
+    // LDS writes must be visible, global loads may stay in flight across the barrier
+    // (__syncthreads() would add s_waitcnt vmcnt(0) and drain the two-stage prefetch).
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    fetch(0, sa);
+    stash(0, sa);
+    lds_barrier();
 
     const int a_base = (wm * MI * 32 + li) * LDK + 4 * lh;
     const int b_base = (wn * NI * 32 + li) * LDK + 4 * lh;
 
-    for (int s = 0; s < NS; ++s) {
-        const int cur = s & 1;
-        if (s + 1 < NS) fetch(s + 1);
+    auto compute = [&](int cur) {
+        if (H3) {
+            // one v_mfma_f32_32x32x16_f16 spans a whole 16-channel unit: lane (i, h) holds k = 8h..8h+7
+#pragma unroll
+            for (int ku = 0; ku < KU; ++ku) {
+                h16x8 ah[Smem::NA][MI], al[Smem::NA][MI], bh[NI], bl[NI];
+#pragma unroll
+                for (int k = 0; k < Smem::NA; ++k)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const char* pa = reinterpret_cast<const char*>(&sm.a[k][cur][a_base + mi * 32 * LDK + ku * 16]);
+                        ah[k][mi] = *reinterpret_cast<const h16x8*>(pa);
+                        al[k][mi] = *reinterpret_cast<const h16x8*>(pa + 32);
+                    }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const char* pb = reinterpret_cast<const char*>(&sm.b[cur][b_base + ni * 32 * LDK + ku * 16]);
+                    bh[ni] = *reinterpret_cast<const h16x8*>(pb);
+                    bl[ni] = *reinterpret_cast<const h16x8*>(pb + 32);
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const int ka = DUAL ? ni : 0;
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ka][mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ka][mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ka][mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                    }
+            }
+        } else {
 #pragma unroll
         for (int g = 0; g < 2 * KU; ++g) {
             f32x4 af[Smem::NA][MI], bf[NI];
@@ -303,8 +369,16 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[DUAL ? ni : 0][mi][k], bf[ni][k],
                                                                            acc[mi][ni], 0, 0, 0);
         }
-        if (s + 1 < NS) stash(cur ^ 1);
-        __syncthreads();
+        }
+    };
+    // (a second register set for a two-stage prefetch costs a wave of occupancy -- 195 vs 154
+    // registers -- and measured slower in both precisions)
+    for (int s = 0; s < NS; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < NS) fetch(s + 1, sa);
+        compute(cur);
+        if (s + 1 < NS) stash(cur ^ 1, sa);
+        lds_barrier();
     }
 
     // ---- epilogue ---------------------------------------------------------------
@@ -465,7 +539,15 @@ static int cg_launch(const eab_conv_desc* d, hipStream_t s) {
     constexpr int BM = 64 * MI, BN = 64 * NI;
     const int tiles = eab_conv_tiles(d->T, d->No, BM);
     dim3 grid((unsigned)(d->B * tiles), (unsigned)(d->N / BN));
-    hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, KU, MODE, XF, VEC>), grid, dim3(CG_THREADS), 0, s, *d);
+    if (d->precision == EAB_PREC_F16X3) {
+        if constexpr (VEC)
+            hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, KU, MODE, XF, VEC, EAB_PREC_F16X3>), grid, dim3(CG_THREADS), 0,
+                               s, *d);
+        else
+            return EAB_EUNSUPPORTED;
+    } else {
+        hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, KU, MODE, XF, VEC, EAB_PREC_F32>), grid, dim3(CG_THREADS), 0, s, *d);
+    }
     EAB_RETURN_LAUNCH_STATUS();
 }
 
@@ -506,6 +588,7 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
     EAB_CHECK_ARG(d->Kpad == d->ntaps * upt * 16);
     for (int j = 0; j < d->ntaps; ++j) EAB_CHECK_ARG(d->dt[j] <= 0 && d->dt[j] > -(1 << 20));
     EAB_CHECK_ARG(d->epi >= EAB_EPI_LINEAR && d->epi <= EAB_EPI_DUALGATE);
+    EAB_CHECK_ARG(d->precision == EAB_PREC_F32 || d->precision == EAB_PREC_F16X3);
     const bool dual = d->epi == EAB_EPI_DUALGATE;
     const bool glu = d->epi == EAB_EPI_GLU;
     EAB_CHECK_ARG(d->Cout == ((glu || dual) ? d->N / 2 : d->N));

@@ -229,12 +229,24 @@ __global__ __launch_bounds__(256) void lstm64_kernel(const float* __restrict__ x
     }
 }
 
+int eab_lstm64_h3_launch(const float* x, const float* ln_g, const float* ln_b, float ln_eps, const float* wcat,
+                         const float* bias, float* h_out, int T, int F, int S, hipStream_t stream);   // lstm_h3.hip
+
 extern "C" int eab_lstm64_f32(const float* x, const float* ln_g, const float* ln_b, float ln_eps, const float* wcat,
                               const float* bias, float* h_out, int B, int T, int F, eab_stream_t stream) {
+    return eab_lstm64_prec_f32(x, ln_g, ln_b, ln_eps, wcat, bias, h_out, B, T, F, EAB_PREC_F32, stream);
+}
+
+extern "C" int eab_lstm64_prec_f32(const float* x, const float* ln_g, const float* ln_b, float ln_eps,
+                                   const float* wcat, const float* bias, float* h_out, int B, int T, int F,
+                                   int precision, eab_stream_t stream) {
     EAB_CHECK_ARG(x && wcat && bias && h_out && B > 0 && T > 0 && F > 0);
+    EAB_CHECK_ARG(precision == EAB_PREC_F32 || precision == EAB_PREC_F16X3);
     EAB_CHECK_ARG((ln_g == nullptr) == (ln_b == nullptr));
     const long long S = (long long)B * F;
     EAB_CHECK_ARG(S * T * LS_H * 4 < (1ll << 31));          // 31-bit byte offsets in the buffer descriptors
+    if (precision == EAB_PREC_F16X3)
+        return eab_lstm64_h3_launch(x, ln_g, ln_b, ln_eps, wcat, bias, h_out, T, F, (int)S, eab_stream(stream));
     const int grid = (int)((S + LS_SEQ - 1) / LS_SEQ);
     if (ln_g)
         hipLaunchKernelGGL(lstm64_kernel<true>, dim3(grid), dim3(256), 0, eab_stream(stream), x, ln_g, ln_b, ln_eps,

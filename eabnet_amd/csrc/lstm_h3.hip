@@ -1,0 +1,218 @@
+// K10+K11 in EAB_PREC_F16X3 arithmetic: LayerNorm(64) + one LSTM(64->64) layer on the f16
+// matrix cores (v_mfma_f32_16x16x32_f16), every fp32 operand split x = hi + lo and every
+// product taken as lo*hi + hi*lo + hi*hi with fp32 accumulation (include/eabnet_hip.h).
+// Reference: LSTM_BF.forward, EaBNet.py:608-611.
+//
+// Same ownership as the fp32 kernel (csrc/lstm.hip): one workgroup = 16 sequences for all T
+// steps, wave w = hidden units 16w..16w+15 (i,f,g,o columns of the same units), weights
+// register-resident (128 VGPRs of fp16 hi/lo fragments).  What changes is the bound: the 48
+// MFMAs of a step take ~770 matrix-pipe cycles instead of 4096, and f16 MFMAs co-execute with
+// VALU, so a step is bound by the recurrence chain
+//     H-MFMAs (24) -> cell update (exp/rcp) -> h_t hi/lo -> LDS -> barrier -> fragments
+// and the input half (24 MFMAs of step t+1) is issued behind the barrier where it covers the
+// LDS round trip.
+#include "common.h"
+#include <type_traits>
+
+#define LH_SEQ 16
+#define LH_ROW 272          // bytes: 2 k-blocks x (32 hi + 32 lo halves) + 16 pad (odd 16-byte-slot stride)
+#define LH_OOB 0x80000000u
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float lh_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float lh_tanh(float x) { return fmaf(2.0f, lh_sigmoid(2.0f * x), -1.0f); }
+
+__device__ __forceinline__ float lh_row_sum(float v) {     // sum over the 16 lanes of a DPP row
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});
+    v += dpp(v, std::integral_constant<int, 0x4E>{});
+    v += dpp(v, std::integral_constant<int, 0x141>{});
+    v += dpp(v, std::integral_constant<int, 0x140>{});
+    return v;
+}
+
+__device__ __forceinline__ void lh_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const h16x2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    const h16x2 l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+template <bool LN>
+__global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict__ x, const float* __restrict__ ln_g,
+                                                        const float* __restrict__ ln_b, float ln_eps,
+                                                        const float* __restrict__ wcat, const float* __restrict__ bias,
+                                                        float* __restrict__ h_out, int T, int F, int S) {
+    __shared__ __attribute__((aligned(16))) char xs[2][LH_SEQ * LH_ROW];
+    __shared__ __attribute__((aligned(16))) char hs[2][LH_SEQ * LH_ROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ln = lane & 15, lk = lane >> 4;
+    const int s0 = blockIdx.x * LH_SEQ;
+
+    // ---- stationary weights as fp16 hi/lo B fragments:
+    //      w?[g][kb] = W[g*64 + 16w + ln][(x:0 | h:64) + 32*kb + 8*lk + j], j = 0..7
+    h16x8 wxh[4][2], wxl[4][2], whh[4][2], whl[4][2];
+    float bia[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int row = g * 64 + wave * 16 + ln;
+        bia[g] = bias[row];
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const float* p = &wcat[(size_t)row * 128 + half * 64 + 32 * kb + 8 * lk];
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
+                h16x8 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float w = j < 4 ? v0[j] : v1[j - 4];
+                    hi[j] = (_Float16)w;
+                    lo[j] = (_Float16)(w - (float)hi[j]);
+                }
+                if (half == 0) { wxh[g][kb] = hi; wxl[g][kb] = lo; } else { whh[g][kb] = hi; whl[g][kb] = lo; }
+            }
+    }
+
+    // ---- loader role: thread -> (sequence ls, channels lc..lc+3)
+    const int ls = tid >> 4, lc = (tid & 15) * 4;
+    const int sg = s0 + ls;
+    const bool sv = sg < S;
+    const int sb = sv ? sg / F : 0, sf = sv ? sg - sb * F : 0;
+    const unsigned total_bytes = (unsigned)S * (unsigned)T * 256u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, total_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(h_out, 0, total_bytes, 0x00020000);
+    const unsigned seq_off = (unsigned)((((size_t)sb * T * F + sf) * 64 + lc) * 4);
+    const unsigned t_stride = (unsigned)F * 256u;
+    f32x4 g4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f};
+    if (LN) {
+        g4 = *reinterpret_cast<const f32x4*>(ln_g + lc);
+        b4 = *reinterpret_cast<const f32x4*>(ln_b + lc);
+    }
+    // byte offset of channel lc inside a row: k-block lc/32, then hi at +0 / lo at +64
+    const int lrow = ls * LH_ROW + (lc >> 5) * 128 + (lc & 31) * 2;
+
+    auto load_x = [&](int t) -> f32x4 {
+        const unsigned off = (sv && t < T) ? seq_off + (unsigned)t * t_stride : LH_OOB;
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+    };
+    auto norm_store = [&](f32x4 v, int buf) {
+        if (LN) {
+            const float mean = lh_row_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 64.0f);
+            f32x4 dlt = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
+            const float q = lh_row_sum((dlt[0] * dlt[0] + dlt[1] * dlt[1]) + (dlt[2] * dlt[2] + dlt[3] * dlt[3]));
+            const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + ln_eps);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = dlt[j] * rstd * g4[j] + b4[j];
+        }
+        unsigned h01, l01, h23, l23;
+        lh_split2(v[0], v[1], h01, l01);
+        lh_split2(v[2], v[3], h23, l23);
+        *reinterpret_cast<uint2*>(&xs[buf][lrow]) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(&xs[buf][lrow + 64]) = make_uint2(l01, l23);
+    };
+    // A fragments of a 16 x 64 tile: lane (m = ln, kq = lk) holds k = 32*kb + 8*kq + j
+    auto frags = [&](const char* tile, h16x8 (&ah)[2], h16x8 (&al)[2]) {
+        const char* p = tile + ln * LH_ROW + lk * 16;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            ah[kb] = *reinterpret_cast<const h16x8*>(p + kb * 128);
+            al[kb] = *reinterpret_cast<const h16x8*>(p + kb * 128 + 64);
+        }
+    };
+    auto mma = [&](const h16x8 (&ah)[2], const h16x8 (&al)[2], const h16x8 (&wh)[4][2], const h16x8 (&wl)[4][2],
+                   f32x4 (&acc)[4]) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kb], wh[g][kb], acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kb], wl[g][kb], acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kb], wh[g][kb], acc[g], 0, 0, 0);
+            }
+    };
+
+    // prologue: h_{-1} = 0 (hi and lo), x_0 / x_1 in LDS, accx = b + W_x x_0
+    for (int e = tid; e < LH_SEQ * LH_ROW / 4; e += 256) reinterpret_cast<unsigned*>(hs[0])[e] = 0u;
+    norm_store(load_x(0), 0);
+    norm_store(load_x(1), 1);
+    float cst[4] = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    f32x4 accx[4];
+    h16x8 xh[2], xl[2], hh[2], hl[2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) accx[g] = f32x4{bia[g], bia[g], bia[g], bia[g]};
+    frags(xs[0], xh, xl);
+    mma(xh, xl, wxh, wxl, accx);
+    frags(hs[0], hh, hl);
+    f32x4 xq = load_x(2), xr = load_x(3);
+
+    const int u = wave * 16 + ln;
+    const int hcol = (u >> 5) * 128 + (u & 31) * 2;         // byte offset of unit u inside a row (hi; lo at +64)
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        const f32x4 xn = load_x(t + 4);
+
+        // ---- recurrence: acc = accx + W_h h_{t-1}, then the cell update
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = accx[g];
+        mma(hh, hl, whh, whl, acc);
+        norm_store(xq, cur);                            // x_{t+2} replaces x_t; VALU work beside the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        char* hrow = &hs[nxt][hcol];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                   // lane holds unit u for sequences 4*lk + r
+            const float ig = lh_sigmoid(acc[0][r]);
+            const float fg = lh_sigmoid(acc[1][r]);
+            const float gg = lh_tanh(acc[2][r]);
+            const float og = lh_sigmoid(acc[3][r]);
+            cst[r] = fmaf(fg, cst[r], ig * gg);
+            const float h = og * lh_tanh(cst[r]);
+            const _Float16 hi = (_Float16)h;
+            const _Float16 lo = (_Float16)(h - (float)hi);
+            *reinterpret_cast<_Float16*>(hrow + (4 * lk + r) * LH_ROW) = hi;
+            *reinterpret_cast<_Float16*>(hrow + (4 * lk + r) * LH_ROW + 64) = lo;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: keep the x prefetch in flight
+        frags(hs[nxt], hh, hl);
+        // coalesced write-back of h_t (hi + lo reproduces h to 2^-21)
+        const uint2 ph = *reinterpret_cast<const uint2*>(&hs[nxt][lrow]);
+        const uint2 pl = *reinterpret_cast<const uint2*>(&hs[nxt][lrow + 64]);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- input half of the next step: independent of the recurrence, covers the LDS round trip
+        frags(xs[nxt], xh, xl);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) accx[g] = f32x4{bia[g], bia[g], bia[g], bia[g]};
+        mma(xh, xl, wxh, wxl, accx);
+        {
+            const h16x2 a0 = __builtin_bit_cast(h16x2, ph.x), a1 = __builtin_bit_cast(h16x2, ph.y);
+            const h16x2 c0 = __builtin_bit_cast(h16x2, pl.x), c1 = __builtin_bit_cast(h16x2, pl.y);
+            const f32x4 hv = {(float)a0[0] + (float)c0[0], (float)a0[1] + (float)c0[1], (float)a1[0] + (float)c1[0],
+                              (float)a1[1] + (float)c1[1]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), rh,
+                                                   sv ? seq_off + (unsigned)t * t_stride : LH_OOB, 0, 0);
+        }
+        xq = xr;
+        xr = xn;
+    }
+}
+
+// dispatcher shared with csrc/lstm.hip
+int eab_lstm64_h3_launch(const float* x, const float* ln_g, const float* ln_b, float ln_eps, const float* wcat,
+                         const float* bias, float* h_out, int T, int F, int S, hipStream_t stream) {
+    const int grid = (S + LH_SEQ - 1) / LH_SEQ;
+    if (ln_g)
+        hipLaunchKernelGGL(lstm64_h3_kernel<true>, dim3(grid), dim3(256), 0, stream, x, ln_g, ln_b, ln_eps, wcat, bias,
+                           h_out, T, F, S);
+    else
+        hipLaunchKernelGGL(lstm64_h3_kernel<false>, dim3(grid), dim3(256), 0, stream, x, ln_g, ln_b, ln_eps, wcat,
+                           bias, h_out, T, F, S);
+    EAB_RETURN_LAUNCH_STATUS();
+}

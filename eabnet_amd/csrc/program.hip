@@ -32,9 +32,9 @@ extern "C" int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream
                                       (float*)o.p[6], o.i[0], o.i[1], o.i[2], stream);
                 break;
             case EAB_OP_LSTM64:
-                rc = eab_lstm64_f32((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2], o.f[0],
-                                    (const float*)o.p[3], (const float*)o.p[4], (float*)o.p[5], o.i[0], o.i[1], o.i[2],
-                                    stream);
+                rc = eab_lstm64_prec_f32((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2], o.f[0],
+                                         (const float*)o.p[3], (const float*)o.p[4], (float*)o.p[5], o.i[0], o.i[1],
+                                         o.i[2], o.i[3], stream);
                 break;
             case EAB_OP_BFW_FS:
                 rc = eab_bfw_filter_sum_f32((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],

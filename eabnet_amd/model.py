@@ -99,7 +99,7 @@ class _Bound:
                     setattr(d, f, A(getattr(op, f)))
                 for f in ("C0", "C1", "xf_mode", "N", "Kpad", "B", "T", "Fin", "Fout", "No", "ostride", "ophase",
                           "istride", "epi", "Cout", "nsets", "stat_tiles", "stat_tile0", "bm", "fin_tiles",
-                          "fin_nsets", "fin_count"):
+                          "fin_nsets", "fin_count", "precision"):
                     setattr(d, f, int(getattr(op, f)))
                 d.fin_eps = float(op.fin_eps)
                 d.ntaps = len(op.dt)
@@ -116,7 +116,7 @@ class _Bound:
                 for j, r in enumerate((op.a, op.xfa, op.slopea, op.b, op.xfb, op.slopeb, op.out)):
                     o.p[j] = A(r)
             elif op.kind == prg.OP_LSTM64:
-                o.i[0:3] = [op.B, op.T, op.F]
+                o.i[0:4] = [op.B, op.T, op.F, op.precision]
                 o.f[0] = op.ln_eps
                 for j, r in enumerate((op.x, op.ln_g, op.ln_b, op.wcat, op.bias, op.h_out)):
                     o.p[j] = A(r)
@@ -174,9 +174,12 @@ class EaBNet(nn.Module):
         self._specs = param_specs(self.cfg)          # raises NotImplementedError for unsupported topologies
         for key, spec in self._specs.items():
             _attach(self, key, nn.Parameter(_default_init(spec)))
-        self._bound: Dict[Tuple[int, int, int, str], _Bound] = {}
-        self._packed_version: Dict[Tuple[int, int, int, str], tuple] = {}
+        self._bound: Dict[tuple, _Bound] = {}
+        self._packed_version: Dict[tuple, tuple] = {}
         self.dump_bfw = False                         # tests: also emit the (B,T,F,M,2) beam-forming weights
+        # arithmetic of the MFMA contractions: "f32" = exact fp32 MFMA; "f16x3" = error-compensated
+        # fp16 split on the f16 matrix cores, same end-to-end error class as fp32
+        self.precision = "f32"
 
     # -- program cache -----------------------------------------------------------
     def _param_fingerprint(self) -> tuple:
@@ -187,16 +190,18 @@ class EaBNet(nn.Module):
         return {k: sd[k].detach().to("cpu", torch.float32).numpy() for k in self._specs}
 
     def _program(self, B: int, T: int, F: int, device: torch.device) -> _Bound:
-        key = (B, T, F, str(device))
+        key = (B, T, F, str(device), self.precision)
         fp = self._param_fingerprint()
         bound = self._bound.get(key)
         if bound is None or ("bf_w" in bound.prog.taps) != self.dump_bfw:
-            prog = prg.lower(self.cfg, self._numpy_params(), B, T, F, dump_bfw=self.dump_bfw)
+            prog = prg.lower(self.cfg, self._numpy_params(), B, T, F, dump_bfw=self.dump_bfw,
+                             precision=self.precision)
             bound = _Bound(prog, device)
             self._bound = {key: bound}                # keep one shape resident (activations can be GBs)
             self._packed_version = {key: fp}
         elif self._packed_version.get(key) != fp:
-            prog = prg.lower(self.cfg, self._numpy_params(), B, T, F, dump_bfw=self.dump_bfw)
+            prog = prg.lower(self.cfg, self._numpy_params(), B, T, F, dump_bfw=self.dump_bfw,
+                             precision=self.precision)
             bound.update_weights(prog.weights)
             self._packed_version[key] = fp
         return bound

@@ -31,6 +31,7 @@ from .spec import NetConfig, param_specs
 XF_NONE, XF_NORM_PRELU, XF_PRELU_NORM = 0, 1, 2
 EPI_LINEAR, EPI_GLU, EPI_RELU, EPI_MULSIG, EPI_ADD, EPI_DUALGATE = 0, 1, 2, 3, 4, 5
 OP_CONV, OP_IN_FINALIZE, OP_NORM_ACT, OP_LSTM64, OP_BFW_FS, OP_MEMSET0 = 1, 2, 3, 4, 5, 6
+PREC_F32, PREC_F16X3 = 0, 1
 MAX_TAPS = 16
 EPS_IN = 1e-5      # nn.InstanceNorm*d default (reference EaBNet.py:684,686)
 EPS_LN = 1e-5      # nn.LayerNorm default (reference EaBNet.py:598)
@@ -105,6 +106,7 @@ class ConvOp:
     fin_nsets: int = 0
     fin_count: int = 0
     fin_eps: float = 0.0
+    precision: int = PREC_F32
     name: str = ""
     kind: int = OP_CONV
 
@@ -156,6 +158,7 @@ class LstmOp:
     B: int
     T: int
     F: int
+    precision: int = PREC_F32
     name: str = ""
     kind: int = OP_LSTM64
 
@@ -210,11 +213,28 @@ def pack_taps(w_nck: np.ndarray, taps_k: Sequence[int]) -> np.ndarray:
     return out.reshape(N, -1)
 
 
+def pack_f16x3(wp: np.ndarray) -> np.ndarray:
+    """fp32 packed weights [N][Kpad] -> the f16x3 operand layout (include/eabnet_hip.h,
+    EAB_PREC_F16X3): per row and per group of 4 consecutive k, 4 fp16 hi then 4 fp16 lo with
+    w = hi + lo; returned as float32-typed storage of identical byte size."""
+    N, K = wp.shape
+    assert K % 4 == 0
+    if np.abs(wp).max(initial=0.0) >= 65504.0:
+        raise ValueError("f16x3 precision needs |weight| < 65504")
+    hi = wp.astype(np.float16)
+    lo = (wp - hi.astype(np.float32)).astype(np.float16)
+    out = np.empty((N, K // 4, 8), dtype=np.float16)
+    out[:, :, :4] = hi.reshape(N, K // 4, 4)
+    out[:, :, 4:] = lo.reshape(N, K // 4, 4)
+    return np.ascontiguousarray(out).view(np.float32).reshape(N, K)
+
+
 class WeightArena:
     """Flat fp32 buffer of packed parameters + name -> Ref table."""
 
     def __init__(self):
         self.chunks: List[np.ndarray] = []
+        self.chunks_by_name: Dict[str, np.ndarray] = {}
         self.size = 0
         self.index: Dict[str, Ref] = {}
 
@@ -225,6 +245,7 @@ class WeightArena:
         pad = (-flat.size) % ALIGN
         ref = Ref("w", self.size)
         self.chunks.append(flat)
+        self.chunks_by_name[name] = flat
         if pad:
             self.chunks.append(np.zeros(pad, dtype=np.float32))
         self.size += flat.size + pad
@@ -253,8 +274,11 @@ class Program:
 
 class Lowering:
     def __init__(self, cfg: NetConfig, params: Dict[str, np.ndarray], B: int, T: int, F: int = 161,
-                 dump_bfw: bool = False):
+                 dump_bfw: bool = False, precision: str = "f32"):
         cfg.check_supported()
+        if precision not in ("f32", "f16x3"):
+            raise ValueError(f"precision must be 'f32' or 'f16x3', got {precision!r}")
+        self.precision = precision
         specs = param_specs(cfg)
         missing = [k for k in specs if k not in params]
         if missing:
@@ -284,6 +308,9 @@ class Lowering:
 
     # -- generic conv emission -----------------------------------------------------
     def pick_bm(self, No: int) -> int:
+        import os
+        if os.environ.get("EAB_BM"):                     # tuning knob
+            return int(os.environ["EAB_BM"])
         return 128 if self.B * conv_tiles(self.T, No, 128) >= 2 * CUS else 64
 
     def emit_conv(self, name: str, srcs: Sequence[Act], w: Ref, bias: Optional[Ref], N: int, Kpad: int,
@@ -306,6 +333,14 @@ class Lowering:
         upt = (C0 + C1 + 15) // 16
         assert Kpad == len(dt) * upt * 16
         bm = bm or self.pick_bm(No)
+        # f16x3 needs bounded operands: every source except the raw network input is either
+        # instance-normalised or a sum of such tensors; the first conv stays on exact fp32.
+        prec = PREC_F16X3 if (self.precision == "f16x3" and s0.ref.arena != "in" and C0 % 4 == 0 and C1 % 4 == 0) \
+            else PREC_F32
+        if prec == PREC_F16X3:
+            key = next(k for k, r in self.W.index.items() if r == w)
+            wf = self.W.chunks_by_name[key].reshape(N, Kpad)
+            w = self.W.add(key + ".f16x3", pack_f16x3(wf))
         finkw = {}
         if fin is not None:
             assert s1 is None and s0.xf is None and mode != XF_NONE
@@ -321,7 +356,7 @@ class Lowering:
                     istride=istride, dt=list(dt), ioff=list(ioff), epi=epi, aux=aux, dst=dst, dst_acc=dst_acc,
                     Cout=N // 2 if epi in (EPI_GLU, EPI_DUALGATE) else N, stats=stats, nsets=nsets,
                     stat_slope0=stat_slopes[0], stat_slope1=stat_slopes[1], stat_tiles=stat_tiles,
-                    stat_tile0=stat_tile0, bm=bm, name=name, **finkw)
+                    stat_tile0=stat_tile0, bm=bm, name=name, precision=prec, **finkw)
         self.ops.append(op)
         self.flops += 2 * self.B * self.T * No * N * len(dt) * (C0 + C1)
         return op
@@ -518,7 +553,8 @@ class Lowering:
             self.ops.append(LstmOp(x=h.ref, ln_g=self.vec("bf_map.norm.weight") if li == 0 else None,
                                    ln_b=self.vec("bf_map.norm.bias") if li == 0 else None, ln_eps=EPS_LN,
                                    wcat=self.W.add(f"{p}#wcat", wcat), bias=self.W.add(f"{p}#bias", bias),
-                                   h_out=out, B=B, T=T, F=F, name=p))
+                                   h_out=out, B=B, T=T, F=F, name=p,
+                                   precision=PREC_F16X3 if self.precision == "f16x3" else PREC_F32))
             self.flops += 2 * B * T * F * 256 * 128
             h = Act(out, F, 64)
             self.taps[p] = h
@@ -536,5 +572,5 @@ class Lowering:
 
 
 def lower(cfg: NetConfig, params: Dict[str, np.ndarray], B: int, T: int, F: int = 161,
-          dump_bfw: bool = False) -> Program:
-    return Lowering(cfg, params, B, T, F, dump_bfw).build()
+          dump_bfw: bool = False, precision: str = "f32") -> Program:
+    return Lowering(cfg, params, B, T, F, dump_bfw, precision).build()

@@ -158,7 +158,17 @@ typedef struct eab_conv_desc {
     const float* fin_beta1;
     int32_t fin_tiles, fin_nsets, fin_count;
     float fin_eps;
+    /* arithmetic of the contraction.  EAB_PREC_F32: exact fp32 MFMA (fmaf chain).
+     * EAB_PREC_F16X3: every fp32 operand x is split x = hi + lo (hi = x truncated to
+     * fp16, lo = fp16(x - hi)) and a*b is taken as hi*hi + hi*lo + lo*hi on the f16
+     * matrix cores with fp32 accumulation (~22-bit products; requires |x| < 65504).
+     * Then `w` holds, per row n and per group of 4 consecutive k, 4 fp16 hi followed
+     * by 4 fp16 lo (same byte size as the fp32 matrix). */
+    int32_t precision;
 } eab_conv_desc;
+
+#define EAB_PREC_F32   0
+#define EAB_PREC_F16X3 1
 
 /* number of tiles per batch element a launch with this geometry produces */
 int eab_conv_tiles(int T, int No, int bm);
@@ -201,6 +211,11 @@ int eab_norm_act_f32(const float* a, const float* xfa, const float* slopea,
 int eab_lstm64_f32(const float* x, const float* ln_g, const float* ln_b, float ln_eps,
                    const float* wcat, const float* bias, float* h_out,
                    int B, int T, int F, eab_stream_t stream);
+/* same with the arithmetic selectable: EAB_PREC_F32 (as above) or EAB_PREC_F16X3 (operands
+ * split in fp16 hi+lo on the fly, three f16 MFMAs per product, fp32 accumulate; wcat stays fp32) */
+int eab_lstm64_prec_f32(const float* x, const float* ln_g, const float* ln_b, float ln_eps,
+                        const float* wcat, const float* bias, float* h_out,
+                        int B, int T, int F, int precision, eab_stream_t stream);
 
 /* --------------------------------------------------------------------------
  * K12(second Linear)+K13  beam-forming weights + filter-and-sum, fused.
@@ -237,7 +252,7 @@ typedef struct eab_op {
  *  IN_FINALIZE i = {B, C, nsets, stat_tiles, count}       f = {eps}
  *              p = {stats, gamma0, beta0, xf0, gamma1, beta1, xf1}
  *  NORM_ACT    i = {B, P, C}  p = {a, xfa, slopea, b, xfb, slopeb, out}
- *  LSTM64      i = {B, T, F}  f = {ln_eps}  p = {x, ln_g, ln_b, wcat, bias, h_out}
+ *  LSTM64      i = {B, T, F, precision}  f = {ln_eps}  p = {x, ln_g, ln_b, wcat, bias, h_out}
  *  BFW_FS      i = {B, T, F, M}  p = {y1, w2, b2, x, out, bfw}
  *  MEMSET0     p = {ptr}  i = {bytes_lo, bytes_hi}
  */

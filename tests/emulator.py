@@ -22,6 +22,26 @@ def _prelu(x, a):
     return np.where(x > 0, x, a * x)
 
 
+def f16_rtz(x):
+    """fp32 -> fp16 rounding toward zero (v_cvt_pkrtz_f16_f32), returned as fp32."""
+    x = np.asarray(x, dtype=np.float32)
+    h = x.astype(np.float16)
+    over = np.abs(h.astype(np.float32)) > np.abs(x)
+    h = np.where(over, np.nextafter(h, np.float16(0)), h)
+    return h.astype(np.float32)
+
+
+def split_f16x3(x):
+    hi = f16_rtz(x)
+    return hi, f16_rtz(np.asarray(x, np.float32) - hi)
+
+
+def unpack_f16x3(w_store, N, K):
+    """inverse of eabnet_amd.program.pack_f16x3 -> (hi, lo) as fp32 [N][K]."""
+    h = np.ascontiguousarray(w_store, dtype=np.float32).view(np.float16).reshape(N, K // 4, 8)
+    return (h[:, :, :4].reshape(N, K).astype(np.float32), h[:, :, 4:].reshape(N, K).astype(np.float32))
+
+
 class Emulator:
     def __init__(self, prog: prg.Program, x_in: np.ndarray):
         self.p = prog
@@ -78,8 +98,22 @@ class Emulator:
         upt = (Ct + 15) // 16
         ntaps = len(op.dt)
         assert op.Kpad == ntaps * upt * 16
-        W = self.v(op.w, (op.N, ntaps, upt * 16))
+        h3 = op.precision == prg.PREC_F16X3
+        if h3:
+            Wh, Wl = unpack_f16x3(self.v(op.w, (op.N, op.Kpad)), op.N, op.Kpad)
+            Wh, Wl = Wh.reshape(op.N, ntaps, upt * 16), Wl.reshape(op.N, ntaps, upt * 16)
+            W = Wh + Wl
+        else:
+            W = self.v(op.w, (op.N, ntaps, upt * 16))
         assert not np.any(W[:, :, Ct:]), "padding columns of the packed weights must be zero"
+
+        def mm(G, rows, j):
+            if not h3:
+                return G @ W[rows, j, :Ct].T
+            gh, gl = split_f16x3(G)           # the kernel's three MFMAs: lo*hi + hi*lo + hi*hi
+            return (gl @ Wh[rows, j, :Ct].T + gh @ Wl[rows, j, :Ct].T) + gh @ Wh[rows, j, :Ct].T
+
+        allrows = np.arange(op.N)
         acc = np.zeros((B, T, No, op.N), dtype=np.float32)
         if op.bias is not None:
             acc += self.v(op.bias, (op.N,))
@@ -93,14 +127,14 @@ class Emulator:
             if tv > 0:
                 G[:, -dt:, ok] = X[:, :tv][:, :, fi[ok]]
             if not dual:
-                acc += G @ W[:, j, :Ct].T
+                acc += mm(G, allrows, j)
             else:                            # packed rows with (r % 64) < 32 are "left", the others "right"
                 G2 = np.zeros_like(G)
                 if tv > 0:
                     G2[:, -dt:, ok] = X2[:, :tv][:, :, fi[ok]]
                 left = (np.arange(op.N) % 64) < 32
-                acc[..., left] += G @ W[left, j, :Ct].T
-                acc[..., ~left] += G2 @ W[~left, j, :Ct].T
+                acc[..., left] += mm(G, np.nonzero(left)[0], j)
+                acc[..., ~left] += mm(G2, np.nonzero(~left)[0], j)
         if op.epi in (prg.EPI_GLU, prg.EPI_DUALGATE):
             c = np.arange(op.N // 2)
             rv = (c // 32) * 64 + c % 32
@@ -163,12 +197,25 @@ class Emulator:
         h = np.zeros((B, F, 64), np.float32)
         c = np.zeros((B, F, 64), np.float32)
         out = self.v(op.h_out, (B, T, F, 64))
+        h3 = op.precision == prg.PREC_F16X3
+        if h3:      # weights split with round-to-nearest in the kernel, activations with round-toward-zero
+            Wh = W.astype(np.float16).astype(np.float32)
+            Wl = (W - Wh).astype(np.float16).astype(np.float32)
         for t in range(T):
-            g = np.concatenate([x[:, t], h], -1) @ W.T + bias
+            a = np.concatenate([x[:, t], h], -1)
+            if h3:
+                ah, al = split_f16x3(a)
+                g = ((al @ Wh.T + ah @ Wl.T) + ah @ Wh.T) + bias
+            else:
+                g = a @ W.T + bias
             i, f, gg, o = np.split(g, 4, -1)
             c = _sig(f) * c + _sig(i) * np.tanh(gg)
             h = (_sig(o) * np.tanh(c)).astype(np.float32)
             out[:, t] = h
+            if h3:  # the kernel carries h as fp16 hi + lo (both round-to-nearest)
+                hh = h.astype(np.float16).astype(np.float32)
+                h = hh + (h - hh).astype(np.float16).astype(np.float32)
+                out[:, t] = h
 
     def bfw(self, op: prg.BfwOp):
         B, T, F, M = op.B, op.T, op.F, op.M

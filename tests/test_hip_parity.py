@@ -87,8 +87,10 @@ def test_filter_sum_vs_oracle_and_linearity(dev):
 
 
 # ------------------------------------------------------------------ op by op
-@pytest.mark.parametrize("M,B,T,pq", [(8, 1, 12, (6, 3)), (9, 2, 21, (2, 1)), (16, 1, 9, (1, 1))])
-def test_every_op_matches_the_emulator(dev, M, B, T, pq):
+@pytest.mark.parametrize("M,B,T,pq,precision", [(8, 1, 12, (6, 3), "f32"), (9, 2, 21, (2, 1), "f32"),
+                                                 (16, 1, 9, (1, 1), "f32"), (8, 2, 21, (2, 1), "f16x3"),
+                                                 (9, 1, 12, (1, 1), "f16x3")])
+def test_every_op_matches_the_emulator(dev, M, B, T, pq, precision):
     """Run the device program one op at a time next to the numpy interpreter of
     the same program (tests/emulator.py, itself pinned to the reference fixtures
     on CPU) and compare the WHOLE workspace after each op: the first diverging
@@ -101,7 +103,7 @@ def test_every_op_matches_the_emulator(dev, M, B, T, pq):
     cfg = NetConfig(M=M, p=p, q=q)
     P = paramgen.make_params(param_specs(cfg), 50 + M)
     x = paramgen.make_spec_input(B, T, 161, M, 60 + M)
-    prog = prg.lower(cfg, P, B, T, 161, dump_bfw=True)
+    prog = prg.lower(cfg, P, B, T, 161, dump_bfw=True, precision=precision)
     emu = Emulator(prog, x)
     bound = _Bound(prog, dev)
     bound.acts.fill_(float("nan"))
@@ -204,6 +206,36 @@ def test_c2_batch16_properties(dev):
     assert_close(y[0:1].cpu().numpy(), g["out"], TOL_HIP, "slot 0 vs reference fixture")
     assert torch.equal(y[0], y[5]), "identical utterances must give bit-identical outputs"
     assert_close(y[3:4].cpu().numpy(), y3.cpu().numpy(), 1e-5, "batch independence")
+
+
+@pytest.mark.parametrize("name,M,B,T", [("e2e_M8_B2_T20.npz", 8, 2, 20), ("e2e_M9_B1_T10.npz", 9, 1, 10)])
+def test_f16x3_e2e_fixtures(dev, name, M, B, T):
+    """precision='f16x3' (fp16 hi+lo split on the f16 matrix cores) against the SAME reference
+    fixtures and the SAME 1e-4 bar as the exact-fp32 path."""
+    g = load(name)
+    net = _model(M, int(g["param_seed"]), dev)
+    net.precision = "f16x3"
+    x = torch.from_numpy(paramgen.make_spec_input(B, T, 161, M, int(g["input_seed"]))).to(dev)
+    with torch.no_grad():
+        y = net(x)
+    m, l2 = assert_close(y.cpu().numpy(), g["out"], TOL_HIP)
+    print(f"f16x3 {name}: max-rel {m:.2e}, l2-rel {l2:.2e}")
+
+
+def test_f16x3_c1_full_size(dev):
+    import eabnet_amd
+    g = load("c1_M8_T401.npz")
+    net = _model(8, int(g["param_seed"]), dev)
+    net.precision = "f16x3"
+    wav = torch.from_numpy(paramgen.make_wave(1, 8, 64000, int(g["wave_seed"])))
+    with torch.no_grad():
+        ns = eabnet_amd.stft_compress(wav.to(dev), 320, 160, torch.hann_window(320))
+        y = net(ns)
+        net.precision = "f32"
+        y32 = net(ns)
+    m, l2 = assert_close(y.cpu().numpy(), g["out"], TOL_HIP)
+    m2, _ = rel_errs(y.cpu().numpy(), y32.cpu().numpy())
+    print(f"f16x3 C1: max-rel {m:.2e}, l2-rel {l2:.2e} vs reference; {m2:.2e} vs the f32 mode")
 
 
 def test_moderate_size_vs_oracle(dev):
