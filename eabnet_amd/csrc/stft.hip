@@ -5,10 +5,16 @@
 // workgroup's output is ONE contiguous F*M*2 block (coalesced stores), and the
 // twiddle pair of (bin f, sample n) is read once and used for all M mics.
 //
-// Round-1 arithmetic: direct DFT against an exact (host, fp64-rounded) twiddle
-// table; frame samples sit in LDS as [n][Mpad] so one broadcast ds_read_b128
-// feeds four mics.  The 320-point FFT (radix 4*4*4*5) that makes this kernel
-// HBM-bound is the next step for this row.
+// Arithmetic: real FFT.  The even and odd samples of ONE microphone share a
+// complex transform of half the length (z[n] = x[2n] + i x[2n+1], split by
+// conjugate symmetry and one twiddle afterwards) -- never two microphones, so a
+// silent microphone gives exactly 0 as in the reference and no rounding noise
+// leaks across channels (sqrt-compression would amplify 1e-8 to 1e-4).  The
+// n_fft/2-point complex FFT is a Stockham autosort chain of radix-5/4/2 passes
+// in LDS (160 = 5*4*4*2) against an exact (host, fp64-rounded) twiddle table, so the
+// kernel does ~6.6 kFLOP per frame and mic and is bound by its HBM traffic
+// (5,120 B read + 20,608 B written per frame at M = 8).  Sizes that do not
+// factor into {5,4,2} fall back to a direct DFT kernel.
 #include "common.h"
 
 #define STFT_MAX_NFFT 512
@@ -23,7 +29,7 @@ __device__ __forceinline__ int reflect_index(int i, int P, int L) {
     return j;
 }
 
-__global__ __launch_bounds__(STFT_THREADS) void stft_compress_kernel(
+__global__ __launch_bounds__(STFT_THREADS) void stft_dft_kernel(
     const float* __restrict__ wav, const float* __restrict__ window, const float* __restrict__ twiddle,
     float* __restrict__ out, int M, int L, int n_fft, int hop, int T, int layout) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -85,6 +91,138 @@ __global__ __launch_bounds__(STFT_THREADS) void stft_compress_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// FFT path
+// ---------------------------------------------------------------------------
+#define FFT_SIGS 8             // microphones (= half-length complex transforms) per LDS pass
+#define FFT_MAX_PASSES 8
+
+struct FftPlan {
+    int npass;
+    int radix[FFT_MAX_PASSES];
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// One Stockham pass (decimation in frequency, autosort) of NT-point transforms: sub-length n,
+// stride s, radix R:
+//   y[q + s(R p + k)] = (sum_j x[q + s(p + j n/R)] W_R^{jk}) * W_n^{pk},   p < n/R, q < s.
+// tw[j] = exp(-2 pi i j / TW) with NT | TW, so W_n^x = tw[x * TW/n].
+template <int R>
+__device__ __forceinline__ void fft_pass(const float2* __restrict__ x, float2* __restrict__ y, const float2* __restrict__ tw,
+                                         int NT, int TW, int n, int s, int tid, int nthreads) {
+    const int m = n / R, per = NT / R;                        // butterflies per transform
+    const int twstep = TW / n;
+    for (int e = tid; e < FFT_SIGS * per; e += nthreads) {
+        const int c = e / per, bfly = e - c * per;
+        const int p = bfly / s, q = bfly - p * s;
+        const float2* xi = x + c * NT + q + s * p;
+        float2* yo = y + c * NT + q + s * R * p;
+        float2 a[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) a[j] = xi[s * m * j];
+        float2 o[R];
+        if (R == 2) {
+            o[0] = make_float2(a[0].x + a[1].x, a[0].y + a[1].y);
+            o[1] = make_float2(a[0].x - a[1].x, a[0].y - a[1].y);
+        } else if (R == 4) {
+            const float2 t0 = make_float2(a[0].x + a[2].x, a[0].y + a[2].y), t1 = make_float2(a[0].x - a[2].x, a[0].y - a[2].y);
+            const float2 t2 = make_float2(a[1].x + a[3].x, a[1].y + a[3].y), t3 = make_float2(a[1].x - a[3].x, a[1].y - a[3].y);
+            o[0] = make_float2(t0.x + t2.x, t0.y + t2.y);
+            o[2] = make_float2(t0.x - t2.x, t0.y - t2.y);
+            o[1] = make_float2(t1.x + t3.y, t1.y - t3.x);     // t1 - i t3   (W_4 = -i)
+            o[3] = make_float2(t1.x - t3.y, t1.y + t3.x);     // t1 + i t3
+        } else {                                              // generic small radix (5): direct DFT with table twiddles
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                float2 acc = a[0];
+#pragma unroll
+                for (int j = 1; j < R; ++j) {
+                    const float2 t = cmul(a[j], tw[((j * k) % R) * (TW / R)]);
+                    acc.x += t.x;
+                    acc.y += t.y;
+                }
+                o[k] = acc;
+            }
+        }
+        yo[0] = o[0];
+#pragma unroll
+        for (int k = 1; k < R; ++k) yo[s * k] = (m > 1) ? cmul(o[k], tw[p * k * twstep]) : o[k];
+    }
+}
+
+__global__ __launch_bounds__(STFT_THREADS) void stft_fft_kernel(
+    const float* __restrict__ wav, const float* __restrict__ window, const float* __restrict__ twiddle,
+    float* __restrict__ out, int M, int L, int n_fft, int hop, int T, int layout, FftPlan plan) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int NH = n_fft / 2, F = NH + 1;
+    float2* tw = reinterpret_cast<float2*>(smem);                         // [n_fft]  exp(-2 pi i j / n_fft)
+    float2* buf0 = tw + n_fft;                                            // [FFT_SIGS][NH]
+    float2* buf1 = buf0 + FFT_SIGS * NH;
+    const int b = blockIdx.x / T, t = blockIdx.x % T;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < n_fft; k += STFT_THREADS) {       // table is (cos, sin)(+theta); the passes use exp(-i theta)
+        const float2 cs = reinterpret_cast<const float2*>(twiddle)[k];
+        tw[k] = make_float2(cs.x, -cs.y);
+    }
+
+    for (int m0 = 0; m0 < M; m0 += FFT_SIGS) {
+        __syncthreads();
+        // gather + window: z_mm[n/2].(re|im) = w[n] x_mm[reflect(t hop + n)]; consecutive threads -> consecutive samples
+        for (int e = tid; e < FFT_SIGS * n_fft; e += STFT_THREADS) {
+            const int mm = e / n_fft, n = e - mm * n_fft;
+            float v = 0.0f;
+            if (m0 + mm < M) v = window[n] * wav[((size_t)b * M + m0 + mm) * L + reflect_index(t * hop + n, NH, L)];
+            reinterpret_cast<float*>(buf0)[mm * n_fft + n] = v;           // float index 2*(n/2) + (n&1) = n
+        }
+        __syncthreads();
+        float2* src = buf0;
+        float2* dst = buf1;
+        int n = NH, s = 1;
+        for (int ps = 0; ps < plan.npass; ++ps) {
+            const int R = plan.radix[ps];
+            if (R == 5) fft_pass<5>(src, dst, tw, NH, n_fft, n, s, tid, STFT_THREADS);
+            else if (R == 4) fft_pass<4>(src, dst, tw, NH, n_fft, n, s, tid, STFT_THREADS);
+            else fft_pass<2>(src, dst, tw, NH, n_fft, n, s, tid, STFT_THREADS);
+            __syncthreads();
+            n /= R;
+            s *= R;
+            float2* tmp = src; src = dst; dst = tmp;
+        }
+        // X[k] = E[k] + W_N^k O[k],  E = (Z[k] + conj Z[NH-k]) / 2,  O = (Z[k] - conj Z[NH-k]) / 2i;  k = 0..NH
+        for (int e = tid; e < F * FFT_SIGS; e += STFT_THREADS) {
+            const int f = e / FFT_SIGS, mm = e - f * FFT_SIGS;           // consecutive threads -> consecutive mics
+            const int m = m0 + mm;
+            if (m >= M) continue;
+            const float2 z = src[mm * NH + (f == NH ? 0 : f)];
+            const float2 zc = src[mm * NH + ((f == 0 || f == NH) ? 0 : NH - f)];
+            const float2 E = make_float2(0.5f * (z.x + zc.x), 0.5f * (z.y - zc.y));
+            const float2 O = make_float2(0.5f * (z.y + zc.y), 0.5f * (zc.x - z.x));
+            const float2 w = (f == NH) ? make_float2(-1.0f, 0.0f) : tw[f];
+            const float2 wo = cmul(w, O);
+            const float re = E.x + wo.x, im = E.y + wo.y;
+            // sqrt-magnitude compression with the phase kept: X * |X|^-1/2, 0 -> 0
+            const float mag = sqrtf(re * re + im * im);
+            const float sc = mag > 0.0f ? 1.0f / sqrtf(mag) : 0.0f;
+            if (layout == EAB_STFT_LAYOUT_BTFM2) {
+                *reinterpret_cast<float2*>(&out[((((size_t)b * T + t) * F + f) * M + m) * 2]) = make_float2(re * sc, im * sc);
+            } else {                                        // (B,2,T,F), M == 1
+                out[(((size_t)b * 2 + 0) * T + t) * F + f] = re * sc;
+                out[(((size_t)b * 2 + 1) * T + t) * F + f] = im * sc;
+            }
+        }
+    }
+}
+
+static bool fft_plan(int n, FftPlan* p) {
+    p->npass = 0;
+    // radix 5 first (its generic butterfly is the most expensive one and runs once), then 4s, then a 2
+    while (n % 5 == 0 && p->npass < FFT_MAX_PASSES) { p->radix[p->npass++] = 5; n /= 5; }
+    while (n % 4 == 0 && p->npass < FFT_MAX_PASSES) { p->radix[p->npass++] = 4; n /= 4; }
+    while (n % 2 == 0 && p->npass < FFT_MAX_PASSES) { p->radix[p->npass++] = 2; n /= 2; }
+    return n == 1;
+}
+
 __global__ void stft_frames_kernel(const float* __restrict__ wav, float* __restrict__ frames, int L, int n_fft,
                                    int hop, int T) {
     const int n = blockIdx.x / T, t = blockIdx.x % T;
@@ -101,8 +239,15 @@ extern "C" int eab_stft_compress_f32(const float* wav, const float* window, cons
     EAB_CHECK_ARG(layout == EAB_STFT_LAYOUT_BTFM2 || (layout == EAB_STFT_LAYOUT_B2TF && M == 1));
     const int T = 1 + L / hop;
     EAB_CHECK_ARG((long long)B * T < (1ll << 31));
+    FftPlan plan;
+    if (fft_plan(n_fft / 2, &plan)) {
+        const size_t sh = (size_t)(2 * n_fft + 2 * FFT_SIGS * n_fft) * sizeof(float);
+        hipLaunchKernelGGL(stft_fft_kernel, dim3(B * T), dim3(STFT_THREADS), sh, eab_stream(stream), wav, window,
+                           twiddle, out, M, L, n_fft, hop, T, layout, plan);
+        EAB_RETURN_LAUNCH_STATUS();
+    }
     size_t shmem = (size_t)(2 * n_fft + n_fft * STFT_MC) * sizeof(float);
-    hipLaunchKernelGGL(stft_compress_kernel, dim3(B * T), dim3(STFT_THREADS), shmem, eab_stream(stream), wav,
+    hipLaunchKernelGGL(stft_dft_kernel, dim3(B * T), dim3(STFT_THREADS), shmem, eab_stream(stream), wav,
                        window, twiddle, out, M, L, n_fft, hop, T, layout);
     EAB_RETURN_LAUNCH_STATUS();
 }
