@@ -36,7 +36,7 @@ class ConvDesc(C.Structure):
         ("fin_stats", C.c_void_p), ("fin_gamma0", C.c_void_p), ("fin_beta0", C.c_void_p),
         ("fin_gamma1", C.c_void_p), ("fin_beta1", C.c_void_p),
         ("fin_tiles", C.c_int32), ("fin_nsets", C.c_int32), ("fin_count", C.c_int32), ("fin_eps", C.c_float),
-        ("precision", C.c_int32),
+        ("precision", C.c_int32), ("korder", C.c_int32),
     ]
 
 

@@ -39,11 +39,16 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define CG_DUAL 2    // value/gate columns see the SAME source through two transforms (S-TCM branches)
 #define CG_XFC 128   // max channels of a source that carries a fused transform
 
-template <int MI, int NI, int KU, int MODE>
+#define CG_PMAX 352  // input positions of one patch (PATCH mode): 352 * 80 B = 27.5 KB, three workgroups per CU
+
+template <int MI, int NI, int KU, int MODE, bool PATCH>
 struct CgSmem {
     static constexpr int BM = 64 * MI, BN = 64 * NI, LDK = 16 * KU + 4;
     static constexpr int NA = MODE == CG_DUAL ? 2 : 1;
-    float a[NA][2][BM * LDK];
+    static constexpr int ATILE = BM * LDK;                       // one A tile (floats)
+    // gather mode: NA x 2 (double-buffered) A tiles of BM output rows;
+    // patch mode: ONE tile of CG_PMAX input positions, re-read by every tap of a channel chunk
+    float a[PATCH ? CG_PMAX * LDK : NA * 2 * ATILE];
     float b[2][BN * LDK];
     float xft[2][CG_XFC][2];     // (scale, shift) per channel: table 0 = src0 / left, 1 = src1 / right
     float xsl[2][CG_XFC];        // PReLU slopes
@@ -89,12 +94,13 @@ __device__ __forceinline__ void cg_split2(float x0, float x1, unsigned& hi, unsi
     lo = __builtin_bit_cast(unsigned, l);
 }
 
-template <int MI, int NI, int KU, int MODE, int XF, bool VEC, int PREC>
+template <int MI, int NI, int KU, int MODE, int XF, bool VEC, int PREC, bool PATCH>
 __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_desc d) {
+    static_assert(!PATCH || (KU == 1 && MODE != CG_DUAL && VEC), "patch mode: one unit per stage, single transform");
     constexpr bool H3 = PREC == EAB_PREC_F16X3;
     constexpr bool GLU = MODE != CG_PLAIN;          // gated epilogue (value tile, gate tile per lane)
     constexpr bool DUAL = MODE == CG_DUAL;
-    using Smem = CgSmem<MI, NI, KU, MODE>;
+    using Smem = CgSmem<MI, NI, KU, MODE, PATCH>;
     constexpr int BM = Smem::BM, BN = Smem::BN, LDK = Smem::LDK;
     __shared__ __attribute__((aligned(16))) Smem sm;
 
@@ -193,6 +199,204 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
 #pragma unroll
     for (int p = 0; p < NI; ++p) wrow[p] = d.w + (size_t)(n_blk + srow + 64 * p) * d.Kpad + skq * 4;
 
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+    // LDS writes must be visible, global loads may stay in flight across the barrier
+    // (__syncthreads() would add s_waitcnt vmcnt(0) and drain the prefetch).
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    __syncthreads();   // tap tables (and transform tables) visible
+
+    if constexpr (PATCH) {
+        // ------------------------------------------------------------------------------
+        // PATCH pipeline.  K is walked chunk-major (16 channels of ALL taps, then the next
+        // 16 channels; the host packs the weights in that order).  The input patch of one
+        // chunk -- every position (t', f') any row of the tile touches through any tap, plus
+        // zeroed halo cells -- is fetched, transformed and (f16x3) split ONCE, and each tap's
+        // MFMAs read their A fragments from it at a per-lane base + a per-tap shift.  Only the
+        // weights stream per stage.  Versus the gather pipeline this removes the ntaps-fold
+        // re-fetch / re-transform / re-split of A.
+        // ------------------------------------------------------------------------------
+        constexpr int PP = (CG_PMAX + 63) / 64;
+        int dt_min = 0, io_min = 0, io_max = 0;
+#pragma unroll
+        for (int j = 0; j < EAB_MAX_TAPS; ++j)
+            if (j < d.ntaps) {
+                dt_min = d.dt[j] < dt_min ? d.dt[j] : dt_min;
+                io_min = d.ioff[j] < io_min ? d.ioff[j] : io_min;
+                io_max = d.ioff[j] > io_max ? d.ioff[j] : io_max;
+            }
+        const int halo_lo = -io_min;
+        const int hi_need = (d.No - 1) * d.istride + io_max - (d.Fin - 1);
+        const int Fp = d.Fin + halo_lo + (hi_need > 0 ? hi_need : 0);
+        const float inv_fp = 1.0f / (float)Fp;
+        const int t_first = cg_div(q0, d.No, inv_no);
+        const int t_last = cg_div((q0 + BM < Q ? q0 + BM : Q) - 1, d.No, inv_no);
+        const int P = (t_last - t_first + 1 - dt_min) * Fp;          // <= CG_PMAX (checked on the host)
+
+        int p_tf[PP];
+        bool p_ok[PP];
+#pragma unroll
+        for (int pp = 0; pp < PP; ++pp) {
+            const int pidx = srow + 64 * pp;
+            const int tr = cg_div(pidx, Fp, inv_fp);
+            const int t_in = t_first + dt_min + tr, fi = pidx - tr * Fp - halo_lo;
+            p_ok[pp] = pidx < P && t_in >= 0 && fi >= 0 && fi < d.Fin;
+            p_tf[pp] = t_in * d.Fin + fi;
+        }
+        int fa[MI];                                                  // float index of this lane's fragment for a zero tap shift
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            int q = q0 + (wm * MI + mi) * 32 + li;
+            q = q < Q ? q : Q - 1;                                   // tile tail: any valid row (masked in the epilogue)
+            const int t = cg_div(q, d.No, inv_no), o = q - t * d.No;
+            fa[mi] = ((t - t_first - dt_min) * Fp + o * d.istride + halo_lo) * LDK + 4 * lh;
+        }
+        const int b_base = (wn * NI * 32 + li) * LDK + 4 * lh;
+
+        f32x4 rp[PP];
+        f32x4 rbw0[NI], rbw1[NI];        // weights of stages u+1 and u+2 (two named sets, static indexing)
+        int p_tc = 0;
+        auto patch_fetch = [&](int chunk) {
+            const int c0 = chunk << 4;
+            const bool second = (d.C1 > 0) && (c0 >= d.C0);
+            const int Cs = second ? d.C1 : d.C0;
+            const int c = (second ? c0 - d.C0 : c0) + skq * 4;
+            const bool cok = c < Cs;
+            p_tc = ((second ? 1 : 0) << 8) | (cok ? c : 0);
+#pragma unroll
+            for (int pp = 0; pp < PP; ++pp) {
+                const unsigned off = (p_ok[pp] && cok) ? (unsigned)((p_tf[pp] * Cs + c) * 4) : CG_OOB;
+                const u32x4 v = second ? __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0)
+                                       : __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0);
+                rp[pp] = __builtin_bit_cast(f32x4, v);
+            }
+        };
+        auto patch_stash = [&]() {
+            f32x4 sh01, sh23, sl;
+            if (XF != EAB_XF_NONE) {
+                const int cc = p_tc & 0xFF, tb = p_tc >> 8;
+                sh01 = *reinterpret_cast<const f32x4*>(&sm.xft[tb][cc][0]);
+                sh23 = *reinterpret_cast<const f32x4*>(&sm.xft[tb][cc + 2][0]);
+                sl = *reinterpret_cast<const f32x4*>(&sm.xsl[tb][cc]);
+            }
+#pragma unroll
+            for (int pp = 0; pp < PP; ++pp) {
+                const int pidx = srow + 64 * pp;
+                if (pidx >= CG_PMAX) continue;
+                f32x4 v = rp[pp];
+                if (XF != EAB_XF_NONE) {
+                    const f32x4 x = cg_xform<XF>(v, sh01, sh23, sl);
+                    v = p_ok[pp] ? x : f32x4{0.f, 0.f, 0.f, 0.f};     // halo / causal zeros stay exactly 0
+                }
+                float* arow = &sm.a[pidx * LDK];
+                if (H3) {
+                    unsigned h01, l01, h23, l23;
+                    cg_split2(v[0], v[1], h01, l01);
+                    cg_split2(v[2], v[3], h23, l23);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(arow) + skq * 8) = make_uint2(h01, h23);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(arow) + 32 + skq * 8) = make_uint2(l01, l23);
+                } else {
+                    *reinterpret_cast<f32x4*>(arow + skq * 4) = v;
+                }
+            }
+        };
+        auto b_fetch = [&](int u, f32x4 (&rbw)[NI]) {
+            const int uu = u < NU ? u : 0;                           // past the end: harmless reload of unit 0
+#pragma unroll
+            for (int p = 0; p < NI; ++p) rbw[p] = *reinterpret_cast<const f32x4*>(wrow[p] + (size_t)uu * 16);
+        };
+        auto b_stash = [&](int buf, const f32x4 (&rbw)[NI]) {
+#pragma unroll
+            for (int p = 0; p < NI; ++p) {
+                float* brow = &sm.b[buf][(srow + 64 * p) * LDK];
+                if (H3) {
+                    const u32x4 w = __builtin_bit_cast(u32x4, rbw[p]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(brow) + skq * 8) = make_uint2(w[0], w[1]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(brow) + 32 + skq * 8) = make_uint2(w[2], w[3]);
+                } else {
+                    *reinterpret_cast<f32x4*>(brow + skq * 4) = rbw[p];
+                }
+            }
+        };
+        auto pcompute = [&](int cur, int tap) {
+            const int toff = (sm.dt[tap] * Fp + sm.ioff[tap]) * LDK;  // per-tap shift inside the patch (wave-uniform)
+            if (H3) {
+                h16x8 ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const char* pa = reinterpret_cast<const char*>(&sm.a[fa[mi] + toff]);
+                    ah[mi] = *reinterpret_cast<const h16x8*>(pa);
+                    al[mi] = *reinterpret_cast<const h16x8*>(pa + 32);
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const char* pb = reinterpret_cast<const char*>(&sm.b[cur][b_base + ni * 32 * LDK]);
+                    bh[ni] = *reinterpret_cast<const h16x8*>(pb);
+                    bl[ni] = *reinterpret_cast<const h16x8*>(pb + 32);
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    f32x4 af[MI], bf[NI];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const f32x4*>(&sm.a[fa[mi] + toff + g * 8]);
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        bf[ni] = *reinterpret_cast<const f32x4*>(&sm.b[cur][b_base + ni * 32 * LDK + g * 8]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                            for (int ni = 0; ni < NI; ++ni)
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][k], bf[ni][k], acc[mi][ni], 0, 0, 0);
+                }
+            }
+        };
+
+        patch_fetch(0);
+        b_fetch(0, rbw0);
+        patch_stash();
+        b_stash(0, rbw0);
+        b_fetch(1, rbw0);                                            // stage u+1 -> rbw0, stage u+2 -> rbw1
+        b_fetch(2, rbw1);
+        lds_barrier();
+        const int pre = d.ntaps >= 3 ? d.ntaps - 3 : 0;             // request the next patch three taps early
+        int chunk = 0, tap = 0;
+        auto stage = [&](int u, int cur, f32x4 (&rnext)[NI]) {
+            // rnext holds the weights of stage u+1 (loaded two stages ago); it is refilled with u+3
+            if (tap == pre && chunk + 1 < UPT) patch_fetch(chunk + 1);
+            pcompute(cur, tap);
+            if (u + 1 < NU) b_stash(cur ^ 1, rnext);
+            b_fetch(u + 3, rnext);
+            if (tap == d.ntaps - 1 && chunk + 1 < UPT) {
+                lds_barrier();                                       // every wave is done with this chunk's patch
+                patch_stash();
+            }
+            lds_barrier();
+            if (++tap == d.ntaps) { tap = 0; ++chunk; }
+        };
+        for (int u = 0; u < NU; u += 2) {
+            stage(u, 0, rbw0);
+            if (u + 1 < NU) stage(u + 1, 1, rbw1);
+        }
+        __syncthreads();                                             // drain the look-ahead loads before LDS is reused
+    } else {
     // Zero padding acts on the NORMALISED tensor in the reference (ConstantPad2d /
     // the transposed conv's implicit zeros come after norm+PReLU), so out-of-range
     // taps must stay exactly 0 through the fused transform: st_ok remembers which
@@ -203,8 +407,6 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
         bool st_ok[KU][MI];
     };
     Stage sa;                       // stage s+1 in flight while stage s is multiplied
-
-    __syncthreads();   // tap tables visible
 
     auto fetch = [&](int stage, Stage& rg) {
 #pragma unroll
@@ -272,7 +474,7 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
                         const f32x4 x = cg_xform<XF>(v, sh01[k], sh23[k], sl[k]);
                         v = rg.st_ok[ku][p] ? x : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
-                    float* arow = &sm.a[k][buf][(srow + 64 * p) * LDK + ku * 16];
+                    float* arow = &sm.a[(k * 2 + buf) * Smem::ATILE + (srow + 64 * p) * LDK + ku * 16];
                     if (H3) {
                         // unit layout in LDS (64 B): 16 fp16 hi | 16 fp16 lo; this thread owns channels 4*skq..+3
                         unsigned h01, l01, h23, l23;
@@ -299,18 +501,6 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
         }
     };
 
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
-
-    // LDS writes must be visible, global loads may stay in flight across the barrier
-    // (__syncthreads() would add s_waitcnt vmcnt(0) and drain the two-stage prefetch).
-    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-
     fetch(0, sa);
     stash(0, sa);
     lds_barrier();
@@ -328,7 +518,7 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
                 for (int k = 0; k < Smem::NA; ++k)
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) {
-                        const char* pa = reinterpret_cast<const char*>(&sm.a[k][cur][a_base + mi * 32 * LDK + ku * 16]);
+                        const char* pa = reinterpret_cast<const char*>(&sm.a[(k * 2 + cur) * Smem::ATILE + a_base + mi * 32 * LDK + ku * 16]);
                         ah[k][mi] = *reinterpret_cast<const h16x8*>(pa);
                         al[k][mi] = *reinterpret_cast<const h16x8*>(pa + 32);
                     }
@@ -356,7 +546,7 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
             for (int k = 0; k < Smem::NA; ++k)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
-                    af[k][mi] = *reinterpret_cast<const f32x4*>(&sm.a[k][cur][a_base + mi * 32 * LDK + g * 8]);
+                    af[k][mi] = *reinterpret_cast<const f32x4*>(&sm.a[(k * 2 + cur) * Smem::ATILE + a_base + mi * 32 * LDK + g * 8]);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
                 bf[ni] = *reinterpret_cast<const f32x4*>(&sm.b[cur][b_base + ni * 32 * LDK + g * 8]);
@@ -379,6 +569,8 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
         compute(cur);
         if (s + 1 < NS) stash(cur ^ 1, sa);
         lds_barrier();
+    }
+
     }
 
     // ---- epilogue ---------------------------------------------------------------
@@ -491,7 +683,7 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
     if (d.stats) {
         // lanes l and l^32 hold the same columns; then the two wm waves; fixed
         // order everywhere => bit-reproducible partials.
-        float* red = &sm.a[0][0][0];               // staging LDS is free after the last barrier
+        float* red = &sm.a[0];               // staging LDS is free after the last barrier
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -539,16 +731,45 @@ static int cg_launch(const eab_conv_desc* d, hipStream_t s) {
     constexpr int BM = 64 * MI, BN = 64 * NI;
     const int tiles = eab_conv_tiles(d->T, d->No, BM);
     dim3 grid((unsigned)(d->B * tiles), (unsigned)(d->N / BN));
+    constexpr bool can_patch = KU == 1 && MODE != CG_DUAL && VEC && XF != EAB_XF_PRELU_NORM;
+    if (d->korder == EAB_KORDER_CHUNK) {
+        if constexpr (can_patch) {
+            if (d->precision == EAB_PREC_F16X3)
+                hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, 1, MODE, XF, true, EAB_PREC_F16X3, true>), grid,
+                                   dim3(CG_THREADS), 0, s, *d);
+            else
+                hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, 1, MODE, XF, true, EAB_PREC_F32, true>), grid,
+                                   dim3(CG_THREADS), 0, s, *d);
+            EAB_RETURN_LAUNCH_STATUS();
+        } else {
+            return EAB_EUNSUPPORTED;
+        }
+    }
     if (d->precision == EAB_PREC_F16X3) {
         if constexpr (VEC)
-            hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, KU, MODE, XF, VEC, EAB_PREC_F16X3>), grid, dim3(CG_THREADS), 0,
-                               s, *d);
+            hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, KU, MODE, XF, VEC, EAB_PREC_F16X3, false>), grid,
+                               dim3(CG_THREADS), 0, s, *d);
         else
             return EAB_EUNSUPPORTED;
     } else {
-        hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, KU, MODE, XF, VEC, EAB_PREC_F32>), grid, dim3(CG_THREADS), 0, s, *d);
+        hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, KU, MODE, XF, VEC, EAB_PREC_F32, false>), grid, dim3(CG_THREADS), 0,
+                           s, *d);
     }
     EAB_RETURN_LAUNCH_STATUS();
+}
+
+// worst-case number of input positions a BM-row tile touches (the kernel's P)
+static long long cg_patch_positions(const eab_conv_desc* d) {
+    int dt_min = 0, io_min = 0, io_max = 0;
+    for (int j = 0; j < d->ntaps; ++j) {
+        dt_min = d->dt[j] < dt_min ? d->dt[j] : dt_min;
+        io_min = d->ioff[j] < io_min ? d->ioff[j] : io_min;
+        io_max = d->ioff[j] > io_max ? d->ioff[j] : io_max;
+    }
+    const int hi_need = (d->No - 1) * d->istride + io_max - (d->Fin - 1);
+    const long long Fp = d->Fin - io_min + (hi_need > 0 ? hi_need : 0);
+    const long long rows = (d->bm - 1) / d->No + 2 - dt_min;
+    return rows * Fp;
 }
 
 // K units per pipeline stage: big tiles keep three workgroups per CU resident
@@ -589,6 +810,11 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
     for (int j = 0; j < d->ntaps; ++j) EAB_CHECK_ARG(d->dt[j] <= 0 && d->dt[j] > -(1 << 20));
     EAB_CHECK_ARG(d->epi >= EAB_EPI_LINEAR && d->epi <= EAB_EPI_DUALGATE);
     EAB_CHECK_ARG(d->precision == EAB_PREC_F32 || d->precision == EAB_PREC_F16X3);
+    EAB_CHECK_ARG(d->korder == EAB_KORDER_TAP || d->korder == EAB_KORDER_CHUNK);
+    if (d->korder == EAB_KORDER_CHUNK) {   // patch pipeline: the tile's input patch must fit its LDS area
+        EAB_CHECK_ARG(cg_patch_positions(d) <= CG_PMAX && d->epi != EAB_EPI_DUALGATE);
+        EAB_CHECK_ARG(d->C0 % 4 == 0 && d->C1 % 4 == 0 && d->xf_mode != EAB_XF_PRELU_NORM);
+    }
     const bool dual = d->epi == EAB_EPI_DUALGATE;
     const bool glu = d->epi == EAB_EPI_GLU;
     EAB_CHECK_ARG(d->Cout == ((glu || dual) ? d->N / 2 : d->N));
@@ -631,6 +857,7 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
         EAB_CHECK_ARG(d->C0 <= CG_XFC && d->C1 <= CG_XFC && vec);
     int ku = cg_ku_override();
     if (ku == 0) ku = (mi == 1 && !glu && vec && d->Fin == 1) ? 4 : 1;
+    if (d->korder == EAB_KORDER_CHUNK) ku = 1;
     if (dual) {
         if (d->N != 128 || mi != 1 || xf != EAB_XF_PRELU_NORM) return EAB_EUNSUPPORTED;
         return cg_pick_ku<1, 2, CG_DUAL, EAB_XF_PRELU_NORM, true>(d, s, ku == 2 ? 1 : ku);

@@ -99,7 +99,7 @@ class _Bound:
                     setattr(d, f, A(getattr(op, f)))
                 for f in ("C0", "C1", "xf_mode", "N", "Kpad", "B", "T", "Fin", "Fout", "No", "ostride", "ophase",
                           "istride", "epi", "Cout", "nsets", "stat_tiles", "stat_tile0", "bm", "fin_tiles",
-                          "fin_nsets", "fin_count", "precision"):
+                          "fin_nsets", "fin_count", "precision", "korder"):
                     setattr(d, f, int(getattr(op, f)))
                 d.fin_eps = float(op.fin_eps)
                 d.ntaps = len(op.dt)

@@ -20,6 +20,7 @@ Data layout: activations are channels-last
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -32,6 +33,8 @@ XF_NONE, XF_NORM_PRELU, XF_PRELU_NORM = 0, 1, 2
 EPI_LINEAR, EPI_GLU, EPI_RELU, EPI_MULSIG, EPI_ADD, EPI_DUALGATE = 0, 1, 2, 3, 4, 5
 OP_CONV, OP_IN_FINALIZE, OP_NORM_ACT, OP_LSTM64, OP_BFW_FS, OP_MEMSET0 = 1, 2, 3, 4, 5, 6
 PREC_F32, PREC_F16X3 = 0, 1
+KORDER_TAP, KORDER_CHUNK = 0, 1
+PATCH_MAX = 352    # CG_PMAX in csrc/conv_gemm.hip
 MAX_TAPS = 16
 EPS_IN = 1e-5      # nn.InstanceNorm*d default (reference EaBNet.py:684,686)
 EPS_LN = 1e-5      # nn.LayerNorm default (reference EaBNet.py:598)
@@ -107,6 +110,7 @@ class ConvOp:
     fin_count: int = 0
     fin_eps: float = 0.0
     precision: int = PREC_F32
+    korder: int = KORDER_TAP
     name: str = ""
     kind: int = OP_CONV
 
@@ -189,6 +193,14 @@ class MemsetOp:
 
 def conv_tiles(T: int, No: int, bm: int) -> int:
     return (T * No + bm - 1) // bm
+
+
+def patch_positions(bm: int, No: int, Fin: int, istride: int, dt, ioff) -> int:
+    """worst-case input positions a bm-row tile touches (cg_patch_positions in conv_gemm.hip)"""
+    dt_min, io_min, io_max = min(0, min(dt)), min(0, min(ioff)), max(0, max(ioff))
+    hi_need = (No - 1) * istride + io_max - (Fin - 1)
+    Fp = Fin - io_min + max(hi_need, 0)
+    return ((bm - 1) // No + 2 - dt_min) * Fp
 
 
 # ----------------------------------------------------------------------------
@@ -279,6 +291,7 @@ class Lowering:
         if precision not in ("f32", "f16x3"):
             raise ValueError(f"precision must be 'f32' or 'f16x3', got {precision!r}")
         self.precision = precision
+        self.patch = os.environ.get("EAB_PATCH", "1") != "0"      # tuning knob: 0 = gather pipeline everywhere
         specs = param_specs(cfg)
         missing = [k for k in specs if k not in params]
         if missing:
@@ -333,6 +346,21 @@ class Lowering:
         upt = (C0 + C1 + 15) // 16
         assert Kpad == len(dt) * upt * 16
         bm = bm or self.pick_bm(No)
+        # patch pipeline (input patch of a 16-channel chunk staged once, taps read it shifted): pays
+        # when several taps re-read the same inputs; needs the patch of a tile to fit its LDS area
+        korder = KORDER_TAP
+        if (self.patch and len(dt) >= 2 and s0.F > 1 and epi != EPI_DUALGATE and mode != XF_PRELU_NORM
+                and C0 % 4 == 0 and C1 % 4 == 0 and stats is not None):
+            for cand in ((bm,) if bm == 64 else (128, 64)):
+                if patch_positions(cand, No, s0.F, istride, dt, ioff) <= PATCH_MAX:
+                    korder, bm_p = KORDER_CHUNK, cand
+                    break
+            if korder == KORDER_CHUNK and bm_p != bm:
+                korder = KORDER_TAP        # tile counts of the statistics were planned for bm
+        if korder == KORDER_CHUNK:
+            key = next(k for k, r in self.W.index.items() if r == w)
+            wt = self.W.chunks_by_name[key].reshape(N, len(dt), upt, 16)
+            w = self.W.add(key + ".chunk", np.ascontiguousarray(wt.transpose(0, 2, 1, 3)).reshape(N, Kpad))
         # f16x3 needs bounded operands: every source except the raw network input is either
         # instance-normalised or a sum of such tensors; the first conv stays on exact fp32.
         prec = PREC_F16X3 if (self.precision == "f16x3" and s0.ref.arena != "in" and C0 % 4 == 0 and C1 % 4 == 0) \
@@ -356,7 +384,7 @@ class Lowering:
                     istride=istride, dt=list(dt), ioff=list(ioff), epi=epi, aux=aux, dst=dst, dst_acc=dst_acc,
                     Cout=N // 2 if epi in (EPI_GLU, EPI_DUALGATE) else N, stats=stats, nsets=nsets,
                     stat_slope0=stat_slopes[0], stat_slope1=stat_slopes[1], stat_tiles=stat_tiles,
-                    stat_tile0=stat_tile0, bm=bm, name=name, precision=prec, **finkw)
+                    stat_tile0=stat_tile0, bm=bm, name=name, precision=prec, korder=korder, **finkw)
         self.ops.append(op)
         self.flops += 2 * self.B * self.T * No * N * len(dt) * (C0 + C1)
         return op

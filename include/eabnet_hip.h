@@ -165,10 +165,17 @@ typedef struct eab_conv_desc {
      * Then `w` holds, per row n and per group of 4 consecutive k, 4 fp16 hi followed
      * by 4 fp16 lo (same byte size as the fp32 matrix). */
     int32_t precision;
+    /* order of the K units inside `w`: EAB_KORDER_TAP (unit = tap*UPT + chunk, the gather
+     * pipeline) or EAB_KORDER_CHUNK (unit = chunk*ntaps + tap): selects the patch pipeline,
+     * which stages the input patch of one 16-channel chunk once in LDS and lets every tap
+     * read it at a shifted position.  Requires eab_conv_patch_positions(d) <= 352. */
+    int32_t korder;
 } eab_conv_desc;
 
 #define EAB_PREC_F32   0
 #define EAB_PREC_F16X3 1
+#define EAB_KORDER_TAP   0
+#define EAB_KORDER_CHUNK 1
 
 /* number of tiles per batch element a launch with this geometry produces */
 int eab_conv_tiles(int T, int No, int bm);

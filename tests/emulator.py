@@ -99,12 +99,18 @@ class Emulator:
         ntaps = len(op.dt)
         assert op.Kpad == ntaps * upt * 16
         h3 = op.precision == prg.PREC_F16X3
+
+        def by_tap(w2d):     # packed [N][Kpad] -> [N][tap][channel], whatever the unit order
+            if op.korder == prg.KORDER_CHUNK:
+                return w2d.reshape(op.N, upt, ntaps, 16).transpose(0, 2, 1, 3).reshape(op.N, ntaps, upt * 16)
+            return w2d.reshape(op.N, ntaps, upt * 16)
+
         if h3:
             Wh, Wl = unpack_f16x3(self.v(op.w, (op.N, op.Kpad)), op.N, op.Kpad)
-            Wh, Wl = Wh.reshape(op.N, ntaps, upt * 16), Wl.reshape(op.N, ntaps, upt * 16)
+            Wh, Wl = by_tap(Wh), by_tap(Wl)
             W = Wh + Wl
         else:
-            W = self.v(op.w, (op.N, ntaps, upt * 16))
+            W = by_tap(self.v(op.w, (op.N, op.Kpad)))
         assert not np.any(W[:, :, Ct:]), "padding columns of the packed weights must be zero"
 
         def mm(G, rows, j):
