@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary f16x3 measurement")
+    ap.add_argument("--no-graph", action="store_true", help="direct kernel launches instead of hipGraph replay")
     ap.add_argument("--precision", choices=("f32", "f16x3"), default="f32",
                     help="MFMA arithmetic of the timed path (DESIGN.md §4.4)")
     ap.add_argument("--per-op", type=str, default="", help="write the per-op timing table (instrumented replay) here")
@@ -142,6 +143,7 @@ def main():
     T = 1 + L // HOP
     net, state = make_model(MICS, dev)
     net.precision = a.precision
+    net.use_graph = not a.no_graph
     wav = synth_waves(B_PER_GPU, MICS, L, 1234 + rank).to(dev)    # resident in HBM before timing
     window = torch.hann_window(N_FFT)
 
