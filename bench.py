@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary f16x3 measurement")
+    ap.add_argument("--no-c1", action="store_true", help="skip the single-utterance (B=1) latency measurement")
     ap.add_argument("--no-graph", action="store_true", help="direct kernel launches instead of hipGraph replay")
     ap.add_argument("--precision", choices=("f32", "f16x3"), default="f32",
                     help="MFMA arithmetic of the timed path (DESIGN.md §4.4)")
@@ -263,6 +264,25 @@ def main():
                     "duration (HIP events per op on the launch stream, instrumented replay after the timed region); "
                     "peak = fp32 MFMA dense (MI355X_MICROARCH.md); traffic: see profiles/ (PMC passes are separate runs)",
         }
+    if rank == 0 and not a.no_c1:
+        # BASELINE configs[0] shape on the GPU: ONE 4-s 8-mic utterance, wave -> output, latency and RTF
+        wav1 = wav[:1].contiguous()
+        c1 = {}
+        for prec in (("f32", "f16x3") if (a.precision == "f32" and not a.no_alt) else (a.precision,)):
+            net.precision = prec
+            with torch.no_grad():
+                for _ in range(3):
+                    y1 = net(eabnet_amd.stft_compress(wav1, N_FFT, HOP, window))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    y1 = net(eabnet_amd.stft_compress(wav1, N_FFT, HOP, window))
+                torch.cuda.synchronize()
+                dt1 = (time.perf_counter() - t0) / 20
+            c1[prec] = {"ms_per_utterance": 1e3 * dt1, "rtf": dt1 / SECONDS, "frames_per_s": T / dt1}
+        net.precision = a.precision
+        out["single_utterance_c1"] = c1
+
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(state, MICS, L)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -72,6 +72,18 @@ __device__ __forceinline__ f32x4 cg_xform(f32x4 v, f32x4 sh01, f32x4 sh23, f32x4
     return r;
 }
 
+// Welford/Chan merge of two partial (count, mean, M2) statistics; (0,*,*) is the neutral element
+__device__ __forceinline__ void cg_merge(float& n, float& mean, float& m2, float nb, float meanb, float m2b) {
+    const float nt = n + nb;
+    if (nt > 0.0f) {
+        const float delta = meanb - mean;
+        const float fb = nb / nt;
+        mean = fmaf(delta, fb, mean);
+        m2 = m2 + m2b + delta * delta * n * fb;
+    }
+    n = nt;
+}
+
 __device__ __forceinline__ float cg_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // q / n for 0 <= q < 2^22 via the fp32 reciprocal, exact after one correction
@@ -140,16 +152,17 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
             if (d.fin_stats && k < d.fin_nsets) {
                 const float* gm = k == 0 ? d.fin_gamma0 : d.fin_gamma1;
                 const float* bt = k == 0 ? d.fin_beta0 : d.fin_beta1;
-                double sum = 0.0, sq = 0.0;
+                double sn = 0.0, sm = 0.0, sq = 0.0;            // same exact merge as in_finalize_kernel
                 for (int t = 0; t < d.fin_tiles; ++t) {
-                    const float2 v = *reinterpret_cast<const float2*>(
-                        &d.fin_stats[((((size_t)b * d.fin_tiles + t) * d.fin_nsets + k) * d.C0 + c) * 2]);
-                    sum += (double)v.x;
-                    sq += (double)v.y;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(
+                        &d.fin_stats[((((size_t)b * d.fin_tiles + t) * d.fin_nsets + k) * d.C0 + c) * 4]);
+                    const double n = (double)v[0], mu = (double)v[1];
+                    sn += n;
+                    sm = fma(n, mu, sm);
+                    sq += fma(n * mu, mu, (double)v[2]);
                 }
-                const double inv = 1.0 / (double)d.fin_count;
-                const double mean = sum * inv;
-                double var = sq * inv - mean * mean;
+                const double mean = sn > 0.0 ? sm / sn : 0.0;
+                double var = sn > 0.0 ? sq / sn - mean * mean : 0.0;
                 if (var < 0.0) var = 0.0;
                 const double scale = (double)gm[c] / sqrt(var + (double)d.fin_eps);
                 sc = (float)scale;
@@ -598,11 +611,16 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
             const float* sp = s == 0 ? d.stat_slope0 : d.stat_slope1;
             st_slope[s][c] = (d.stats && s < d.nsets && sp) ? sp[ch[c]] : 1.0f;
         }
-    float ssum[2][NC], ssq[2][NC];
+    // InstanceNorm partials in Welford form: per lane a shifted single pass (shift = the lane's first
+    // valid value, so a nearly constant channel loses nothing to cancellation), then Chan merges
+    // lane <-> lane^32 <-> the two wm waves.  (sum, sum of squares) partials in fp32 fail the
+    // reference's two-pass variance when var << mean^2, e.g. on two-frame utterances.
+    float skk[2][NC], ssum[2][NC], ssq[2][NC];
+    float scount = 0.0f;                        // valid rows seen by this lane (same for every column)
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) ssum[s][c] = ssq[s][c] = 0.0f;
+        for (int c = 0; c < NC; ++c) skk[s][c] = ssum[s][c] = ssq[s][c] = 0.0f;
     const bool two_sets = d.nsets == 2;
     // Output-side tensors through bounds-checked descriptors spanning this batch element:
     // rows past the tile end get an out-of-range offset (loads give 0, stores are dropped), and
@@ -668,38 +686,61 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_dst, o4, 0, 0);
                 if (d.dst_acc)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + accv[r][c]), r_acc, o4, 0, 0);
-                const float g0 = rowok[r] ? eab_prelu(v, st_slope[0][c]) : 0.0f;
-                ssum[0][c] += g0;
-                ssq[0][c] = fmaf(g0, g0, ssq[0][c]);
-                if (two_sets) {
-                    const float g1 = rowok[r] ? eab_prelu(v, st_slope[1][c]) : 0.0f;
-                    ssum[1][c] += g1;
-                    ssq[1][c] = fmaf(g1, g1, ssq[1][c]);
+                if (rowok[r]) {
+                    const bool first = scount == 0.0f;
+                    const float g0 = eab_prelu(v, st_slope[0][c]);
+                    if (first) skk[0][c] = g0;
+                    const float e0 = g0 - skk[0][c];
+                    ssum[0][c] += e0;
+                    ssq[0][c] = fmaf(e0, e0, ssq[0][c]);
+                    if (two_sets) {
+                        const float g1 = eab_prelu(v, st_slope[1][c]);
+                        if (first) skk[1][c] = g1;
+                        const float e1 = g1 - skk[1][c];
+                        ssum[1][c] += e1;
+                        ssq[1][c] = fmaf(e1, e1, ssq[1][c]);
+                    }
                 }
             }
+            if (rowok[r]) scount += 1.0f;
         }
     }
 
     if (d.stats) {
-        // lanes l and l^32 hold the same columns; then the two wm waves; fixed
-        // order everywhere => bit-reproducible partials.
+        // per lane: (n, mean, M2) from the shifted sums; then lanes l and l^32 (same columns), then
+        // the two wm waves through LDS; fixed order everywhere => bit-reproducible partials.
         float* red = &sm.a[0];               // staging LDS is free after the last barrier
+        float mean[2][NC], m2[2][NC];
+        float cnt = scount;
+        const float inv_n = scount > 0.0f ? 1.0f / scount : 0.0f;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                ssum[s][c] += __shfl_xor(ssum[s][c], 32);
-                ssq[s][c] += __shfl_xor(ssq[s][c], 32);
+                mean[s][c] = fmaf(ssum[s][c], inv_n, skk[s][c]);
+                m2[s][c] = fmaxf(ssq[s][c] - ssum[s][c] * ssum[s][c] * inv_n, 0.0f);
             }
-        // red[wm][wn][s][c][li][2]
+        const float cnt_o = __shfl_xor(cnt, 32);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float n = cnt;
+                const float mo = __shfl_xor(mean[s][c], 32), qo = __shfl_xor(m2[s][c], 32);
+                // both lanes of a pair must apply the merge in the same order: lower lane first
+                if (lh == 0) cg_merge(n, mean[s][c], m2[s][c], cnt_o, mo, qo);
+            }
+        cnt += cnt_o;
+        // red[wm][wn][s][c][li][3]
         if (lh == 0) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    const int i = ((((wm * 2 + wn) * 2 + s) * NC + c) * 32 + li) * 2;
-                    red[i] = ssum[s][c];
-                    red[i + 1] = ssq[s][c];
+                    const int i = ((((wm * 2 + wn) * 2 + s) * NC + c) * 32 + li) * 3;
+                    red[i] = cnt;
+                    red[i + 1] = mean[s][c];
+                    red[i + 2] = m2[s][c];
                 }
         }
         __syncthreads();
@@ -710,10 +751,11 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
                 if (s >= d.nsets) break;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    const int i0 = ((((0 * 2 + wn) * 2 + s) * NC + c) * 32 + li) * 2;
-                    const int i1 = ((((1 * 2 + wn) * 2 + s) * NC + c) * 32 + li) * 2;
-                    float2 o2 = make_float2(red[i0] + red[i1], red[i0 + 1] + red[i1 + 1]);
-                    *reinterpret_cast<float2*>(&d.stats[((tbase + s) * Cout + ch[c]) * 2]) = o2;
+                    const int i0 = ((((0 * 2 + wn) * 2 + s) * NC + c) * 32 + li) * 3;
+                    const int i1 = ((((1 * 2 + wn) * 2 + s) * NC + c) * 32 + li) * 3;
+                    float n = red[i0], mu = red[i0 + 1], q = red[i0 + 2];
+                    cg_merge(n, mu, q, red[i1], red[i1 + 1], red[i1 + 2]);
+                    *reinterpret_cast<f32x4*>(&d.stats[((tbase + s) * Cout + ch[c]) * 4]) = f32x4{n, mu, q, 0.0f};
                 }
             }
         }
@@ -858,6 +900,8 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
     int ku = cg_ku_override();
     if (ku == 0) ku = (mi == 1 && !glu && vec && d->Fin == 1) ? 4 : 1;
     if (d->korder == EAB_KORDER_CHUNK) ku = 1;
+    if (ku == 4 && !(mi == 1 && !glu && vec)) ku = 1;       // KU = 4 exists for the 64-row plain / dual tiles only
+    if (ku == 2 && (!vec || dual)) ku = 1;
     if (dual) {
         if (d->N != 128 || mi != 1 || xf != EAB_XF_PRELU_NORM) return EAB_EUNSUPPORTED;
         return cg_pick_ku<1, 2, CG_DUAL, EAB_XF_PRELU_NORM, true>(d, s, ku == 2 ? 1 : ku);

@@ -4,54 +4,60 @@
 // utterance), nn.PReLU(c), En_unet_module's residual add (EaBNet.py:386).
 #include "common.h"
 
-// grid = (B * nsets, C/64), block = 1024: 16 tile-slices x 64 channels, four
-// independent loads in flight per thread; fp64 accumulation in a fixed order.
+// grid = (B * nsets, C/64), block = 1024: 16 tile-slices x 64 channels.
 #define FIN_SLICES 16
+// Partials are Welford triples (n, mean_i, M2_i) per tile (conv_gemm.hip).  Exact merge:
+//   N = sum n_i,  mean = sum n_i mean_i / N,  M2 = sum (M2_i + n_i mean_i^2) - N mean^2.
+// The three sums run in fp64 over fp32 inputs that are already centred per tile, so the final
+// subtraction loses ~1e-16 * mean^2 / var -- unlike fp32 (sum x, sum x^2) partials -- and no
+// division is needed per tile.  Fixed summation order => bit-reproducible.
 __global__ __launch_bounds__(1024) void in_finalize_kernel(const float* __restrict__ stats, int C, int nsets,
-                                                           int stat_tiles, double inv_count, float eps,
+                                                           int stat_tiles, float eps,
                                                            const float* __restrict__ gamma0,
                                                            const float* __restrict__ beta0, float* __restrict__ xf0,
                                                            const float* __restrict__ gamma1,
                                                            const float* __restrict__ beta1, float* __restrict__ xf1) {
-    __shared__ double red[2][FIN_SLICES][64];
+    __shared__ double red[3][FIN_SLICES][64];
     const int b = blockIdx.x / nsets, s = blockIdx.x % nsets;
     const float* gamma = s == 0 ? gamma0 : gamma1;
     const float* beta = s == 0 ? beta0 : beta1;
     float* xf = s == 0 ? xf0 : xf1;
     const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cl;
-    double sum = 0.0, sq = 0.0;
+    double sn = 0.0, sm = 0.0, sq = 0.0;
+    auto add = [&](const f32x4 v) {
+        const double n = (double)v[0], mu = (double)v[1];
+        sn += n;
+        sm = fma(n, mu, sm);
+        sq += fma(n * mu, mu, (double)v[2]);
+    };
     if (c < C) {
-        const size_t stride = (size_t)nsets * C * 2;                         // floats between tiles
-        const float* p = stats + (((size_t)b * stat_tiles) * nsets + s) * C * 2 + (size_t)c * 2;
+        const size_t stride = (size_t)nsets * C * 4;                         // floats between tiles
+        const float* p = stats + (((size_t)b * stat_tiles) * nsets + s) * C * 4 + (size_t)c * 4;
         int t = slice;
-        for (; t + 3 * FIN_SLICES < stat_tiles; t += 4 * FIN_SLICES) {
-            const float2 v0 = *reinterpret_cast<const float2*>(p + (size_t)t * stride);
-            const float2 v1 = *reinterpret_cast<const float2*>(p + (size_t)(t + FIN_SLICES) * stride);
-            const float2 v2 = *reinterpret_cast<const float2*>(p + (size_t)(t + 2 * FIN_SLICES) * stride);
-            const float2 v3 = *reinterpret_cast<const float2*>(p + (size_t)(t + 3 * FIN_SLICES) * stride);
-            sum += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
-            sq += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+        for (; t + 3 * FIN_SLICES < stat_tiles; t += 4 * FIN_SLICES) {       // four loads in flight
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)t * stride);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(t + FIN_SLICES) * stride);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (size_t)(t + 2 * FIN_SLICES) * stride);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (size_t)(t + 3 * FIN_SLICES) * stride);
+            add(v0); add(v1); add(v2); add(v3);
         }
-        for (; t < stat_tiles; t += FIN_SLICES) {
-            const float2 v = *reinterpret_cast<const float2*>(p + (size_t)t * stride);
-            sum += (double)v.x;
-            sq += (double)v.y;
-        }
+        for (; t < stat_tiles; t += FIN_SLICES) add(*reinterpret_cast<const f32x4*>(p + (size_t)t * stride));
     }
-    red[0][slice][cl] = sum;
-    red[1][slice][cl] = sq;
+    red[0][slice][cl] = sn;
+    red[1][slice][cl] = sm;
+    red[2][slice][cl] = sq;
     __syncthreads();
     if (slice == 0 && c < C) {
-        sum = 0.0;
-        sq = 0.0;
+        sn = 0.0; sm = 0.0; sq = 0.0;
 #pragma unroll
         for (int k = 0; k < FIN_SLICES; ++k) {
-            sum += red[0][k][cl];
-            sq += red[1][k][cl];
+            sn += red[0][k][cl];
+            sm += red[1][k][cl];
+            sq += red[2][k][cl];
         }
-        const double mean = sum * inv_count;
-        double var = sq * inv_count - mean * mean;
+        const double mean = sn > 0.0 ? sm / sn : 0.0;
+        double var = sn > 0.0 ? sq / sn - mean * mean : 0.0;                 // biased variance, as nn.InstanceNorm
         if (var < 0.0) var = 0.0;
         const double scale = (double)gamma[c] / sqrt(var + (double)eps);
         const double shift = (double)beta[c] - mean * scale;
@@ -67,7 +73,7 @@ extern "C" int eab_in_finalize_f32(const float* stats, int B, int C, int nsets, 
     EAB_CHECK_ARG(gamma0 && beta0 && xf0);
     EAB_CHECK_ARG(nsets == 1 || (gamma1 && beta1 && xf1));
     hipLaunchKernelGGL(in_finalize_kernel, dim3(B * nsets, (C + 63) / 64), dim3(1024), 0, eab_stream(stream), stats, C,
-                       nsets, stat_tiles, 1.0 / (double)count, eps, gamma0, beta0, xf0, gamma1, beta1, xf1);
+                       nsets, stat_tiles, eps, gamma0, beta0, xf0, gamma1, beta1, xf1);
     EAB_RETURN_LAUNCH_STATUS();
 }
 

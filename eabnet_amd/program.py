@@ -349,7 +349,8 @@ class Lowering:
         # patch pipeline (input patch of a 16-channel chunk staged once, taps read it shifted): pays
         # when several taps re-read the same inputs; needs the patch of a tile to fit its LDS area
         korder = KORDER_TAP
-        if (self.patch and len(dt) >= 2 and s0.F > 1 and epi != EPI_DUALGATE and mode != XF_PRELU_NORM
+        patch_min_n = int(os.environ.get("EAB_PATCH_MIN_N", "128"))      # tuning knob
+        if (self.patch and N >= patch_min_n and len(dt) >= 2 and s0.F > 1 and epi != EPI_DUALGATE and mode != XF_PRELU_NORM
                 and C0 % 4 == 0 and C1 % 4 == 0 and stats is not None):
             for cand in ((bm,) if bm == 64 else (128, 64)):
                 if patch_positions(cand, No, s0.F, istride, dt, ioff) <= PATCH_MAX:
@@ -420,7 +421,7 @@ class Lowering:
         dst = self.alloc_act(Fout, Cout)
         bm = self.pick_bm(Fout)
         tiles = conv_tiles(self.T, Fout, bm)
-        stats = self.alloc(self.B * tiles * Cout * 2)
+        stats = self.alloc(self.B * tiles * Cout * 4)
         self.emit_conv(name, srcs, wref, bref, N, wp.shape[1], Fout, Fout, 1, 0, 2,
                        [a - (kt - 1) for a, _ in taps], [c for _, c in taps],
                        EPI_GLU if glu else EPI_LINEAR, dst, stats, 1, (None, None), tiles, 0, bm)
@@ -446,7 +447,7 @@ class Lowering:
         No = [(Fout + 1) // 2, Fout // 2]
         bm = self.pick_bm(No[0])
         tiles = [conv_tiles(self.T, n, bm) for n in No]
-        stats = self.alloc(self.B * sum(tiles) * Cout * 2)
+        stats = self.alloc(self.B * sum(tiles) * Cout * 4)
         for ph in (0, 1):
             taps = [(a, c) for a in range(kt) for c in range(ph, kf, 2)]
             wp = pack_taps(wn, [a * kf + c for a, c in taps])
@@ -506,7 +507,7 @@ class Lowering:
         w_in = self.P[f"{pre}.in_conv.weight"][:, perm, :]               # (cd, D, 1)
         wref = self.W.add(f"{pre}.in_conv.weight#packed", pack_taps(w_in, [0]))
         y = self.alloc_act(1, cd)
-        st = self.alloc(B * tiles * 2 * cd * 2)
+        st = self.alloc(B * tiles * 2 * cd * 4)
         slL, slR = self.vec(f"{pre}.left_conv.0.weight"), self.vec(f"{pre}.right_conv.0.weight")
         self.emit_conv(f"{pre}.in_conv", [x], wref, None, cd, D, 1, 1, 1, 0, 1, [0], [0], EPI_LINEAR, y,
                        st, 2, (slL, slR), tiles, 0, bm)
@@ -515,7 +516,7 @@ class Lowering:
         wlr = np.concatenate([self.P[f"{pre}.left_conv.3.weight"], self.P[f"{pre}.right_conv.3.weight"]], axis=0)
         wd = self.W.add(f"{pre}.lr_conv.weight#packed", pack_taps(wlr[glu_row_order(2 * cd)], range(kd)))
         z = self.alloc_act(1, cd)
-        st2 = self.alloc(B * tiles * cd * 2)
+        st2 = self.alloc(B * tiles * cd * 4)
         slO = self.vec(f"{pre}.out_conv.0.weight")
         self.emit_conv(f"{pre}.lr_conv", [Act(y, 1, cd, None, slL, XF_PRELU_NORM)], wd, None, 2 * cd,
                        kd * ((cd + 15) // 16) * 16, 1, 1, 1, 0, 1, dts, [0] * kd, EPI_DUALGATE, z, st2, 1, (slO, None),

@@ -137,9 +137,10 @@ typedef struct eab_conv_desc {
     float* dst;             /* [B][T][Fout][Cout] */
     float* dst_acc;         /* optional running sum: dst_acc += out (same layout) */
     int32_t Cout;           /* N/2 for GLU, else N */
-    /* statistics for the consumer's InstanceNorm: per tile, per set s, per
-     * channel c: (sum g_s(out), sum g_s(out)^2), g_s = PReLU(stat_slope[s]) or id.
-     * stats[((b*stat_tiles + stat_tile0 + tile)*nsets + s)*Cout + c][2] */
+    /* statistics for the consumer's InstanceNorm: per tile, per set s, per channel c the
+     * Welford triple (n, mean, M2 = sum (g - mean)^2, 0) of g_s(out) over the tile's valid rows,
+     * g_s = PReLU(stat_slope[s]) or id:
+     * stats[((b*stat_tiles + stat_tile0 + tile)*nsets + s)*Cout + c][4] */
     float* stats;
     int32_t nsets;          /* 0, 1 or 2 */
     const float* stat_slope0;
@@ -149,7 +150,7 @@ typedef struct eab_conv_desc {
     int32_t bm;             /* rows per tile: 64 or 128 (host's choice, see eab_conv_tiles) */
     /* optional in-kernel InstanceNorm finalisation (replaces eab_in_finalize_f32 + xf0[/xf1]
      * when the producer wrote few tiles): fin_stats = the producer's partials
-     * [B][fin_tiles][fin_nsets][C0][2]; set 0 -> transform 0 with (fin_gamma0, fin_beta0),
+     * [B][fin_tiles][fin_nsets][C0][4]; set 0 -> transform 0 with (fin_gamma0, fin_beta0),
      * set 1 -> transform 1 (EAB_EPI_DUALGATE only).  xf0/xf1 must be NULL then. */
     const float* fin_stats;
     const float* fin_gamma0;
@@ -184,8 +185,9 @@ int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream);
 /* --------------------------------------------------------------------------
  * K8 (statistics half)  InstanceNorm finalisation.  Replaces the reduction in
  * nn.InstanceNorm{1,2}d(affine=True), EaBNet.py:684,686 (eps 1e-5, biased var).
- * Reduces the partials written by eab_conv_f32 (fp64 accumulation, fixed order
- * => bit-reproducible) and emits, per set s, xf_s[b][c] = (scale, shift) with
+ * Merges the (n, mean, M2) partials written by eab_conv_f32 (Chan's formula in fp64, fixed
+ * order => bit-reproducible, no E[x^2]-E[x]^2 cancellation; `count` is informational: the
+ * partials carry their own counts) and emits, per set s, xf_s[b][c] = (scale, shift) with
  *   scale = gamma_s[c] / sqrt(var + eps), shift = beta_s[c] - mean*scale.
  * ------------------------------------------------------------------------ */
 int eab_in_finalize_f32(const float* stats, int B, int C, int nsets, int stat_tiles,

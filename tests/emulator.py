@@ -22,6 +22,15 @@ def _prelu(x, a):
     return np.where(x > 0, x, a * x)
 
 
+def _merge_welford(st):
+    """st: (B, tiles, C, 4) float64 triples (n, mean, M2, -) -> (mean, biased variance), (B, C)."""
+    n, mu, m2 = st[..., 0], st[..., 1], st[..., 2]
+    N = n.sum(1)
+    mean = (n * mu).sum(1) / N
+    M2 = m2.sum(1) + (n * (mu - mean[:, None]) ** 2).sum(1)
+    return mean, M2 / N
+
+
 def f16_rtz(x):
     """fp32 -> fp16 rounding toward zero (v_cvt_pkrtz_f16_f32), returned as fp32."""
     x = np.asarray(x, dtype=np.float32)
@@ -69,15 +78,13 @@ class Emulator:
         dual = op.epi == prg.EPI_DUALGATE
         fin_tabs = None
         if op.fin_stats is not None:         # in-kernel InstanceNorm finalisation
-            st = self.v(op.fin_stats, (B, op.fin_tiles, op.fin_nsets, op.C0, 2)).astype(np.float64)
+            st = self.v(op.fin_stats, (B, op.fin_tiles, op.fin_nsets, op.C0, 4)).astype(np.float64)
             assert not np.isnan(st).any(), f"{op.name}: producer partials not fully written"
             fin_tabs = []
             for k, (g, bb) in enumerate(((op.fin_gamma0, op.fin_beta0), (op.fin_gamma1, op.fin_beta1))):
                 if g is None:
                     break
-                tot = st[:, :, k].sum(1)
-                mean = tot[..., 0] / op.fin_count
-                var = np.maximum(tot[..., 1] / op.fin_count - mean * mean, 0)
+                mean, var = _merge_welford(st[:, :, k])
                 scale = self.v(g, (op.C0,)) / np.sqrt(var + op.fin_eps)
                 fin_tabs.append(np.stack([scale, self.v(bb, (op.C0,)) - mean * scale], -1).astype(np.float32))
         srcs, X2 = [], None
@@ -161,23 +168,25 @@ class Emulator:
         if op.dst_acc is not None:
             self.v(op.dst_acc, (B, T, op.Fout, Cout))[:, :, fo] += out
         if op.stats is not None:
-            st = self.v(op.stats, (B, op.stat_tiles, op.nsets, Cout, 2))
+            st = self.v(op.stats, (B, op.stat_tiles, op.nsets, Cout, 4))
             rows = out.reshape(B, T * No, Cout)
             tiles = prg.conv_tiles(T, No, op.bm)
             for s, slr in enumerate((op.stat_slope0, op.stat_slope1)[:op.nsets]):
                 g = rows if slr is None else _prelu(rows, self.v(slr, (Cout,)))
-                for t in range(tiles):
-                    blk = g[:, t * op.bm:(t + 1) * op.bm].astype(np.float32)
-                    st[:, op.stat_tile0 + t, s, :, 0] = blk.sum(1)
-                    st[:, op.stat_tile0 + t, s, :, 1] = (blk * blk).sum(1)
+                for t in range(tiles):       # Welford triple (n, mean, M2, 0) of the tile's valid rows
+                    blk = g[:, t * op.bm:(t + 1) * op.bm].astype(np.float64)
+                    mu = blk.mean(1)
+                    st[:, op.stat_tile0 + t, s, :, 0] = blk.shape[1]
+                    st[:, op.stat_tile0 + t, s, :, 1] = mu
+                    st[:, op.stat_tile0 + t, s, :, 2] = ((blk - mu[:, None]) ** 2).sum(1)
+                    st[:, op.stat_tile0 + t, s, :, 3] = 0.0
 
     def finalize(self, op: prg.FinalizeOp):
-        st = self.v(op.stats, (op.B, op.stat_tiles, op.nsets, op.C, 2)).astype(np.float64)
+        st = self.v(op.stats, (op.B, op.stat_tiles, op.nsets, op.C, 4)).astype(np.float64)
         assert not np.isnan(st).any(), f"{op.name}: statistics partials not fully written"
         for s, (g, b, xf) in enumerate(((op.gamma0, op.beta0, op.xf0), (op.gamma1, op.beta1, op.xf1))[:op.nsets]):
-            tot = st[:, :, s].sum(1)
-            mean = tot[..., 0] / op.count
-            var = np.maximum(tot[..., 1] / op.count - mean * mean, 0)
+            mean, var = _merge_welford(st[:, :, s])
+            assert np.all(st[:, :, s, :, 0].sum(1) == op.count), f"{op.name}: partial counts do not add up"
             scale = self.v(g, (op.C,)) / np.sqrt(var + op.eps)
             shift = self.v(b, (op.C,)) - mean * scale
             out = self.v(xf, (op.B, op.C, 2))

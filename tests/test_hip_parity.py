@@ -250,6 +250,59 @@ def test_moderate_size_vs_oracle(dev):
     assert_close(y.numpy(), ref.numpy(), TOL_HIP)
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_c5_shape_16_mics_8_seconds_vs_oracle(dev, precision):
+    """BASELINE configs[4] shape (16-mic array, 8-s utterance, T = 801), wave -> output, against the
+    oracle on the host cores.  (The streaming / bf16 aspects of that config are later rows.)"""
+    import eabnet_amd
+    from oracle import eabnet_oracle as orc
+    P = torch_params(16, 123)
+    net = _model(16, 123, dev)
+    net.precision = precision
+    wav = torch.from_numpy(paramgen.make_wave(1, 16, 128000, 124))
+    with torch.no_grad():
+        ns = eabnet_amd.stft_compress(wav.to(dev), 320, 160, torch.hann_window(320))
+        y = net(ns).cpu()
+        ns_ref, _ = orc.prepare_data_oracle(wav, None)
+        ref = orc.eabnet_forward(P, ns_ref, fast_lstm=True)
+    assert ns.shape == (1, 801, 161, 16, 2)
+    assert_compressed_close(ns.cpu().numpy(), ns_ref.numpy(), TOL_HIP)
+    m, l2 = assert_close(y.numpy(), ref.numpy(), TOL_HIP)
+    print(f"C5 shape {precision}: max-rel {m:.2e}, l2-rel {l2:.2e}")
+
+
+@pytest.mark.parametrize("L", [161, 319, 480, 800])
+def test_shortest_utterances(dev, L):
+    """torch.stft(center=True, reflect) needs L > n_fft/2 = 160: L = 161 is the shortest legal wave
+    (T = 2 frames).  InstanceNorm over 2-4 frames divides by a vanishing variance, so the reference
+    ALGORITHM is ill-conditioned there: its own fp32 and fp64 evaluations differ by 5e-2 at T = 2
+    (5.7e-5 at T = 4, 3.5e-6 at T = 11).  The bar is therefore: against the fp64 evaluation, the HIP
+    path may not be worse than max(1e-4, 3 x the fp32 reference arithmetic's own error)."""
+    import eabnet_amd
+    from oracle import eabnet_oracle as orc
+    P = torch_params(2, 130)
+    net = _model(2, 130, dev)
+    wav = torch.from_numpy(paramgen.make_wave(1, 2, L, 131))
+    with torch.no_grad():
+        ns = eabnet_amd.stft_compress(wav.to(dev), 320, 160, torch.hann_window(320))
+        y = net(ns).cpu()
+        ns_ref, _ = orc.prepare_data_oracle(wav, None)
+        ref32 = orc.eabnet_forward(P, ns_ref)
+        ref64 = orc.eabnet_forward({k: v.double() for k, v in P.items()}, ns_ref.double())
+    assert y.shape == (1, 2, 1 + L // 160, 161) and torch.isfinite(y).all()
+    assert_compressed_close(ns.cpu().numpy(), ns_ref.numpy(), TOL_HIP)
+    e_ref = max(rel_errs(ref32.numpy(), ref64.numpy()))
+    e_hip = max(rel_errs(y.numpy(), ref64.numpy()))
+    assert e_hip <= max(TOL_HIP, 3.0 * e_ref), f"T={1 + L // 160}: HIP {e_hip:.2e} vs fp32 reference arithmetic {e_ref:.2e}"
+
+
+def test_too_short_wave_is_rejected(dev):
+    import eabnet_amd
+    from eabnet_amd import _lib
+    with pytest.raises(_lib.EabError):
+        eabnet_amd.stft_compress(torch.zeros(1, 1, 160, device=dev), 320, 160, torch.hann_window(320))
+
+
 def test_graph_replay_equals_direct_launches(dev):
     """hipGraph replay of the op program (default) and ~250 direct launches give bit-identical
     outputs; changing the input between replays is honoured (static buffers are refreshed)."""
