@@ -249,11 +249,25 @@ def main():
                   prg.OP_LSTM64: "lstm64", prg.OP_BFW_FS: "bfw_filter_sum", prg.OP_MEMSET0: "memset"}[o.kind]
             by_kind[nm] = by_kind.get(nm, 0.0) + float(ms[k])
         peak = PEAK_FP32_MFMA_TFLOPS
+        # HBM traffic of the dominant kernel from the committed PMC summary of the same command
+        # (tools/prof.sh + tools/summarize_profiles.py; PMC passes are separate runs by necessity).
+        # MI355X_MICROARCH.md §HBM: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE reads
+        # half of a wide coalesced read stream on gfx950.
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_final", "pmc_summary.json")))
+            tag = "conv_gemm_kernel<2, 2, 1, 1, 0, true, %d, true>" % (0 if a.precision == "f32" else 1)
+            ent = next(v for k, v in pmc.items() if tag in k)
+            c = ent["counters"]
+            traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / ent["dispatches"]
+        except Exception:                                   # noqa: BLE001 - no committed profile: leave null
+            traffic = None
         out["roofline"] = {
             "kernel": "conv_gemm_kernel<MI=2,NI=2,KU=1,GLU,XF=0,VEC," + ("f32" if a.precision == "f32" else "f16x3")
                       + "> (128x128-tile gated gather-GEMM convolution)",
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "traffic": None, "launches_per_step": len(dom), "avg_launch_ms": dom_ms / max(len(dom), 1),
+            "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r01_final)",
+            "launches_per_step": len(dom), "avg_launch_ms": dom_ms / max(len(dom), 1),
             "algorithmic_gflop_per_launch": dom_flop / max(len(dom), 1) / 1e9,
             "share_of_program_time": dom_ms / float(ms.sum()),
             "all_conv_launches": {"launches_per_step": len(conv), "ms": conv_ms,
