@@ -2,6 +2,16 @@
 // EaBNet.forward (reference EaBNet.py:88-117) lowered by eabnet_amd/program.py.
 #include "common.h"
 
+// Zero fill as a KERNEL: a hipMemsetAsync captured into a hipGraph was observed (ROCm 7.2, 6.5 MB) not
+// to be ordered against the neighbouring kernel nodes when the graph is replayed on an idle stream --
+// the S-TCN running sum then accumulated across replays.  A kernel node has no such ambiguity.
+__global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ p, size_t n4, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = i; k < n4; k += stride) reinterpret_cast<f32x4*>(p)[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (size_t k = 4 * n4 + i; k < n; k += stride) p[k] = 0.0f;
+}
+
 extern "C" int eab_abi_version(void) { return EAB_ABI_VERSION; }
 
 extern "C" const char* eab_error_string(int code) {
@@ -43,8 +53,17 @@ extern "C" int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream
                 break;
             case EAB_OP_MEMSET0: {
                 const size_t bytes = ((size_t)(uint32_t)o.i[1] << 32) | (uint32_t)o.i[0];
-                rc = o.p[0] ? eab_hip_status(hipMemsetAsync(const_cast<void*>(o.p[0]), 0, bytes, eab_stream(stream)))
-                            : EAB_EINVAL;
+                if (!o.p[0] || (bytes & 3) || ((uintptr_t)o.p[0] & 15)) {
+                    rc = EAB_EINVAL;
+                    break;
+                }
+                const size_t n = bytes / 4, n4 = n / 4;
+                size_t g = (n4 + 255) / 256;
+                if (g > 2048) g = 2048;
+                if (g == 0) g = 1;
+                hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)g), dim3(256), 0, eab_stream(stream),
+                                   (float*)const_cast<void*>(o.p[0]), n4, n);
+                rc = eab_hip_status(hipGetLastError());
                 break;
             }
             default:

@@ -319,6 +319,24 @@ def test_graph_replay_equals_direct_launches(dev):
     assert not torch.equal(a1, a2)
 
 
+def test_graph_replay_on_idle_stream_full_length(dev):
+    """Regression: at T = 401 a hipMemsetAsync node inside the captured program was not ordered against
+    its neighbours when the graph was replayed on an IDLE stream (the S-TCN running sum was not
+    re-zeroed).  Replays separated by synchronisations must equal direct launches bit for bit."""
+    net = _model(8, 100, dev)
+    x = torch.from_numpy(paramgen.make_spec_input(2, 401, 161, 8, 141)).to(dev)
+    with torch.no_grad():
+        net.use_graph = False
+        ref = net(x).clone()
+        torch.cuda.synchronize()
+        net.use_graph = True
+        for i in range(4):
+            y = net(x)
+            torch.cuda.synchronize()
+            assert net._last[0].graph is not None
+            assert torch.equal(y, ref), f"replay {i} deviates from direct launches"
+
+
 def test_weights_are_repacked_after_update(dev):
     net = _model(2, 95, dev)
     x = torch.from_numpy(paramgen.make_spec_input(1, 8, 161, 2, 96)).to(dev)
