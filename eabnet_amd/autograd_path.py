@@ -1,0 +1,118 @@
+"""Differentiable evaluation of EaBNet for TRAINING (BASELINE config 4).
+
+Inference runs the hand-written HIP program (model.py -> libeabnet_hip.so).  The backward kernels
+are a later row; until they exist, a forward that must be differentiable is evaluated with
+PyTorch-ROCm operators (MIOpen convolutions, ATen LSTM) on the module's own ``nn.Parameter``s, so
+``loss.backward()``, ``clip_grad_norm_``, Adam and ``DistributedDataParallel`` (RCCL bucketed
+gradient all-reduce over xGMI; reference train_distributed.py:198,228-230) work unchanged.  It is
+selected only when autograd needs a graph (``torch.is_grad_enabled()`` and something requires
+grad); ``torch.no_grad()`` inference never takes this path and never falls back to it.
+
+The network definition follows the reference's forward (EaBNet.py:88-117 and the block
+forwards :372-388, :455-460, :485-490, :572-578, :600-614); parameters are looked up by their
+state-dict keys (eabnet_amd/spec.py).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+def _norm_act(m, x, norm: str, act: str):
+    x = F.instance_norm(x, weight=m.get_parameter(f"{norm}.norm.weight"), bias=m.get_parameter(f"{norm}.norm.bias"),
+                        use_input_stats=True, eps=1e-5)
+    return F.prelu(x, m.get_parameter(f"{act}.weight"))
+
+
+def _glu(y):
+    a, g = y.chunk(2, dim=1)
+    return a * torch.sigmoid(g)
+
+
+def _gate_conv(m, x, key: str):
+    w, b = m.get_parameter(f"{key}.weight"), m.get_parameter(f"{key}.bias")
+    return _glu(F.conv2d(F.pad(x, (0, 0, w.shape[2] - 1, 0)), w, b, stride=(1, 2)))      # causal top pad
+
+
+def _gate_deconv(m, x, key: str):
+    w, b = m.get_parameter(f"{key}.weight"), m.get_parameter(f"{key}.bias")
+    y = F.conv_transpose2d(x, w, b, stride=(1, 2))
+    kt = w.shape[2]
+    return _glu(y[:, :, :y.shape[2] - (kt - 1)] if kt > 1 else y)                          # chomp the last rows
+
+
+def _unet(m, x, pre: str, scale: int, transposed: bool):
+    g = _gate_deconv(m, x, f"{pre}.in_conv.0.conv.0") if transposed else _gate_conv(m, x, f"{pre}.in_conv.0.conv.1")
+    resi = _norm_act(m, g, f"{pre}.in_conv.1", f"{pre}.in_conv.2")
+    y, downs = resi, []
+    for j in range(scale):
+        q = f"{pre}.enco.{j}.conv"
+        y = _norm_act(m, F.conv2d(y, m.get_parameter(f"{q}.0.weight"), m.get_parameter(f"{q}.0.bias"), stride=(1, 2)),
+                      f"{q}.1", f"{q}.2")
+        downs.append(y)
+    for j in range(scale):
+        q = f"{pre}.deco.{j}.deconv"
+        if j:
+            y = torch.cat((y, downs[-(j + 1)]), dim=1)
+        y = _norm_act(m, F.conv_transpose2d(y, m.get_parameter(f"{q}.0.weight"), m.get_parameter(f"{q}.0.bias"),
+                                            stride=(1, 2)), f"{q}.1", f"{q}.2")
+    return resi + y
+
+
+def _tcm(m, x, pre: str, dilation: int):
+    kd = m.kd1
+    y = F.conv1d(x, m.get_parameter(f"{pre}.in_conv.weight"))
+
+    def branch(side):
+        z = F.prelu(y, m.get_parameter(f"{pre}.{side}.0.weight"))
+        z = F.instance_norm(z, weight=m.get_parameter(f"{pre}.{side}.1.norm.weight"),
+                            bias=m.get_parameter(f"{pre}.{side}.1.norm.bias"), use_input_stats=True, eps=1e-5)
+        return F.conv1d(F.pad(z, ((kd - 1) * dilation, 0)), m.get_parameter(f"{pre}.{side}.3.weight"), dilation=dilation)
+
+    z = branch("left_conv") * torch.sigmoid(branch("right_conv"))
+    z = F.prelu(z, m.get_parameter(f"{pre}.out_conv.0.weight"))
+    z = F.instance_norm(z, weight=m.get_parameter(f"{pre}.out_conv.1.norm.weight"),
+                        bias=m.get_parameter(f"{pre}.out_conv.1.norm.bias"), use_input_stats=True, eps=1e-5)
+    return F.conv1d(z, m.get_parameter(f"{pre}.out_conv.2.weight")) + x
+
+
+def _lstm(m, x, name: str):
+    p = f"bf_map.{name}"
+    flat = [m.get_parameter(f"{p}.weight_ih_l0"), m.get_parameter(f"{p}.weight_hh_l0"),
+            m.get_parameter(f"{p}.bias_ih_l0"), m.get_parameter(f"{p}.bias_hh_l0")]
+    z = x.new_zeros(1, x.shape[0], flat[1].shape[1])
+    return torch._VF.lstm(x, (z, z), flat, True, 1, 0.0, m.training, False, True)[0]
+
+
+def forward_autograd(m, inpt: torch.Tensor) -> torch.Tensor:
+    """(B,T,F,M,2) -> (B,2,T,F), differentiable w.r.t. the module's parameters and the input."""
+    if inpt.ndim == 4:
+        inpt = inpt.unsqueeze(-2)
+    B, T, Fq, M, _ = inpt.shape
+    x = inpt.transpose(-2, -1).contiguous().view(B, T, Fq, 2 * M).permute(0, 3, 1, 2)     # channel = ri*M + m
+    skips = []
+    for i in range(4):
+        x = _unet(m, x, f"en.meta_unet_list.{i}", 4 - i, False)
+        skips.append(x)
+    x = _norm_act(m, _gate_conv(m, x, "en.last_conv.0.conv.1"), "en.last_conv.1", "en.last_conv.2")
+    skips.append(x)
+    C = x.shape[1]
+    x = x.transpose(-2, -1).contiguous().view(B, -1, T)
+    acc = torch.zeros_like(x)
+    for g in range(m.q):
+        for i in range(m.p):
+            x = _tcm(m, x, f"stcns.{g}.tcm_list.{i}", 2 ** i)
+        acc = acc + x
+    x = acc.view(B, C, -1, T).transpose(-2, -1).contiguous()
+    for i in range(4):
+        x = _unet(m, torch.cat((x, skips[-(i + 1)]), dim=1), f"de.meta_unet_list.{i}", i + 1, True)
+    x = _norm_act(m, _gate_deconv(m, torch.cat((x, skips[0]), dim=1), "de.last_conv.0.conv.0"),
+                  "de.last_conv.1", "de.last_conv.2")
+    # LSTM_BF
+    e = F.layer_norm(x.permute(0, 3, 2, 1).contiguous(), (C,), m.get_parameter("bf_map.norm.weight"),
+                     m.get_parameter("bf_map.norm.bias"), 1e-5).view(B * Fq, T, C)
+    h = _lstm(m, _lstm(m, e, "rnn1"), "rnn2").view(B, Fq, T, -1).transpose(1, 2).contiguous()
+    h = F.relu(F.linear(h, m.get_parameter("bf_map.w_dnn.0.weight"), m.get_parameter("bf_map.w_dnn.0.bias")))
+    w = F.linear(h, m.get_parameter("bf_map.w_dnn.2.weight"), m.get_parameter("bf_map.w_dnn.2.bias")).view(B, T, Fq, M, 2)
+    wr, wi, xr, xi = w[..., 0], w[..., 1], inpt[..., 0], inpt[..., 1]
+    return torch.stack(((wr * xr - wi * xi).sum(-1), (wr * xi + wi * xr).sum(-1)), dim=1)

@@ -186,9 +186,11 @@ class EaBNet(nn.Module):
 
     Same constructor keywords and defaults, same ``forward`` signature:
     ``inpt`` (B, T, F, M, 2) [or (B, T, F, 2) for one microphone] ->
-    (B, 2, T, F), same state-dict keys.  Inference only in this round:
-    calling ``forward`` with autograd enabled on parameters that require grad
-    raises (SURVEY §8 row C4 "training" is not built yet).
+    (B, 2, T, F), same state-dict keys.  ``torch.no_grad()`` / ``requires_grad=False`` calls run
+    the hand-written HIP program (CUDA tensors only, no fallback).  A call that must be
+    differentiable (training: train.py / train_distributed.py) is evaluated by
+    eabnet_amd/autograd_path.py with PyTorch-ROCm operators so that backward, the optimiser and
+    DistributedDataParallel work; hand-written backward kernels are a later row.
     """
 
     def __init__(self, k1: tuple = (2, 3), k2: tuple = (1, 3), c: int = 64, M: int = 9, embed_dim: int = 64,
@@ -249,13 +251,13 @@ class EaBNet(nn.Module):
             inpt = inpt.unsqueeze(-2)
         if inpt.ndim != 5 or inpt.shape[-1] != 2 or inpt.shape[-2] != self.M:
             raise ValueError(f"expected (B,T,F,{self.M},2), got {tuple(inpt.shape)}")
-        if not inpt.is_cuda:
-            raise _lib.EabError("eabnet_amd.EaBNet runs on MI355X only: move the input (and module) to 'cuda'. "
-                                "There is no CPU fallback by design.")
         if torch.is_grad_enabled() and (inpt.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError(
-                "eabnet_amd.EaBNet is inference-only in this round (backward kernels: DESIGN.md, 'next'). "
-                "Wrap the call in torch.no_grad().")
+            # training: autograd needs a graph -> PyTorch-ROCm operator path (autograd_path.py)
+            from .autograd_path import forward_autograd
+            return forward_autograd(self, inpt)
+        if not inpt.is_cuda:
+            raise _lib.EabError("eabnet_amd.EaBNet inference runs on MI355X only: move the input (and module) to "
+                                "'cuda'. There is no CPU fallback by design.")
         _lib.load()
         B, T, F, M, _ = inpt.shape
         x = inpt.detach().to(torch.float32).contiguous()

@@ -59,6 +59,27 @@ def test_product_path_refuses_cpu_tensors():
         eabnet_amd.filter_and_sum(torch.zeros(1, 1, 1, 1, 2), torch.zeros(1, 1, 1, 1, 2))
 
 
+def test_training_forward_matches_oracle_on_cpu():
+    """The differentiable path (training) against the oracle; runs on CPU because it is plain PyTorch."""
+    import torch
+    import paramgen
+    import eabnet_amd
+    from eabnet_amd.spec import NetConfig, param_specs
+    from oracle import eabnet_oracle as orc
+    cfg = NetConfig(M=3, p=2, q=2)
+    P = {k: torch.from_numpy(v) for k, v in paramgen.make_params(param_specs(cfg), 160).items()}
+    net = eabnet_amd.EaBNet(M=3, p=2, q=2)
+    net.load_state_dict(P, strict=True)
+    x = torch.from_numpy(paramgen.make_spec_input(2, 9, 161, 3, 161))
+    y = net(x)                                           # grad enabled -> autograd path
+    assert y.requires_grad
+    with torch.no_grad():
+        ref = orc.eabnet_forward(P, x, p=2, q=2)
+    assert float((y.detach() - ref).abs().max() / ref.abs().max()) < 1e-5
+    y.square().mean().backward()
+    assert all(p.grad is not None for p in net.parameters())
+
+
 def test_state_dict_round_trip_with_reference_keys():
     import json
     import torch

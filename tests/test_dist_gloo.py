@@ -74,3 +74,50 @@ def test_two_rank_sharded_inference_matches_single_process():
         assert t == 2.0                  # MAX over ranks of (1 + rank)
         assert abs(loss - 0.5) < 1e-12   # SUM / world_size
     np.testing.assert_allclose(out, ref, rtol=0, atol=2e-6 * np.abs(ref).max())
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    torch.manual_seed(0)
+    import eabnet_amd
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    assert dist.init("gloo")
+    net = eabnet_amd.EaBNet(M=2, p=1, q=1)
+    ddp = DDP(net)                                     # reference: DDP(net, device_ids=[device]) train_distributed.py:198
+    opt = torch.optim.Adam(ddp.parameters(), lr=5e-4)
+    losses = []
+    for it in range(2):
+        x = torch.from_numpy(paramgen.make_spec_input(1, 5, 161, 2, 200 + 10 * it + rank))     # rank-specific shard
+        label = torch.from_numpy(paramgen.make_spec_input(1, 5, 161, 1, 300 + 10 * it + rank)[..., 0, :]).permute(0, 3, 1, 2)
+        opt.zero_grad()
+        out = ddp(x)
+        loss = eabnet_amd.com_mag_mse_loss(out, label, [5])
+        loss.backward()                                # gradient all-reduce happens here
+        torch.nn.utils.clip_grad_norm_(ddp.parameters(), 1.0)
+        opt.step()
+        losses.append(float(dist.mean_over_ranks(loss.detach())))
+    g = torch.cat([p.grad.flatten() for p in net.parameters()])
+    w = torch.cat([p.detach().flatten() for p in net.parameters()])
+    q.put((rank, losses, float(g.double().norm()), float(w.double().sum())))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_ddp_training_step():
+    """BASELINE config 4 on CPU ranks: DDP gradient all-reduce keeps the replicas identical."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=500) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, l0, g0, w0), (_, l1, g1, w1) = got
+    assert l0 == l1 and all(np.isfinite(l0))          # the averaged loss is the same number on both ranks
+    assert abs(g0 - g1) <= 1e-9 * max(g0, 1.0)        # all-reduced gradients are identical
+    assert abs(w0 - w1) <= 1e-9 * max(abs(w0), 1.0)   # so are the updated parameters

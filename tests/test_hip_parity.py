@@ -347,7 +347,25 @@ def test_weights_are_repacked_after_update(dev):
     assert not torch.allclose(y0, y1)
 
 
-def test_training_mode_is_refused_loudly(dev):
-    net = _model(2, 95, dev)
-    with pytest.raises(NotImplementedError):
-        net(torch.zeros(1, 4, 161, 2, 2, device=dev))
+def test_training_forward_matches_hip_inference_and_steps(dev):
+    """Differentiable forward (PyTorch-ROCm operators, autograd_path.py) == HIP inference forward within
+    the parity bar, and one optimiser step of the reference's loop (train_distributed.py:218-230) runs."""
+    import eabnet_amd
+    net = _model(4, 150, dev)
+    x = torch.from_numpy(paramgen.make_spec_input(2, 30, 161, 4, 151)).to(dev)
+    label = torch.from_numpy(paramgen.make_spec_input(2, 30, 161, 1, 152)[..., 0, :]).permute(0, 3, 1, 2).to(dev)
+    with torch.no_grad():
+        y_hip = net(x)
+    net.train()
+    y_tr = net(x)                                   # grad enabled, parameters require grad
+    assert y_tr.requires_grad
+    assert_close(y_tr.detach().cpu().numpy(), y_hip.cpu().numpy(), TOL_HIP)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+    loss = eabnet_amd.com_mag_mse_loss(y_tr, label, [30, 30])
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+    opt.step()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+    with torch.no_grad():                           # updated weights are re-packed for the HIP program
+        y2 = net.eval()(x)
+    assert not torch.equal(y2, y_hip) and torch.isfinite(y2).all()
