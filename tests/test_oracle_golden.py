@@ -119,3 +119,49 @@ def test_c1_full_size():
     assert abs(float(torch.linalg.vector_norm(ns.double())) - float(g["stft_l2"])) < 1e-6 * float(g["stft_l2"])
     assert abs(float(torch.linalg.vector_norm(ts.double())) - float(g["target_l2"])) < 1e-6 * float(g["target_l2"])
     assert_close(y.numpy(), g["out"], TOL_ORACLE)
+
+
+def _c_oracle():
+    import ctypes
+    import subprocess
+    root = os.path.dirname(GOLDEN.rstrip("/")).rsplit("/tests", 1)[0]
+    subprocess.run(["make", "-C", os.path.join(root, "oracle")], check=True, capture_output=True)
+    lib = ctypes.CDLL(os.path.join(root, "oracle", "build", "libfrontend_ref.so"))
+    lib.oracle_stft_compress.restype = ctypes.c_int
+    lib.oracle_stft_compress.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_long,
+                                                                 ctypes.c_int, ctypes.c_int]
+    lib.oracle_filter_sum.restype = None
+    lib.oracle_filter_sum.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_long, ctypes.c_int]
+    return lib
+
+
+@pytest.mark.parametrize("name", ["stft_B1_M2_L1600.npz", "stft_B1_M3_L2085.npz", "stft_zero_mic.npz"])
+def test_plain_c_front_end_vs_reference_fixtures(name):
+    """oracle/frontend_ref.c (O(N^2) double-precision DFT, no PyTorch) against the reference fixtures."""
+    lib = _c_oracle()
+    g = load(name)
+    B, T, F, M, _ = g["noisy"].shape
+    L = 1600 if "zero" in name else int(name.split("_L")[1].split(".")[0])
+    x = paramgen.make_wave(B, M, L, int(g["seed"]))
+    if "zero" in name:
+        x[:, 1] = 0.0
+    x = np.ascontiguousarray(x)
+    win = torch.hann_window(320).numpy().copy()
+    out = np.empty((B, T, F, M, 2), dtype=np.float32)
+    assert lib.oracle_stft_compress(x.ctypes.data, win.ctypes.data, out.ctypes.data, B, M, L, 320, 160) == 0
+    assert_compressed_close(out, g["noisy"], TOL_ORACLE)
+    if "zero" in name:
+        assert np.count_nonzero(out[..., 1, :]) == 0
+
+
+def test_plain_c_filter_sum_vs_oracle():
+    lib = _c_oracle()
+    rng = np.random.default_rng(3)
+    w = rng.standard_normal((2, 5, 161, 8, 2)).astype(np.float32)
+    x = rng.standard_normal((2, 5, 161, 8, 2)).astype(np.float32)
+    yr = np.empty(2 * 5 * 161, np.float32)
+    yi = np.empty_like(yr)
+    lib.oracle_filter_sum(w.ctypes.data, x.ctypes.data, yr.ctypes.data, yi.ctypes.data, yr.size, 8)
+    ref = orc.filter_and_sum(torch.from_numpy(w), torch.from_numpy(x)).numpy()
+    assert_close(yr.reshape(2, 5, 161), ref[:, 0], 1e-6)
+    assert_close(yi.reshape(2, 5, 161), ref[:, 1], 1e-6)
