@@ -278,6 +278,38 @@ def main():
                     "duration (HIP events per op on the launch stream, instrumented replay after the timed region); "
                     "peak = fp32 MFMA dense (MI355X_MICROARCH.md); traffic: see profiles/ (PMC passes are separate runs)",
         }
+    if rank == 0 and not a.no_roofline:
+        # HBM-side kernels of the path (SURVEY §8d asks for both fractions): algorithmic bytes / time
+        def timed(fn, reps=10):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps * 1e-3
+        with torch.no_grad():
+            t_stft = timed(lambda: eabnet_amd.stft_compress(wav, N_FFT, HOP, window))
+            wts = torch.randn_like(ns)
+            t_fs = timed(lambda: eabnet_amd.filter_and_sum(wts, ns))
+        fr = B_PER_GPU * T
+        by_stft = fr * (160 * MICS * 4 + 161 * MICS * 2 * 4)
+        by_fs = fr * 161 * (4 * MICS + 2) * 4
+        by_na = fr * 3 * 64 * 4 * sum(o.P for o in ops if o.kind == prg.OP_NORM_ACT and o.b is not None) / T \
+            + fr * 2 * 64 * 4 * sum(o.P for o in ops if o.kind == prg.OP_NORM_ACT and o.b is None) / T
+        t_na = 1e-3 * sum(float(ms[k]) for k, o in enumerate(ops) if o.kind == prg.OP_NORM_ACT)
+        out["hbm_kernels"] = {
+            "peak_GBs": PEAK_HBM_GBS,
+            "stft_compress": {"us": 1e6 * t_stft, "achieved_GBs": by_stft / t_stft / 1e9, "frac": by_stft / t_stft / 1e9 / PEAK_HBM_GBS,
+                              "bytes_per_frame": 160 * MICS * 4 + 161 * MICS * 2 * 4},
+            "filter_sum": {"us": 1e6 * t_fs, "achieved_GBs": by_fs / t_fs / 1e9, "frac": by_fs / t_fs / 1e9 / PEAK_HBM_GBS,
+                           "bytes_per_frame": 161 * (4 * MICS + 2) * 4},
+            "norm_act(all 10 launches)": {"us": 1e6 * t_na, "achieved_GBs": by_na / t_na / 1e9, "frac": by_na / t_na / 1e9 / PEAK_HBM_GBS},
+        }
+
     if rank == 0 and not a.no_c1:
         # BASELINE configs[0] shape on the GPU: ONE 4-s 8-mic utterance, wave -> output, latency and RTF
         wav1 = wav[:1].contiguous()

@@ -296,6 +296,41 @@ def test_shortest_utterances(dev, L):
     assert e_hip <= max(TOL_HIP, 3.0 * e_ref), f"T={1 + L // 160}: HIP {e_hip:.2e} vs fp32 reference arithmetic {e_ref:.2e}"
 
 
+def test_long_utterance_12_seconds(dev):
+    """T = 1201 frames: many tiles per utterance, large per-utterance tensors (offset arithmetic)."""
+    import eabnet_amd
+    from oracle import eabnet_oracle as orc
+    P = torch_params(4, 170)
+    net = _model(4, 170, dev)
+    wav = torch.from_numpy(paramgen.make_wave(1, 4, 192000, 171))
+    with torch.no_grad():
+        ns = eabnet_amd.stft_compress(wav.to(dev), 320, 160, torch.hann_window(320))
+        y = net(ns).cpu()
+        ns_ref, _ = orc.prepare_data_oracle(wav, None)
+        ref = orc.eabnet_forward(P, ns_ref, fast_lstm=True)
+    assert y.shape == (1, 2, 1201, 161)
+    assert_close(y.numpy(), ref.numpy(), TOL_HIP)
+
+
+def test_input_forms_odd_batch_noncontiguous_float64(dev):
+    """forward accepts what the reference accepts: any batch size, non-contiguous views, other float
+    dtypes (converted to fp32 for the HIP program, result cast back)."""
+    from oracle import eabnet_oracle as orc
+    P = torch_params(2, 180)
+    net = _model(2, 180, dev)
+    x = torch.from_numpy(paramgen.make_spec_input(3, 17, 161, 2, 181))
+    with torch.no_grad():
+        ref = orc.eabnet_forward(P, x)
+        y = net(x.to(dev))
+        big = torch.zeros(3, 17, 161, 2, 4)
+        big[..., ::2] = x
+        y_nc = net(big.to(dev)[..., ::2])                       # strided view
+        y64 = net(x.double().to(dev))
+    assert_close(y.cpu().numpy(), ref.numpy(), TOL_HIP)
+    assert torch.equal(y_nc, y)
+    assert y64.dtype == torch.float64 and torch.equal(y64.float(), y)
+
+
 def test_too_short_wave_is_rejected(dev):
     import eabnet_amd
     from eabnet_amd import _lib
