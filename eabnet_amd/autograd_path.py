@@ -18,10 +18,20 @@ import torch
 import torch.nn.functional as F
 
 
+def _norm(m, x, norm: str):
+    """NormSwitch (EaBNet.py:662-694).  BatchNorm follows nn.BatchNorm*d: batch statistics and a
+    momentum-0.1 update of the running buffers in training mode, running statistics in eval mode."""
+    w, b = m.get_parameter(f"{norm}.norm.weight"), m.get_parameter(f"{norm}.norm.bias")
+    if m.norm_type == "BN":
+        if m.training:
+            m.get_buffer(f"{norm}.norm.num_batches_tracked").add_(1)
+        return F.batch_norm(x, m.get_buffer(f"{norm}.norm.running_mean"), m.get_buffer(f"{norm}.norm.running_var"),
+                            w, b, training=m.training, momentum=0.1, eps=1e-5)
+    return F.instance_norm(x, weight=w, bias=b, use_input_stats=True, eps=1e-5)
+
+
 def _norm_act(m, x, norm: str, act: str):
-    x = F.instance_norm(x, weight=m.get_parameter(f"{norm}.norm.weight"), bias=m.get_parameter(f"{norm}.norm.bias"),
-                        use_input_stats=True, eps=1e-5)
-    return F.prelu(x, m.get_parameter(f"{act}.weight"))
+    return F.prelu(_norm(m, x, norm), m.get_parameter(f"{act}.weight"))
 
 
 def _glu(y):
@@ -53,26 +63,23 @@ def _unet(m, x, pre: str, scale: int, transposed: bool):
     for j in range(scale):
         q = f"{pre}.deco.{j}.deconv"
         if j:
-            y = torch.cat((y, downs[-(j + 1)]), dim=1)
+            y = y + downs[-(j + 1)] if m.intra_connect == "add" else torch.cat((y, downs[-(j + 1)]), dim=1)
         y = _norm_act(m, F.conv_transpose2d(y, m.get_parameter(f"{q}.0.weight"), m.get_parameter(f"{q}.0.bias"),
                                             stride=(1, 2)), f"{q}.1", f"{q}.2")
     return resi + y
 
 
 def _tcm(m, x, pre: str, dilation: int):
-    kd = m.kd1
+    span = (m.kd1 - 1) * dilation
+    pad = (span, 0) if m.is_causal else (span // 2, span // 2)          # EaBNet.py:550-553
     y = F.conv1d(x, m.get_parameter(f"{pre}.in_conv.weight"))
 
     def branch(side):
-        z = F.prelu(y, m.get_parameter(f"{pre}.{side}.0.weight"))
-        z = F.instance_norm(z, weight=m.get_parameter(f"{pre}.{side}.1.norm.weight"),
-                            bias=m.get_parameter(f"{pre}.{side}.1.norm.bias"), use_input_stats=True, eps=1e-5)
-        return F.conv1d(F.pad(z, ((kd - 1) * dilation, 0)), m.get_parameter(f"{pre}.{side}.3.weight"), dilation=dilation)
+        z = _norm(m, F.prelu(y, m.get_parameter(f"{pre}.{side}.0.weight")), f"{pre}.{side}.1")
+        return F.conv1d(F.pad(z, pad), m.get_parameter(f"{pre}.{side}.3.weight"), dilation=dilation)
 
     z = branch("left_conv") * torch.sigmoid(branch("right_conv"))
-    z = F.prelu(z, m.get_parameter(f"{pre}.out_conv.0.weight"))
-    z = F.instance_norm(z, weight=m.get_parameter(f"{pre}.out_conv.1.norm.weight"),
-                        bias=m.get_parameter(f"{pre}.out_conv.1.norm.bias"), use_input_stats=True, eps=1e-5)
+    z = _norm(m, F.prelu(z, m.get_parameter(f"{pre}.out_conv.0.weight")), f"{pre}.out_conv.1")
     return F.conv1d(z, m.get_parameter(f"{pre}.out_conv.2.weight")) + x
 
 
@@ -85,17 +92,25 @@ def _lstm(m, x, name: str):
 
 
 def forward_autograd(m, inpt: torch.Tensor) -> torch.Tensor:
-    """(B,T,F,M,2) -> (B,2,T,F), differentiable w.r.t. the module's parameters and the input."""
+    """(B,T,F,M,2) -> (B,2,T,F) [(B,2,T) for topo_type="miso"], differentiable w.r.t. the module's
+    parameters and the input."""
     if inpt.ndim == 4:
         inpt = inpt.unsqueeze(-2)
     B, T, Fq, M, _ = inpt.shape
     x = inpt.transpose(-2, -1).contiguous().view(B, T, Fq, 2 * M).permute(0, 3, 1, 2)     # channel = ri*M + m
     skips = []
-    for i in range(4):
-        x = _unet(m, x, f"en.meta_unet_list.{i}", 4 - i, False)
+    if m.is_u2:
+        for i in range(4):
+            x = _unet(m, x, f"en.meta_unet_list.{i}", 4 - i, False)
+            skips.append(x)
+        x = _norm_act(m, _gate_conv(m, x, "en.last_conv.0.conv.1"), "en.last_conv.1", "en.last_conv.2")
         skips.append(x)
-    x = _norm_act(m, _gate_conv(m, x, "en.last_conv.0.conv.1"), "en.last_conv.1", "en.last_conv.2")
-    skips.append(x)
+    else:                                                 # UNet_Encoder, EaBNet.py:234-239
+        for i in range(5):
+            q = f"en.unet_list.{i}"
+            x = _gate_conv(m, x, f"{q}.0.conv.1")
+            x = F.prelu(x, m.get_parameter(f"{q}.1.weight")) if i in (1, 2) else _norm_act(m, x, f"{q}.1", f"{q}.2")
+            skips.append(x)
     C = x.shape[1]
     x = x.transpose(-2, -1).contiguous().view(B, -1, T)
     acc = torch.zeros_like(x)
@@ -104,10 +119,24 @@ def forward_autograd(m, inpt: torch.Tensor) -> torch.Tensor:
             x = _tcm(m, x, f"stcns.{g}.tcm_list.{i}", 2 ** i)
         acc = acc + x
     x = acc.view(B, C, -1, T).transpose(-2, -1).contiguous()
-    for i in range(4):
-        x = _unet(m, torch.cat((x, skips[-(i + 1)]), dim=1), f"de.meta_unet_list.{i}", i + 1, True)
-    x = _norm_act(m, _gate_deconv(m, torch.cat((x, skips[0]), dim=1), "de.last_conv.0.conv.0"),
-                  "de.last_conv.1", "de.last_conv.2")
+    if m.is_u2:
+        for i in range(4):
+            x = _unet(m, torch.cat((x, skips[-(i + 1)]), dim=1), f"de.meta_unet_list.{i}", i + 1, True)
+        x = _norm_act(m, _gate_deconv(m, torch.cat((x, skips[0]), dim=1), "de.last_conv.0.conv.0"),
+                      "de.last_conv.1", "de.last_conv.2")
+    else:                                                 # UNet_Decoder, EaBNet.py:324-328
+        for i in range(5):
+            q = f"de.unet_list.{i}"
+            x = _norm_act(m, _gate_deconv(m, torch.cat((x, skips[-(i + 1)]), dim=1), f"{q}.0.conv.0"), f"{q}.1", f"{q}.2")
+    if m.topo_type == "miso":                             # EaBNet.py:118-125 (sum over frequency, as written there)
+        k = F.conv2d(x, m.get_parameter("bf_map.weight"), m.get_parameter("bf_map.bias")).permute(0, 2, 3, 1)
+        kr, ki, xr, xi = k[..., 0], k[..., -1], inpt[..., 0, 0], inpt[..., 0, -1]
+        return torch.stack(((kr * xr - ki * xi).sum(-1), (kr * xi + ki * xr).sum(-1)), dim=1)
+    if m.bf_type == "cnn":                                # EaBNet.py:111-113
+        w = F.conv2d(x, m.get_parameter("bf_map.weight"), m.get_parameter("bf_map.bias"))
+        w = w.view(B, M, -1, T, Fq).permute(0, 3, 4, 1, 2)
+        wr, wi, xr, xi = w[..., 0], w[..., 1], inpt[..., 0], inpt[..., 1]
+        return torch.stack(((wr * xr - wi * xi).sum(-1), (wr * xi + wi * xr).sum(-1)), dim=1)
     # LSTM_BF
     e = F.layer_norm(x.permute(0, 3, 2, 1).contiguous(), (C,), m.get_parameter("bf_map.norm.weight"),
                      m.get_parameter("bf_map.norm.bias"), 1e-5).view(B * Fq, T, C)

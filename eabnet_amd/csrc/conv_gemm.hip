@@ -260,7 +260,7 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
             const int pidx = srow + 64 * pp;
             const int tr = cg_div(pidx, Fp, inv_fp);
             const int t_in = t_first + dt_min + tr, fi = pidx - tr * Fp - halo_lo;
-            p_ok[pp] = pidx < P && t_in >= 0 && fi >= 0 && fi < d.Fin;
+            p_ok[pp] = pidx < P && t_in >= 0 && t_in < d.T && fi >= 0 && fi < d.Fin;
             p_tf[pp] = t_in * d.Fin + fi;
         }
         int fa[MI];                                                  // float index of this lane's fragment for a zero tap shift
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
 #pragma unroll
             for (int p = 0; p < MI; ++p) {
                 const int tt = a_t[p] + dt, fi = a_f0[p] + io;
-                const bool ok = a_ok[p] && cok && tt >= 0 && fi >= 0 && fi < d.Fin;
+                const bool ok = a_ok[p] && cok && tt >= 0 && tt < d.T && fi >= 0 && fi < d.Fin;
                 rg.st_ok[ku][p] = ok;
                 const unsigned off = ok ? (unsigned)(((a_tf[p] + dt * d.Fin + io) * Cs + c) * 4) : CG_OOB;
                 if (VEC) {
@@ -849,7 +849,12 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
     EAB_CHECK_ARG((d->No - 1) * d->ostride + d->ophase < d->Fout);
     const int upt = (d->C0 + d->C1 + 15) / 16;
     EAB_CHECK_ARG(d->Kpad == d->ntaps * upt * 16);
-    for (int j = 0; j < d->ntaps; ++j) EAB_CHECK_ARG(d->dt[j] <= 0 && d->dt[j] > -(1 << 20));
+    // taps may look ahead in time (non-causal S-TCMs): rows past the utterance read as zero through
+    // the per-utterance buffer bound; the patch pipeline is laid out for causal taps only
+    for (int j = 0; j < d->ntaps; ++j) {
+        EAB_CHECK_ARG(d->dt[j] < (1 << 20) && d->dt[j] > -(1 << 20));
+        EAB_CHECK_ARG(d->dt[j] <= 0 || d->korder == EAB_KORDER_TAP);
+    }
     EAB_CHECK_ARG(d->epi >= EAB_EPI_LINEAR && d->epi <= EAB_EPI_DUALGATE);
     EAB_CHECK_ARG(d->precision == EAB_PREC_F32 || d->precision == EAB_PREC_F16X3);
     EAB_CHECK_ARG(d->korder == EAB_KORDER_TAP || d->korder == EAB_KORDER_CHUNK);
@@ -907,8 +912,11 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
         return cg_pick_ku<1, 2, CG_DUAL, EAB_XF_PRELU_NORM, true>(d, s, ku == 2 ? 1 : ku);
     }
     if (glu) {
-        if (d->N != 128 || xf != EAB_XF_NONE) return EAB_EUNSUPPORTED;
+        if (d->N != 128 || xf == EAB_XF_PRELU_NORM) return EAB_EUNSUPPORTED;
         if (!vec) return mi == 2 ? cg_pick_ku<2, 2, CG_GLU, 0, false>(d, s, 1) : cg_pick_ku<1, 2, CG_GLU, 0, false>(d, s, 1);
+        if (xf == EAB_XF_NORM_PRELU)    // gated conv on raw producers (plain U-Net, is_u2 = False)
+            return mi == 2 ? cg_pick_ku<2, 2, CG_GLU, EAB_XF_NORM_PRELU, true>(d, s, ku)
+                           : cg_pick_ku<1, 2, CG_GLU, EAB_XF_NORM_PRELU, true>(d, s, ku);
         return mi == 2 ? cg_pick_ku<2, 2, CG_GLU, 0, true>(d, s, ku) : cg_pick_ku<1, 2, CG_GLU, 0, true>(d, s, ku);
     }
     if (!vec) return EAB_EUNSUPPORTED;          // only the first (gated) conv can see 2M % 4 != 0 channels

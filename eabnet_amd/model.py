@@ -45,10 +45,17 @@ def _default_init(spec: ParamSpec) -> torch.Tensor:
         return t.zero_()
     if k == "prelu":
         return t.fill_(0.25)
+    if k == "bn_mean":
+        return t.zero_()
+    if k == "bn_var":
+        return t.fill_(1.0)
+    if k == "bn_count":
+        return torch.zeros((), dtype=torch.long)
     raise ValueError(k)
 
 
-def _attach(root: nn.Module, dotted: str, p: nn.Parameter) -> None:
+def _attach(root: nn.Module, dotted: str, p: torch.Tensor) -> None:
+    """Register a parameter (nn.Parameter) or a buffer (plain tensor: BatchNorm statistics)."""
     node = root
     parts = dotted.split(".")
     for name in parts[:-1]:
@@ -57,7 +64,10 @@ def _attach(root: nn.Module, dotted: str, p: nn.Parameter) -> None:
             child = _Scope()
             node.add_module(name, child)
         node = child
-    node.register_parameter(parts[-1], p)
+    if isinstance(p, nn.Parameter):
+        node.register_parameter(parts[-1], p)
+    else:
+        node.register_buffer(parts[-1], p)
 
 
 # ----------------------------------------------------------------------------
@@ -207,7 +217,8 @@ class EaBNet(nn.Module):
                              topo_type=topo_type, intra_connect=intra_connect, norm_type=norm_type)
         self._specs = param_specs(self.cfg)          # raises NotImplementedError for unsupported topologies
         for key, spec in self._specs.items():
-            _attach(self, key, nn.Parameter(_default_init(spec)))
+            t = _default_init(spec)
+            _attach(self, key, t if spec.is_buffer else nn.Parameter(t))
         self._bound: Dict[tuple, _Bound] = {}
         self._packed_version: Dict[tuple, tuple] = {}
         self.dump_bfw = False                         # tests: also emit the (B,T,F,M,2) beam-forming weights
@@ -220,11 +231,12 @@ class EaBNet(nn.Module):
 
     # -- program cache -----------------------------------------------------------
     def _param_fingerprint(self) -> tuple:
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
     def _numpy_params(self) -> Dict[str, np.ndarray]:
         sd = self.state_dict()
-        return {k: sd[k].detach().to("cpu", torch.float32).numpy() for k in self._specs}
+        return {k: sd[k].detach().to("cpu", torch.float32).numpy() for k, s in self._specs.items()
+                if s.kind != "bn_count"}
 
     def _program(self, B: int, T: int, F: int, device: torch.device) -> _Bound:
         key = (B, T, F, str(device), self.precision)
@@ -251,8 +263,10 @@ class EaBNet(nn.Module):
             inpt = inpt.unsqueeze(-2)
         if inpt.ndim != 5 or inpt.shape[-1] != 2 or inpt.shape[-2] != self.M:
             raise ValueError(f"expected (B,T,F,{self.M},2), got {tuple(inpt.shape)}")
-        if torch.is_grad_enabled() and (inpt.requires_grad or any(p.requires_grad for p in self.parameters())):
-            # training: autograd needs a graph -> PyTorch-ROCm operator path (autograd_path.py)
+        needs_graph = torch.is_grad_enabled() and (inpt.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if needs_graph or (self.norm_type == "BN" and self.training):
+            # training: autograd needs a graph (or BatchNorm must see and update batch statistics)
+            # -> PyTorch-ROCm operator path (autograd_path.py)
             from .autograd_path import forward_autograd
             return forward_autograd(self, inpt)
         if not inpt.is_cuda:
@@ -273,6 +287,10 @@ class EaBNet(nn.Module):
                 bound.bind(x.data_ptr(), out.data_ptr())
                 bound.run(torch.cuda.current_stream().cuda_stream)
         self._last = (bound, x)                       # keep the input alive until the stream has consumed it
+        if self.topo_type == "miso":
+            # the reference reduces the masked reference-mic spectrum over frequency (EaBNet.py:122-123:
+            # ``.sum(dim=-1)`` on a (B,T,F) tensor) and returns (B,2,T); kept as is
+            out = out.sum(dim=-1)
         return out.to(inpt.dtype)
 
 

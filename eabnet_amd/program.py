@@ -26,7 +26,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .spec import NetConfig, param_specs
+from .spec import NetConfig, param_specs, unet_decoder_layers, unet_encoder_layers
 
 # mirrors of the C enums (include/eabnet_hip.h)
 XF_NONE, XF_NORM_PRELU, XF_PRELU_NORM = 0, 1, 2
@@ -293,6 +293,7 @@ class Lowering:
         self.precision = precision
         self.patch = os.environ.get("EAB_PATCH", "1") != "0"      # tuning knob: 0 = gather pipeline everywhere
         specs = param_specs(cfg)
+        specs = {k: v for k, v in specs.items() if v.kind != "bn_count"}     # the step counter is not arithmetic
         missing = [k for k in specs if k not in params]
         if missing:
             raise KeyError(f"missing parameters: {missing[:4]} ...")
@@ -306,6 +307,8 @@ class Lowering:
         self.taps: Dict[str, Act] = {}
         self.flops = 0
         self.dump_bfw = dump_bfw
+        self.bn = cfg.norm_type == "BN"
+        self.add = cfg.intra_connect == "add"
 
     # -- arenas ---------------------------------------------------------------
     def alloc(self, nfloats: int) -> Ref:
@@ -319,6 +322,28 @@ class Lowering:
     def vec(self, key: str) -> Ref:
         return self.W.add(key, self.P[key])
 
+    def static_xf(self, name: str, scale: np.ndarray, shift: np.ndarray) -> Ref:
+        """(scale, shift) table that does not depend on the data, laid out like the output of
+        eab_in_finalize_f32 ([B][C][2]) so every consumer reads it the same way."""
+        tab = np.stack([scale, shift], axis=-1).astype(np.float32)            # (C, 2)
+        return self.W.add(f"{name}#xf", np.broadcast_to(tab, (self.B,) + tab.shape))
+
+    def bn_xf(self, norm: str) -> Ref:
+        """BatchNorm in eval mode (NormSwitch BN branch, EaBNet.py:677-681) is a per-channel affine
+        map of the running statistics: scale = g / sqrt(var + eps), shift = b - mean * scale."""
+        g, b = self.P[f"{norm}.norm.weight"].astype(np.float64), self.P[f"{norm}.norm.bias"].astype(np.float64)
+        mu = self.P[f"{norm}.norm.running_mean"].astype(np.float64)
+        var = self.P[f"{norm}.norm.running_var"].astype(np.float64)
+        scale = g / np.sqrt(var + EPS_IN)
+        return self.static_xf(norm, scale, b - mu * scale)
+
+    def fixed_norm(self, norm: Optional[str], C: int) -> Optional[Ref]:
+        """Table of a norm that needs no statistics pass (BatchNorm eval; no norm at all = identity),
+        None for InstanceNorm."""
+        if norm is None:
+            return self.static_xf(f"identity{C}", np.ones(C), np.zeros(C))
+        return self.bn_xf(norm) if self.bn else None
+
     # -- generic conv emission -----------------------------------------------------
     def pick_bm(self, No: int) -> int:
         import os
@@ -330,10 +355,11 @@ class Lowering:
                   Fout: int, No: int, ostride: int, ophase: int, istride: int, dt, ioff, epi: int,
                   dst: Ref, stats: Optional[Ref] = None, nsets: int = 0, stat_slopes=(None, None),
                   stat_tiles: int = 0, stat_tile0: int = 0, bm: Optional[int] = None, aux: Optional[Ref] = None,
-                  dst_acc: Optional[Ref] = None, fin: Optional[dict] = None, slope1: Optional[Ref] = None) -> ConvOp:
+                  dst_acc: Optional[Ref] = None, fin: Optional[dict] = None, slope1: Optional[Ref] = None,
+                  xf1: Optional[Ref] = None, patch_ok: bool = True) -> ConvOp:
         """fin = dict(stats, tiles, nsets, count, norms=[...]) asks the kernel to reduce the
         producer's InstanceNorm partials itself (single source, transform order from srcs[0].mode);
-        slope1 = second PReLU slope of the SAME source for EPI_DUALGATE."""
+        slope1 (+ xf1 when the table is static) = second transform of the SAME source for EPI_DUALGATE."""
         assert 1 <= len(srcs) <= 2 and len(dt) == len(ioff) <= MAX_TAPS
         s0 = srcs[0]
         s1 = srcs[1] if len(srcs) == 2 else None
@@ -351,7 +377,7 @@ class Lowering:
         korder = KORDER_TAP
         patch_min_n = int(os.environ.get("EAB_PATCH_MIN_N", "128"))      # tuning knob
         if (self.patch and N >= patch_min_n and len(dt) >= 2 and s0.F > 1 and epi != EPI_DUALGATE and mode != XF_PRELU_NORM
-                and C0 % 4 == 0 and C1 % 4 == 0 and stats is not None):
+                and C0 % 4 == 0 and C1 % 4 == 0 and patch_ok):
             for cand in ((bm,) if bm == 64 else (128, 64)):
                 if patch_positions(cand, No, s0.F, istride, dt, ioff) <= PATCH_MAX:
                     korder, bm_p = KORDER_CHUNK, cand
@@ -379,7 +405,7 @@ class Lowering:
                          fin_eps=EPS_IN, fin_gamma0=g[0], fin_beta0=b[0],
                          fin_gamma1=g[1] if len(g) > 1 else None, fin_beta1=b[1] if len(b) > 1 else None)
         sl1 = slope1 if slope1 is not None else (s1.slope if s1 else None)
-        op = ConvOp(src0=s0.ref, src1=s1.ref if s1 else None, xf0=s0.xf, xf1=s1.xf if s1 else None,
+        op = ConvOp(src0=s0.ref, src1=s1.ref if s1 else None, xf0=s0.xf, xf1=s1.xf if s1 else xf1,
                     slope0=s0.slope, slope1=sl1, C0=C0, C1=C1, xf_mode=mode, w=w, bias=bias,
                     N=N, Kpad=Kpad, B=self.B, T=self.T, Fin=s0.F, Fout=Fout, No=No, ostride=ostride, ophase=ophase,
                     istride=istride, dt=list(dt), ioff=list(ioff), epi=epi, aux=aux, dst=dst, dst_acc=dst_acc,
@@ -401,10 +427,10 @@ class Lowering:
         return xfs
 
     # -- 2-D units -------------------------------------------------------------------
-    def conv2d_fwd(self, name: str, srcs: Sequence[Act], wkey: str, glu: bool, norm: str, act: str,
+    def conv2d_fwd(self, name: str, srcs: Sequence[Act], wkey: str, glu: bool, norm: Optional[str], act: str,
                    in_perm: Optional[np.ndarray] = None) -> Act:
         """Strided causal Conv2d [(kt,kf), stride (1,2)] (+GLU) -> raw output with
-        InstanceNorm+PReLU pending.  Reference GateConv2d EaBNet.py:434-460 /
+        norm+PReLU pending (norm=None: PReLU only).  Reference GateConv2d EaBNet.py:434-460 /
         Conv2dunit :391-407."""
         w = self.P[f"{wkey}.weight"]                       # (N, Cin, kt, kf)
         N, Cin, kt, kf = w.shape
@@ -421,20 +447,28 @@ class Lowering:
         dst = self.alloc_act(Fout, Cout)
         bm = self.pick_bm(Fout)
         tiles = conv_tiles(self.T, Fout, bm)
-        stats = self.alloc(self.B * tiles * Cout * 4)
+        xf = self.fixed_norm(norm, Cout)
+        stats = self.alloc(self.B * tiles * Cout * 4) if xf is None else None
         self.emit_conv(name, srcs, wref, bref, N, wp.shape[1], Fout, Fout, 1, 0, 2,
                        [a - (kt - 1) for a, _ in taps], [c for _, c in taps],
-                       EPI_GLU if glu else EPI_LINEAR, dst, stats, 1, (None, None), tiles, 0, bm)
-        xf, = self.emit_finalize(name + ".in", stats, Cout, 1, tiles, self.T * Fout, [norm])
+                       EPI_GLU if glu else EPI_LINEAR, dst, stats, 1 if stats else 0, (None, None),
+                       tiles if stats else 0, 0, bm)
+        if xf is None:
+            xf, = self.emit_finalize(name + ".in", stats, Cout, 1, tiles, self.T * Fout, [norm])
         return Act(dst, Fout, Cout, xf, self.vec(f"{act}.weight"), XF_NORM_PRELU)
 
-    def conv2d_transposed(self, name: str, srcs: Sequence[Act], wkey: str, glu: bool, norm: str, act: str) -> Act:
+    def conv2d_transposed(self, name: str, srcs: Sequence[Act], wkey: str, glu: bool, norm: str, act: str,
+                          summed: bool = False) -> Act:
         """ConvTranspose2d [(kt,kf), stride (1,2)] + drop of the last kt-1 rows
         (+GLU) as two gather-form launches, one per output-column parity:
           out[t][2o+ph] = sum_{kt} sum_{kf = ph, ph+2, ..} W[kt][kf] . in[t-kt][o-(kf-ph)/2]
         Reference GateConvTranspose2d EaBNet.py:463-490 + Chomp_T :617-624 /
         Deconv2dunit :410-431."""
         w = self.P[f"{wkey}.weight"]                       # (Cin, N, kt, kf)
+        if summed:
+            # Skip_connect 'add' (EaBNet.py:499-500): W.(f(a) + g(b)) = [W | W].cat(f(a), g(b)) -- the two
+            # sources keep their own pending transforms and the sum is never materialised
+            w = np.concatenate([w] * len(srcs), axis=0)
         Cin, N, kt, kf = w.shape
         assert Cin == sum(s.C for s in srcs)
         Fin = srcs[0].F
@@ -447,16 +481,18 @@ class Lowering:
         No = [(Fout + 1) // 2, Fout // 2]
         bm = self.pick_bm(No[0])
         tiles = [conv_tiles(self.T, n, bm) for n in No]
-        stats = self.alloc(self.B * sum(tiles) * Cout * 4)
+        xf = self.fixed_norm(norm, Cout)
+        stats = self.alloc(self.B * sum(tiles) * Cout * 4) if xf is None else None
         for ph in (0, 1):
             taps = [(a, c) for a in range(kt) for c in range(ph, kf, 2)]
             wp = pack_taps(wn, [a * kf + c for a, c in taps])
             wref = self.W.add(f"{wkey}.weight#packed.ph{ph}", wp)
             self.emit_conv(f"{name}.ph{ph}", srcs, wref, bref, N, wp.shape[1], Fout, No[ph], 2, ph, 1,
                            [-a for a, _ in taps], [-(c - ph) // 2 for _, c in taps],
-                           EPI_GLU if glu else EPI_LINEAR, dst, stats, 1, (None, None), sum(tiles),
-                           0 if ph == 0 else tiles[0], bm)
-        xf, = self.emit_finalize(name + ".in", stats, Cout, 1, sum(tiles), self.T * Fout, [norm])
+                           EPI_GLU if glu else EPI_LINEAR, dst, stats, 1 if stats else 0, (None, None),
+                           sum(tiles) if stats else 0, (0 if ph == 0 else tiles[0]) if stats else 0, bm)
+        if xf is None:
+            xf, = self.emit_finalize(name + ".in", stats, Cout, 1, sum(tiles), self.T * Fout, [norm])
         return Act(dst, Fout, Cout, xf, self.vec(f"{act}.weight"), XF_NORM_PRELU)
 
     def materialise(self, name: str, a: Act, b: Optional[Act] = None) -> Act:
@@ -489,7 +525,7 @@ class Lowering:
         for j in range(scale):
             q = f"{pre}.deco.{j}.deconv"
             ins = [y] if j == 0 else [y, downs[-(j + 1)]]
-            y = self.conv2d_transposed(q, ins, f"{q}.0", False, f"{q}.1", f"{q}.2")
+            y = self.conv2d_transposed(q, ins, f"{q}.0", False, f"{q}.1", f"{q}.2", summed=self.add and j > 0)
         return self.materialise(pre, g, y)
 
     # -- squeezed TCM --------------------------------------------------------------------
@@ -502,33 +538,38 @@ class Lowering:
         D, cd, kd = cfg.d_feat, cfg.cd1, cfg.kd1
         bm = 64
         tiles = conv_tiles(T, 1, bm)
-        assert tiles <= 64, "in-kernel finalisation is sized for <= 64 partial tiles per utterance"
+        bn = self.bn                                   # BatchNorm eval: static tables, no statistics at all
+        assert bn or tiles <= 64, "in-kernel finalisation is sized for <= 64 partial tiles per utterance"
+        nL, nR, nO = f"{pre}.left_conv.1", f"{pre}.right_conv.1", f"{pre}.out_conv.1"
         # in_conv 1x1 (no bias); statistics of BOTH branch PReLUs of its output
         w_in = self.P[f"{pre}.in_conv.weight"][:, perm, :]               # (cd, D, 1)
         wref = self.W.add(f"{pre}.in_conv.weight#packed", pack_taps(w_in, [0]))
         y = self.alloc_act(1, cd)
-        st = self.alloc(B * tiles * 2 * cd * 4)
+        st = None if bn else self.alloc(B * tiles * 2 * cd * 4)
         slL, slR = self.vec(f"{pre}.left_conv.0.weight"), self.vec(f"{pre}.right_conv.0.weight")
         self.emit_conv(f"{pre}.in_conv", [x], wref, None, cd, D, 1, 1, 1, 0, 1, [0], [0], EPI_LINEAR, y,
-                       st, 2, (slL, slR), tiles, 0, bm)
+                       st, 0 if bn else 2, (None, None) if bn else (slL, slR), 0 if bn else tiles, 0, bm)
         # z = left(y) * sigmoid(right(y)): columns [0,cd) see PReLU_L/IN_L(y), columns [cd,2cd) PReLU_R/IN_R(y)
-        dts = [-(kd - 1 - j) * dilation for j in range(kd)]
+        # taps (EaBNet.py:550-553): all in the past when causal, centred otherwise
+        span = (kd - 1) * dilation
+        lead = span if cfg.is_causal else span // 2
+        dts = [j * dilation - lead for j in range(kd)]
         wlr = np.concatenate([self.P[f"{pre}.left_conv.3.weight"], self.P[f"{pre}.right_conv.3.weight"]], axis=0)
         wd = self.W.add(f"{pre}.lr_conv.weight#packed", pack_taps(wlr[glu_row_order(2 * cd)], range(kd)))
         z = self.alloc_act(1, cd)
-        st2 = self.alloc(B * tiles * cd * 4)
+        st2 = None if bn else self.alloc(B * tiles * cd * 4)
         slO = self.vec(f"{pre}.out_conv.0.weight")
-        self.emit_conv(f"{pre}.lr_conv", [Act(y, 1, cd, None, slL, XF_PRELU_NORM)], wd, None, 2 * cd,
-                       kd * ((cd + 15) // 16) * 16, 1, 1, 1, 0, 1, dts, [0] * kd, EPI_DUALGATE, z, st2, 1, (slO, None),
-                       tiles, 0, bm, slope1=slR,
-                       fin=dict(stats=st, tiles=tiles, nsets=2, count=T,
-                                norms=[f"{pre}.left_conv.1", f"{pre}.right_conv.1"]))
+        self.emit_conv(f"{pre}.lr_conv", [Act(y, 1, cd, self.bn_xf(nL) if bn else None, slL, XF_PRELU_NORM)], wd, None,
+                       2 * cd, kd * ((cd + 15) // 16) * 16, 1, 1, 1, 0, 1, dts, [0] * kd, EPI_DUALGATE, z, st2,
+                       0 if bn else 1, (None, None) if bn else (slO, None), 0 if bn else tiles, 0, bm, slope1=slR,
+                       xf1=self.bn_xf(nR) if bn else None,
+                       fin=None if bn else dict(stats=st, tiles=tiles, nsets=2, count=T, norms=[nL, nR]))
         w_out = self.P[f"{pre}.out_conv.2.weight"][perm]                  # (D, cd, 1), rows permuted
         wo = self.W.add(f"{pre}.out_conv.2.weight#packed", pack_taps(w_out, [0]))
         xn = self.alloc_act(1, D)
-        self.emit_conv(f"{pre}.out_conv", [Act(z, 1, cd, None, slO, XF_PRELU_NORM)], wo, None, D, cd, 1, 1, 1, 0, 1,
-                       [0], [0], EPI_ADD, xn, bm=bm, aux=x.ref, dst_acc=x_acc,
-                       fin=dict(stats=st2, tiles=tiles, nsets=1, count=T, norms=[f"{pre}.out_conv.1"]))
+        self.emit_conv(f"{pre}.out_conv", [Act(z, 1, cd, self.bn_xf(nO) if bn else None, slO, XF_PRELU_NORM)], wo, None,
+                       D, cd, 1, 1, 1, 0, 1, [0], [0], EPI_ADD, xn, bm=bm, aux=x.ref, dst_acc=x_acc,
+                       fin=None if bn else dict(stats=st2, tiles=tiles, nsets=1, count=T, norms=[nO]))
         return Act(xn, 1, D)
 
     # -- whole network ----------------------------------------------------------------------
@@ -542,11 +583,22 @@ class Lowering:
 
         skips: List[Act] = []
         x = x_in
-        for i in range(4):
-            x = self.unet_module(f"en.meta_unet_list.{i}", [x], 4 - i, False, in_perm if i == 0 else None)
-            skips.append(x)
-        g = self.conv2d_fwd("en.last_conv", [x], "en.last_conv.0.conv.1", True, "en.last_conv.1", "en.last_conv.2")
-        x = self.materialise("en.last_conv", g)
+        if cfg.is_u2:
+            for i in range(4):
+                x = self.unet_module(f"en.meta_unet_list.{i}", [x], 4 - i, False, in_perm if i == 0 else None)
+                skips.append(x)
+            g = self.conv2d_fwd("en.last_conv", [x], "en.last_conv.0.conv.1", True, "en.last_conv.1", "en.last_conv.2")
+        else:
+            # UNet_Encoder (EaBNet.py:234-239): the skips stay raw with their norm/PReLU pending -- the
+            # next encoder layer and the decoder apply it while loading
+            for i, (_, _, _, has_norm) in enumerate(unet_encoder_layers(cfg)):
+                q = f"en.unet_list.{i}"
+                g = self.conv2d_fwd(q, [x], f"{q}.0.conv.1", True, f"{q}.1" if has_norm else None,
+                                    f"{q}.2" if has_norm else f"{q}.1", in_perm if i == 0 else None)
+                if i < 4:
+                    skips.append(g)
+                    x = g
+        x = self.materialise("en.last_conv", g)       # the S-TCMs need the bottleneck itself in memory
         skips.append(x)
         assert x.F * x.C == cfg.d_feat, "bottleneck width must equal d_feat"
 
@@ -565,12 +617,34 @@ class Lowering:
         x = Act(x_acc, Fb, c)
         self.taps["stcns"] = x
 
-        for i in range(4):
-            x = self.unet_module(f"de.meta_unet_list.{i}", [x, skips[-(i + 1)]], i + 1, True)
-        g = self.conv2d_transposed("de.last_conv", [x, skips[0]], "de.last_conv.0.conv.0", True,
-                                   "de.last_conv.1", "de.last_conv.2")
+        if cfg.is_u2:
+            for i in range(4):
+                x = self.unet_module(f"de.meta_unet_list.{i}", [x, skips[-(i + 1)]], i + 1, True)
+            g = self.conv2d_transposed("de.last_conv", [x, skips[0]], "de.last_conv.0.conv.0", True,
+                                       "de.last_conv.1", "de.last_conv.2")
+        else:
+            for i in range(5):                        # UNet_Decoder (EaBNet.py:324-328)
+                q = f"de.unet_list.{i}"
+                x = g = self.conv2d_transposed(q, [x, skips[-(i + 1)]], f"{q}.0.conv.0", True, f"{q}.1", f"{q}.2")
         e = self.materialise("de.last_conv", g)
         assert e.F == F and e.C == cfg.embed_dim == 64
+
+        if not (cfg.topo_type == "mimo" and cfg.bf_type == "lstm"):
+            # pointwise heads (EaBNet.py:78-81,111-123): the fused "last linear + filter-and-sum" kernel
+            # with the 1x1 conv as its linear map.  cnn: plane m*2+ri is the layout the kernel expects.
+            # miso: one complex mask on microphone 0 = zero rows for every other microphone (the
+            # reference's frequency sum is applied by the caller on the (B,2,T,F) result).
+            w2 = np.zeros((2 * M, 64), np.float32)
+            b2 = np.zeros(2 * M, np.float32)
+            wk = self.P["bf_map.weight"].reshape(-1, 64)
+            w2[:wk.shape[0]], b2[:wk.shape[0]] = wk, self.P["bf_map.bias"]
+            bfw = self.alloc(B * T * F * 2 * M) if self.dump_bfw else None
+            if bfw is not None:
+                self.taps["bf_w"] = Act(bfw, F, 2 * M)
+            self.ops.append(BfwOp(y1=e.ref, w2=self.W.add("bf_map.weight#rows", w2), b2=self.W.add("bf_map.bias#rows", b2),
+                                  x=Ref("in"), out=Ref("out"), bfw=bfw, B=B, T=T, F=F, M=M, name="bf_map+fs"))
+            self.flops += 2 * B * T * F * 64 * wk.shape[0]
+            return Program(cfg, B, T, F, self.ops, self.W.flat(), self.act_size, self.taps, self.flops)
 
         # LSTM_BF (EaBNet.py:600-614)
         h = e

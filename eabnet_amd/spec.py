@@ -18,6 +18,9 @@ Key layout follows the reference constructors (file:line into
   * Conv2dunit 391-405, Deconv2dunit 410-428, NormSwitch 662-686
   * SqueezedTCM        532-571   ``stcns.{g}.tcm_list.{i}``
   * LSTM_BF            581-598   ``bf_map``
+  * UNet_Encoder 199-238 / UNet_Decoder 282-328 (``is_u2=False``)  ``en|de.unet_list.{i}``
+  * pointwise beam-former heads (``bf_type="cnn"``, ``topo_type="miso"``) 78-81  ``bf_map``
+  * BatchNorm branch of NormSwitch 677-681: adds the three running-statistics buffers per norm
 """
 from __future__ import annotations
 
@@ -54,21 +57,21 @@ class NetConfig:
     hid_node: int = 64
 
     def check_supported(self) -> None:
-        """The HIP path covers the reference's default topology (SURVEY §2.1:
-        the other branches are marked out of scope)."""
+        """Every switch of the reference constructor is implemented (U2/plain U-Net, lstm/cnn
+        beam-former, mimo/miso, cat/add, IN/BN, causal or not).  The kernel geometry (64-channel
+        layers, (2,3)/(1,3) kernels) is fixed; ``cLN`` cannot be constructed in the reference
+        either (EaBNet.py:689-691 pass the string dim_size as num_features)."""
         bad = []
-        if not self.is_u2:
-            bad.append("is_u2=False")
-        if self.bf_type != "lstm":
+        if self.bf_type not in ("lstm", "cnn"):
             bad.append(f"bf_type={self.bf_type!r}")
-        if self.topo_type != "mimo":
+        if self.topo_type not in ("mimo", "miso"):
             bad.append(f"topo_type={self.topo_type!r}")
-        if self.intra_connect != "cat":
+        if self.intra_connect not in ("cat", "add"):
             bad.append(f"intra_connect={self.intra_connect!r}")
-        if self.norm_type != "IN":
+        if self.norm_type not in ("IN", "BN"):
             bad.append(f"norm_type={self.norm_type!r}")
-        if not self.is_causal:
-            bad.append("is_causal=False")
+        if not self.is_causal and (self.kd1 - 1) % 2:
+            bad.append("is_causal=False with even kd1 (the reference's residual add fails on the shorter branch)")
         if tuple(self.k1) != (2, 3) or tuple(self.k2) != (1, 3):
             bad.append(f"k1={self.k1} k2={self.k2}")
         if self.c != 64 or self.embed_dim != 64 or self.cd1 != 64:
@@ -79,7 +82,7 @@ class NetConfig:
             bad.append("kd1/p/q/M < 1")
         if bad:
             raise NotImplementedError(
-                "eabnet_amd implements the reference's default EaBNet topology "
+                "eabnet_amd implements EaBNet with the reference's layer geometry "
                 "on MI355X; unsupported option(s): " + ", ".join(bad))
 
 
@@ -87,12 +90,26 @@ class NetConfig:
 class ParamSpec:
     shape: Tuple[int, ...]
     kind: str       # conv_w | convT_w | bias | norm_w | norm_b | prelu | lstm | lin_w | ln_w | ln_b
+    #                 | bn_mean | bn_var | bn_count   (buffers of the BatchNorm branch)
     fan_in: int     # for the default initialiser
 
+    @property
+    def is_buffer(self) -> bool:
+        return self.kind in ("bn_mean", "bn_var", "bn_count")
 
-def _norm_prelu(tab, prefix_norm: str, prefix_act: str, c: int) -> None:
+
+def _norm(tab, prefix_norm: str, c: int, bn: bool) -> None:
+    """NormSwitch (EaBNet.py:662-694): affine InstanceNorm, or BatchNorm with its buffers."""
     tab[f"{prefix_norm}.norm.weight"] = ParamSpec((c,), "norm_w", c)
     tab[f"{prefix_norm}.norm.bias"] = ParamSpec((c,), "norm_b", c)
+    if bn:
+        tab[f"{prefix_norm}.norm.running_mean"] = ParamSpec((c,), "bn_mean", c)
+        tab[f"{prefix_norm}.norm.running_var"] = ParamSpec((c,), "bn_var", c)
+        tab[f"{prefix_norm}.norm.num_batches_tracked"] = ParamSpec((), "bn_count", c)
+
+
+def _norm_prelu(tab, prefix_norm: str, prefix_act: str, c: int, bn: bool = False) -> None:
+    _norm(tab, prefix_norm, c, bn)
     tab[f"{prefix_act}.weight"] = ParamSpec((c,), "prelu", c)
 
 
@@ -111,57 +128,78 @@ def _gate_conv(tab, prefix: str, cin: int, cout: int, k, transposed: bool) -> No
         tab[f"{name}.bias"] = ParamSpec((2 * cout,), "bias", cin * kt * kf)
 
 
-def _unet_module(tab, prefix: str, cin: int, cout: int, k1, k2, scale: int, is_deconv: bool) -> None:
+def _unet_module(tab, prefix: str, cin: int, cout: int, k1, k2, scale: int, is_deconv: bool,
+                 bn: bool = False, add: bool = False) -> None:
     _gate_conv(tab, f"{prefix}.in_conv.0", cin, cout, k1, is_deconv)
-    _norm_prelu(tab, f"{prefix}.in_conv.1", f"{prefix}.in_conv.2", cout)
+    _norm_prelu(tab, f"{prefix}.in_conv.1", f"{prefix}.in_conv.2", cout, bn)
     kt, kf = k2
     for j in range(scale):
         p = f"{prefix}.enco.{j}.conv"
         tab[f"{p}.0.weight"] = ParamSpec((cout, cout, kt, kf), "conv_w", cout * kt * kf)
         tab[f"{p}.0.bias"] = ParamSpec((cout,), "bias", cout * kt * kf)
-        _norm_prelu(tab, f"{p}.1", f"{p}.2", cout)
+        _norm_prelu(tab, f"{p}.1", f"{p}.2", cout, bn)
     for j in range(scale):
         p = f"{prefix}.deco.{j}.deconv"
-        cin_j = cout if j == 0 else 2 * cout          # first inner deconv has no skip
+        cin_j = cout if (j == 0 or add) else 2 * cout   # first inner deconv has no skip; 'add' sums the skip in
         tab[f"{p}.0.weight"] = ParamSpec((cin_j, cout, kt, kf), "convT_w", cout * kt * kf)
         tab[f"{p}.0.bias"] = ParamSpec((cout,), "bias", cout * kt * kf)
-        _norm_prelu(tab, f"{p}.1", f"{p}.2", cout)
+        _norm_prelu(tab, f"{p}.1", f"{p}.2", cout, bn)
 
 
 def param_specs(cfg: NetConfig) -> "OrderedDict[str, ParamSpec]":
-    """Ordered ``key -> ParamSpec`` for the supported topology."""
+    """Ordered ``key -> ParamSpec`` (parameters and buffers) for the configured topology."""
     cfg.check_supported()
     tab: "OrderedDict[str, ParamSpec]" = OrderedDict()
     c, M = cfg.c, cfg.M
+    bn, add = cfg.norm_type == "BN", cfg.intra_connect == "add"
 
-    # encoder: scales 4,3,2,1 then a gated conv down to F=4
-    en_k = [cfg.k_beg, cfg.k1, cfg.k1, cfg.k1]
-    en_cin = [2 * M, c, c, c]
-    for i in range(4):
-        _unet_module(tab, f"en.meta_unet_list.{i}", en_cin[i], c, en_k[i], cfg.k2, 4 - i, False)
-    _gate_conv(tab, "en.last_conv.0", c, cfg.c_end, cfg.k1, False)
-    _norm_prelu(tab, "en.last_conv.1", "en.last_conv.2", cfg.c_end)
+    if cfg.is_u2:
+        # encoder: scales 4,3,2,1 then a gated conv down to F=4
+        en_k = [cfg.k_beg, cfg.k1, cfg.k1, cfg.k1]
+        en_cin = [2 * M, c, c, c]
+        for i in range(4):
+            _unet_module(tab, f"en.meta_unet_list.{i}", en_cin[i], c, en_k[i], cfg.k2, 4 - i, False, bn, add)
+        _gate_conv(tab, "en.last_conv.0", c, cfg.c_end, cfg.k1, False)
+        _norm_prelu(tab, "en.last_conv.1", "en.last_conv.2", cfg.c_end, bn)
 
-    # decoder: scales 1,2,3,4 on cat(skip) inputs, then the (2,5) gated deconv
-    for i in range(4):
-        cin = 2 * cfg.c_end if i == 0 else 2 * c
-        _unet_module(tab, f"de.meta_unet_list.{i}", cin, c, cfg.k1, cfg.k2, i + 1, True)
-    _gate_conv(tab, "de.last_conv.0", 2 * c, cfg.embed_dim, cfg.k_beg, True)
-    _norm_prelu(tab, "de.last_conv.1", "de.last_conv.2", cfg.embed_dim)
+        # decoder: scales 1,2,3,4 on cat(skip) inputs, then the (2,5) gated deconv
+        for i in range(4):
+            cin = 2 * cfg.c_end if i == 0 else 2 * c
+            _unet_module(tab, f"de.meta_unet_list.{i}", cin, c, cfg.k1, cfg.k2, i + 1, True, bn, add)
+        _gate_conv(tab, "de.last_conv.0", 2 * c, cfg.embed_dim, cfg.k_beg, True)
+        _norm_prelu(tab, "de.last_conv.1", "de.last_conv.2", cfg.embed_dim, bn)
+    else:
+        # plain U-Net (EaBNet.py:199-238, 282-328): five gated convs down, five gated deconvs up;
+        # encoder layers 1 and 2 have a PReLU but no norm
+        for i, (cin, cout, k, has_norm) in enumerate(unet_encoder_layers(cfg)):
+            _gate_conv(tab, f"en.unet_list.{i}.0", cin, cout, k, False)
+            if has_norm:
+                _norm_prelu(tab, f"en.unet_list.{i}.1", f"en.unet_list.{i}.2", cout, bn)
+            else:
+                tab[f"en.unet_list.{i}.1.weight"] = ParamSpec((cout,), "prelu", cout)
+        for i, (cin, cout, k) in enumerate(unet_decoder_layers(cfg)):
+            _gate_conv(tab, f"de.unet_list.{i}.0", cin, cout, k, True)
+            _norm_prelu(tab, f"de.unet_list.{i}.1", f"de.unet_list.{i}.2", cout, bn)
 
     # beamformer head
     E, H = cfg.embed_dim, cfg.hid_node
-    for name, isz in (("rnn1", E), ("rnn2", H)):
-        tab[f"bf_map.{name}.weight_ih_l0"] = ParamSpec((4 * H, isz), "lstm", H)
-        tab[f"bf_map.{name}.weight_hh_l0"] = ParamSpec((4 * H, H), "lstm", H)
-        tab[f"bf_map.{name}.bias_ih_l0"] = ParamSpec((4 * H,), "lstm", H)
-        tab[f"bf_map.{name}.bias_hh_l0"] = ParamSpec((4 * H,), "lstm", H)
-    tab["bf_map.w_dnn.0.weight"] = ParamSpec((H, H), "lin_w", H)
-    tab["bf_map.w_dnn.0.bias"] = ParamSpec((H,), "bias", H)
-    tab["bf_map.w_dnn.2.weight"] = ParamSpec((2 * M, H), "lin_w", H)
-    tab["bf_map.w_dnn.2.bias"] = ParamSpec((2 * M,), "bias", H)
-    tab["bf_map.norm.weight"] = ParamSpec((E,), "ln_w", E)
-    tab["bf_map.norm.bias"] = ParamSpec((E,), "ln_b", E)
+    if cfg.topo_type == "mimo" and cfg.bf_type == "lstm":
+        for name, isz in (("rnn1", E), ("rnn2", H)):
+            tab[f"bf_map.{name}.weight_ih_l0"] = ParamSpec((4 * H, isz), "lstm", H)
+            tab[f"bf_map.{name}.weight_hh_l0"] = ParamSpec((4 * H, H), "lstm", H)
+            tab[f"bf_map.{name}.bias_ih_l0"] = ParamSpec((4 * H,), "lstm", H)
+            tab[f"bf_map.{name}.bias_hh_l0"] = ParamSpec((4 * H,), "lstm", H)
+        tab["bf_map.w_dnn.0.weight"] = ParamSpec((H, H), "lin_w", H)
+        tab["bf_map.w_dnn.0.bias"] = ParamSpec((H,), "bias", H)
+        tab["bf_map.w_dnn.2.weight"] = ParamSpec((2 * M, H), "lin_w", H)
+        tab["bf_map.w_dnn.2.bias"] = ParamSpec((2 * M,), "bias", H)
+        tab["bf_map.norm.weight"] = ParamSpec((E,), "ln_w", E)
+        tab["bf_map.norm.bias"] = ParamSpec((E,), "ln_b", E)
+    else:
+        # pointwise Conv2d head (EaBNet.py:78-81): 2M weight planes (mimo/cnn) or one complex mask (miso)
+        n_out = 2 * M if cfg.topo_type == "mimo" else 2
+        tab["bf_map.weight"] = ParamSpec((n_out, E, 1, 1), "conv_w", E)
+        tab["bf_map.bias"] = ParamSpec((n_out,), "bias", E)
 
     # squeezed-TCN bottleneck
     D, cd, kd = cfg.d_feat, cfg.cd1, cfg.kd1
@@ -171,11 +209,23 @@ def param_specs(cfg: NetConfig) -> "OrderedDict[str, ParamSpec]":
             tab[f"{p}.in_conv.weight"] = ParamSpec((cd, D, 1), "conv_w", D)
             for side in ("left_conv", "right_conv"):
                 tab[f"{p}.{side}.0.weight"] = ParamSpec((cd,), "prelu", cd)
-                tab[f"{p}.{side}.1.norm.weight"] = ParamSpec((cd,), "norm_w", cd)
-                tab[f"{p}.{side}.1.norm.bias"] = ParamSpec((cd,), "norm_b", cd)
+                _norm(tab, f"{p}.{side}.1", cd, bn)
                 tab[f"{p}.{side}.3.weight"] = ParamSpec((cd, cd, kd), "conv_w", cd * kd)
             tab[f"{p}.out_conv.0.weight"] = ParamSpec((cd,), "prelu", cd)
-            tab[f"{p}.out_conv.1.norm.weight"] = ParamSpec((cd,), "norm_w", cd)
-            tab[f"{p}.out_conv.1.norm.bias"] = ParamSpec((cd,), "norm_b", cd)
+            _norm(tab, f"{p}.out_conv.1", cd, bn)
             tab[f"{p}.out_conv.2.weight"] = ParamSpec((D, cd, 1), "conv_w", cd)
     return tab
+
+
+def unet_encoder_layers(cfg: NetConfig):
+    """(cin, cout, kernel, has_norm) of UNet_Encoder's five gated convs (EaBNet.py:213-232)."""
+    c = cfg.c
+    return [(2 * cfg.M, c, cfg.k_beg, True), (c, c, cfg.k1, False), (c, c, cfg.k1, False),
+            (c, c, cfg.k1, True), (c, cfg.c_end, cfg.k1, True)]
+
+
+def unet_decoder_layers(cfg: NetConfig):
+    """(cin, cout, kernel) of UNet_Decoder's five gated deconvs on cat(skip) inputs (EaBNet.py:297-321)."""
+    c = cfg.c
+    return [(2 * cfg.c_end, c, cfg.k1), (2 * c, c, cfg.k1), (2 * c, c, cfg.k1), (2 * c, c, cfg.k1),
+            (2 * c, cfg.embed_dim, cfg.k_beg)]

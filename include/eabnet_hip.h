@@ -129,7 +129,7 @@ typedef struct eab_conv_desc {
     int32_t No;             /* output columns per time row computed by this launch */
     int32_t ostride, ophase, istride;
     int32_t ntaps;
-    int32_t dt[EAB_MAX_TAPS];    /* <= 0 */
+    int32_t dt[EAB_MAX_TAPS];    /* time offset of the tap; > 0 (look-ahead, non-causal S-TCM) only with EAB_KORDER_TAP */
     int32_t ioff[EAB_MAX_TAPS];
     /* epilogue */
     int32_t epi;

@@ -6,8 +6,10 @@ imports it; the product path fails loudly when the HIP library is missing.
 
 What it is: a functional (stateless, parameters-as-dict) restatement on
 PyTorch-CPU of ``prepare_data`` (reference train_distributed.py:68-95) and
-``EaBNet.forward`` (reference EaBNet.py:88-125) for the default topology
-(is_u2, lstm beam-former, mimo, cat skips, InstanceNorm, causal).  It uses the
+``EaBNet.forward`` (reference EaBNet.py:88-125): the default topology (is_u2,
+lstm beam-former, mimo, cat skips, InstanceNorm, causal) and, by keyword, the other
+constructor branches (plain U-Net, cnn/miso heads, add skips, BatchNorm in eval
+mode, non-causal S-TCMs).  It uses the
 same ATen primitives the reference reaches (conv2d / conv_transpose2d /
 conv1d / instance_norm / prelu / layer_norm / linear) so its rounding behaviour
 is the reference's; the LSTM is spelled out step by step (gate order i,f,g,o)
@@ -93,10 +95,18 @@ def prepare_data_oracle(x: torch.Tensor, target: Optional[torch.Tensor], n_fft: 
 # ----------------------------------------------------------------------------
 # network blocks
 # ----------------------------------------------------------------------------
-def _in_prelu(x, P: Params, norm_prefix: str, act_prefix: str):
-    y = F.instance_norm(x, weight=P[f"{norm_prefix}.norm.weight"], bias=P[f"{norm_prefix}.norm.bias"],
-                        use_input_stats=True, eps=EPS_IN)
-    return F.prelu(y, P[f"{act_prefix}.weight"])
+def _norm(x, P: Params, norm_prefix: str, bn: bool = False):
+    """NormSwitch (EaBNet.py:662-694): affine InstanceNorm, or BatchNorm in eval mode
+    (running statistics; nn.BatchNorm default eps 1e-5)."""
+    w, b = P[f"{norm_prefix}.norm.weight"], P[f"{norm_prefix}.norm.bias"]
+    if bn:
+        return F.batch_norm(x, P[f"{norm_prefix}.norm.running_mean"], P[f"{norm_prefix}.norm.running_var"], w, b,
+                            training=False, eps=EPS_IN)
+    return F.instance_norm(x, weight=w, bias=b, use_input_stats=True, eps=EPS_IN)
+
+
+def _in_prelu(x, P: Params, norm_prefix: str, act_prefix: str, bn: bool = False):
+    return F.prelu(_norm(x, P, norm_prefix, bn), P[f"{act_prefix}.weight"])
 
 
 def gate_conv2d(x, w, b):
@@ -119,43 +129,43 @@ def gate_deconv2d(x, w, b):
     return a * torch.sigmoid(g)
 
 
-def unet_module(x, P: Params, pre: str, scale: int, is_deconv: bool, taps=None):
-    """En_unet_module.forward (EaBNet.py:372-388)."""
+def unet_module(x, P: Params, pre: str, scale: int, is_deconv: bool, taps=None, bn: bool = False, add: bool = False):
+    """En_unet_module.forward (EaBNet.py:372-388); Skip_connect (:493-503) cat or add."""
     wk = f"{pre}.in_conv.0.conv.{0 if is_deconv else 1}"
     gated = (gate_deconv2d if is_deconv else gate_conv2d)(x, P[f"{wk}.weight"], P[f"{wk}.bias"])
-    resi = _in_prelu(gated, P, f"{pre}.in_conv.1", f"{pre}.in_conv.2")
+    resi = _in_prelu(gated, P, f"{pre}.in_conv.1", f"{pre}.in_conv.2", bn)
     if taps is not None:
         taps[f"{pre}.in_conv"] = resi
     y = resi
     downs: List[torch.Tensor] = []
     for j in range(scale):
         q = f"{pre}.enco.{j}.conv"
-        y = _in_prelu(F.conv2d(y, P[f"{q}.0.weight"], P[f"{q}.0.bias"], stride=(1, 2)), P, f"{q}.1", f"{q}.2")
+        y = _in_prelu(F.conv2d(y, P[f"{q}.0.weight"], P[f"{q}.0.bias"], stride=(1, 2)), P, f"{q}.1", f"{q}.2", bn)
         downs.append(y)
     for j in range(scale):
         q = f"{pre}.deco.{j}.deconv"
         if j > 0:
-            y = torch.cat((y, downs[-(j + 1)]), dim=1)
+            y = y + downs[-(j + 1)] if add else torch.cat((y, downs[-(j + 1)]), dim=1)
         y = _in_prelu(F.conv_transpose2d(y, P[f"{q}.0.weight"], P[f"{q}.0.bias"], stride=(1, 2)),
-                      P, f"{q}.1", f"{q}.2")
+                      P, f"{q}.1", f"{q}.2", bn)
     return resi + y
 
 
-def squeezed_tcm(x, P: Params, pre: str, dilation: int, kd: int):
-    """SqueezedTCM.forward (EaBNet.py:572-578), causal branch (:551)."""
+def squeezed_tcm(x, P: Params, pre: str, dilation: int, kd: int, bn: bool = False, causal: bool = True):
+    """SqueezedTCM.forward (EaBNet.py:572-578); padding of the dilated branch convs :550-553
+    (all on the left when causal, split evenly otherwise)."""
     y = F.conv1d(x, P[f"{pre}.in_conv.weight"])
-    pad = (kd - 1) * dilation
+    span = (kd - 1) * dilation
+    pad = (span, 0) if causal else (span // 2, span // 2)
 
     def branch(side):
         z = F.prelu(y, P[f"{pre}.{side}.0.weight"])
-        z = F.instance_norm(z, weight=P[f"{pre}.{side}.1.norm.weight"], bias=P[f"{pre}.{side}.1.norm.bias"],
-                            use_input_stats=True, eps=EPS_IN)
-        return F.conv1d(F.pad(z, (pad, 0)), P[f"{pre}.{side}.3.weight"], dilation=dilation)
+        z = _norm(z, P, f"{pre}.{side}.1", bn)
+        return F.conv1d(F.pad(z, pad), P[f"{pre}.{side}.3.weight"], dilation=dilation)
 
     z = branch("left_conv") * torch.sigmoid(branch("right_conv"))
     z = F.prelu(z, P[f"{pre}.out_conv.0.weight"])
-    z = F.instance_norm(z, weight=P[f"{pre}.out_conv.1.norm.weight"], bias=P[f"{pre}.out_conv.1.norm.bias"],
-                        use_input_stats=True, eps=EPS_IN)
+    z = _norm(z, P, f"{pre}.out_conv.1", bn)
     return F.conv1d(z, P[f"{pre}.out_conv.2.weight"]) + x
 
 
@@ -205,25 +215,55 @@ def filter_and_sum(w, x):
     return torch.stack(((wr * xr - wi * xi).sum(-1), (wr * xi + wi * xr).sum(-1)), dim=1)
 
 
+def unet_encoder(x, P: Params, bn: bool):
+    """UNet_Encoder.forward (EaBNet.py:234-239): five gated convs; layers 1 and 2 carry a PReLU
+    but no norm (:217-224)."""
+    skips = []
+    for i in range(5):
+        x = gate_conv2d(x, P[f"en.unet_list.{i}.0.conv.1.weight"], P[f"en.unet_list.{i}.0.conv.1.bias"])
+        if i in (1, 2):
+            x = F.prelu(x, P[f"en.unet_list.{i}.1.weight"])
+        else:
+            x = _in_prelu(x, P, f"en.unet_list.{i}.1", f"en.unet_list.{i}.2", bn)
+        skips.append(x)
+    return x, skips
+
+
+def unet_decoder(x, skips, P: Params, bn: bool):
+    """UNet_Decoder.forward (EaBNet.py:324-328)."""
+    for i in range(5):
+        x = gate_deconv2d(torch.cat((x, skips[-(i + 1)]), dim=1), P[f"de.unet_list.{i}.0.conv.0.weight"],
+                          P[f"de.unet_list.{i}.0.conv.0.bias"])
+        x = _in_prelu(x, P, f"de.unet_list.{i}.1", f"de.unet_list.{i}.2", bn)
+    return x
+
+
 def eabnet_forward(P: Params, inpt: torch.Tensor, p: int = 6, q: int = 3, kd: int = 5,
-                   fast_lstm: bool = False, taps: Optional[dict] = None) -> torch.Tensor:
-    """EaBNet.forward (EaBNet.py:88-117), default topology.
-    inpt (B,T,F,M,2) [or (B,T,F,2)] -> (B,2,T,F)."""
+                   fast_lstm: bool = False, taps: Optional[dict] = None, *, is_causal: bool = True,
+                   is_u2: bool = True, bf_type: str = "lstm", topo_type: str = "mimo",
+                   intra_connect: str = "cat", norm_type: str = "IN") -> torch.Tensor:
+    """EaBNet.forward (EaBNet.py:88-125).
+    inpt (B,T,F,M,2) [or (B,T,F,2)] -> (B,2,T,F)  [(B,2,T) for topo_type="miso", as the reference]."""
     if inpt.ndim == 4:
         inpt = inpt.unsqueeze(-2)
     B, T, Fq, M, _ = inpt.shape
+    bn, add = norm_type == "BN", intra_connect == "add"
+    assert norm_type in ("IN", "BN") and intra_connect in ("cat", "add")
     # (B,T,F,M,2) -> (B,2M,T,F), channel = ri*M + m   (EaBNet.py:96-97)
     x = inpt.transpose(-2, -1).contiguous().view(B, T, Fq, 2 * M).permute(0, 3, 1, 2)
 
     skips = []
-    for i in range(4):
-        x = unet_module(x, P, f"en.meta_unet_list.{i}", 4 - i, False, taps)
+    if not is_u2:
+        x, skips = unet_encoder(x, P, bn)
+    else:
+        for i in range(4):
+            x = unet_module(x, P, f"en.meta_unet_list.{i}", 4 - i, False, taps, bn, add)
+            skips.append(x)
+            if taps is not None:
+                taps[f"en.{i}"] = x
+        x = gate_conv2d(x, P["en.last_conv.0.conv.1.weight"], P["en.last_conv.0.conv.1.bias"])
+        x = _in_prelu(x, P, "en.last_conv.1", "en.last_conv.2", bn)
         skips.append(x)
-        if taps is not None:
-            taps[f"en.{i}"] = x
-    x = gate_conv2d(x, P["en.last_conv.0.conv.1.weight"], P["en.last_conv.0.conv.1.bias"])
-    x = _in_prelu(x, P, "en.last_conv.1", "en.last_conv.2")
-    skips.append(x)
     if taps is not None:
         taps["en.4"] = x
 
@@ -232,7 +272,7 @@ def eabnet_forward(P: Params, inpt: torch.Tensor, p: int = 6, q: int = 3, kd: in
     acc = torch.zeros_like(x)
     for g in range(q):
         for i in range(p):
-            x = squeezed_tcm(x, P, f"stcns.{g}.tcm_list.{i}", 2 ** i, kd)
+            x = squeezed_tcm(x, P, f"stcns.{g}.tcm_list.{i}", 2 ** i, kd, bn, is_causal)
             if taps is not None and g == 0 and i == 0:
                 taps["stcns.0.0"] = x
         acc = acc + x
@@ -240,16 +280,31 @@ def eabnet_forward(P: Params, inpt: torch.Tensor, p: int = 6, q: int = 3, kd: in
     if taps is not None:
         taps["stcns"] = x
 
-    for i in range(4):
-        x = unet_module(torch.cat((x, skips[-(i + 1)]), dim=1), P, f"de.meta_unet_list.{i}", i + 1, True, taps)
-        if taps is not None:
-            taps[f"de.{i}"] = x
-    x = gate_deconv2d(torch.cat((x, skips[0]), dim=1), P["de.last_conv.0.conv.0.weight"], P["de.last_conv.0.conv.0.bias"])
-    x = _in_prelu(x, P, "de.last_conv.1", "de.last_conv.2")
+    if not is_u2:
+        x = unet_decoder(x, skips, P, bn)
+    else:
+        for i in range(4):
+            x = unet_module(torch.cat((x, skips[-(i + 1)]), dim=1), P, f"de.meta_unet_list.{i}", i + 1, True, taps,
+                            bn, add)
+            if taps is not None:
+                taps[f"de.{i}"] = x
+        x = gate_deconv2d(torch.cat((x, skips[0]), dim=1), P["de.last_conv.0.conv.0.weight"],
+                          P["de.last_conv.0.conv.0.bias"])
+        x = _in_prelu(x, P, "de.last_conv.1", "de.last_conv.2", bn)
     if taps is not None:
         taps["de.4"] = x
 
-    w = lstm_bf(x, P, M, fast_lstm, taps)
+    if topo_type == "miso":
+        # EaBNet.py:118-125: one complex mask on microphone 0, then -- as written there -- a sum over
+        # the LAST axis of a (B,T,F) tensor, i.e. over frequency: the result is (B,2,T)
+        m = F.conv2d(x, P["bf_map.weight"], P["bf_map.bias"]).permute(0, 2, 3, 1)           # (B,T,F,2)
+        mr, mi, xr, xi = m[..., 0], m[..., -1], inpt[..., 0, 0], inpt[..., 0, -1]
+        return torch.stack(((mr * xr - mi * xi).sum(-1), (mr * xi + mi * xr).sum(-1)), dim=1)
+    if bf_type == "cnn":
+        # EaBNet.py:111-113: pointwise conv to 2M planes, plane m*2+ri
+        w = F.conv2d(x, P["bf_map.weight"], P["bf_map.bias"]).view(B, M, -1, T, Fq).permute(0, 3, 4, 1, 2)
+    else:
+        w = lstm_bf(x, P, M, fast_lstm, taps)
     if taps is not None:
         taps["bf_w"] = w
     return filter_and_sum(w, inpt)

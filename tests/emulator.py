@@ -133,18 +133,19 @@ class Emulator:
         o = np.arange(No)
         for j in range(ntaps):
             dt, fi = op.dt[j], o * op.istride + op.ioff[j]
-            assert dt <= 0
             ok = (fi >= 0) & (fi < Fin)
             G = np.zeros((B, T, No, Ct), dtype=np.float32)
-            tv = T + dt
+            tv = T - abs(dt)                 # rows whose source row t+dt lies inside [0, T)
+            dst_t = slice(-dt, T) if dt <= 0 else slice(0, tv)
+            src_t = slice(0, tv) if dt <= 0 else slice(dt, T)
             if tv > 0:
-                G[:, -dt:, ok] = X[:, :tv][:, :, fi[ok]]
+                G[:, dst_t, ok] = X[:, src_t][:, :, fi[ok]]
             if not dual:
                 acc += mm(G, allrows, j)
             else:                            # packed rows with (r % 64) < 32 are "left", the others "right"
                 G2 = np.zeros_like(G)
                 if tv > 0:
-                    G2[:, -dt:, ok] = X2[:, :tv][:, :, fi[ok]]
+                    G2[:, dst_t, ok] = X2[:, src_t][:, :, fi[ok]]
                 left = (np.arange(op.N) % 64) < 32
                 acc[..., left] += mm(G, np.nonzero(left)[0], j)
                 acc[..., ~left] += mm(G2, np.nonzero(~left)[0], j)

@@ -35,9 +35,21 @@ torch.set_num_threads(8)
 N_FFT, HOP = 320, 160
 
 
-def ref_model(M: int, seed: int):
-    specs = param_specs(NetConfig(M=M))
-    net = RefEaBNet(M=M).eval()
+VARIANTS = {          # constructor branches away from the default, T=20, B=2
+    "bn": dict(norm_type="BN"),
+    "unet": dict(is_u2=False),
+    "cnn": dict(bf_type="cnn"),
+    "miso": dict(topo_type="miso"),
+    "add": dict(intra_connect="add"),
+    "noncausal": dict(is_causal=False),
+    "unet_bn_cnn_noncausal": dict(is_u2=False, norm_type="BN", bf_type="cnn", is_causal=False),
+    "add_bn_miso": dict(intra_connect="add", norm_type="BN", topo_type="miso"),
+}
+
+
+def ref_model(M: int, seed: int, **kw):
+    specs = param_specs(NetConfig(M=M, **kw))
+    net = RefEaBNet(M=M, **kw).eval()
     sd = net.state_dict()
     assert list(sd.keys()) == list(specs.keys()), "key order/name mismatch vs reference"
     for k, v in sd.items():
@@ -153,6 +165,24 @@ def main():
          target_l2=np.float64(torch.linalg.vector_norm(ts.double()).item()))
 
 
+def main_variants():
+    """One small end-to-end fixture per non-default constructor branch (eval mode)."""
+    inventory = {}
+    for i, (name, kw) in enumerate(VARIANTS.items()):
+        M = 4
+        net, specs = ref_model(M, seed=200 + i, **kw)
+        inventory[name] = dict(kwargs=kw, M=M, keys=[[k, list(v.shape)] for k, v in net.state_dict().items()])
+        x = torch.from_numpy(paramgen.make_spec_input(2, 20, 161, M, seed=300 + i))
+        y = net(x)
+        save(f"var_{name}.npz", out=y.numpy(), param_seed=200 + i, input_seed=300 + i, M=M)
+    with open(os.path.join(HERE, "keys_variants.json"), "w") as f:
+        json.dump(inventory, f)
+
+
 if __name__ == "__main__":
     with torch.no_grad():
-        main()
+        if sys.argv[1:] == ["variants"]:
+            main_variants()
+        else:
+            main()
+            main_variants()

@@ -33,6 +33,12 @@ def make_param(key: str, shape: Tuple[int, ...], kind: str, fan_in: int, seed: i
         return g.uniform(-0.3, 0.3, size=shape).astype(np.float32)
     if kind == "prelu":
         return g.uniform(0.05, 0.45, size=shape).astype(np.float32)
+    if kind == "bn_mean":
+        return g.uniform(-0.2, 0.2, size=shape).astype(np.float32)
+    if kind == "bn_var":
+        return g.uniform(0.3, 1.2, size=shape).astype(np.float32)
+    if kind == "bn_count":
+        return np.asarray(7, dtype=np.int64)
     raise ValueError(kind)
 
 

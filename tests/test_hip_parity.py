@@ -25,7 +25,7 @@ def dev():
 def _model(M, seed, dev, **kw):
     import eabnet_amd
     net = eabnet_amd.EaBNet(M=M, **kw)
-    net.load_state_dict(torch_params(M, seed, **{k: v for k, v in kw.items() if k in ("p", "q")}), strict=True)
+    net.load_state_dict(torch_params(M, seed, **kw), strict=True)
     return net.to(dev).eval()
 
 
@@ -206,6 +206,47 @@ def test_c2_batch16_properties(dev):
     assert_close(y[0:1].cpu().numpy(), g["out"], TOL_HIP, "slot 0 vs reference fixture")
     assert torch.equal(y[0], y[5]), "identical utterances must give bit-identical outputs"
     assert_close(y[3:4].cpu().numpy(), y3.cpu().numpy(), 1e-5, "batch independence")
+
+
+def _variants():
+    import json
+    import os
+    from util import GOLDEN
+    with open(os.path.join(GOLDEN, "keys_variants.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("name", sorted(_variants()))
+def test_constructor_variants_vs_reference_fixtures(dev, name, precision):
+    """Every non-default constructor branch of the reference (EaBNet.py:68-85) on the HIP program,
+    against outputs of the reference built with the same keywords."""
+    e = _variants()[name]
+    g = load(f"var_{name}.npz")
+    net = _model(e["M"], int(g["param_seed"]), dev, **e["kwargs"])
+    net.precision = precision
+    x = torch.from_numpy(paramgen.make_spec_input(2, 20, 161, e["M"], int(g["input_seed"]))).to(dev)
+    with torch.no_grad():
+        y = net(x)
+    assert tuple(y.shape) == tuple(g["out"].shape)
+    assert_close(y.cpu().numpy(), g["out"], TOL_HIP, name)
+
+
+@pytest.mark.parametrize("kw", [dict(norm_type="BN"), dict(intra_connect="add", is_causal=False),
+                                dict(is_u2=False, norm_type="BN", bf_type="cnn", is_causal=False)],
+                         ids=["bn", "add_noncausal", "unet_bn_cnn_noncausal"])
+def test_constructor_variants_moderate_size_vs_oracle(dev, kw):
+    """Same branches at a size with several 128-row tiles per utterance, the patch pipeline without
+    a statistics epilogue (BN) and S-TCM look-ahead taps longer than a tile (dilation 32, T = 150)."""
+    from oracle import eabnet_oracle as orc
+    M, B, T = 8, 2, 150
+    net = _model(M, 410, dev, **kw)
+    x = torch.from_numpy(paramgen.make_spec_input(B, T, 161, M, 411))
+    with torch.no_grad():
+        ref = orc.eabnet_forward(torch_params(M, 410, **kw), x, fast_lstm=True, **kw).numpy()
+        for precision in ("f32", "f16x3"):
+            net.precision = precision
+            assert_close(net(x.to(dev)).cpu().numpy(), ref, TOL_HIP, f"{kw} {precision}")
 
 
 @pytest.mark.parametrize("name,M,B,T", [("e2e_M8_B2_T20.npz", 8, 2, 20), ("e2e_M9_B1_T10.npz", 9, 1, 10)])

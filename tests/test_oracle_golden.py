@@ -165,3 +165,24 @@ def test_plain_c_filter_sum_vs_oracle():
     ref = orc.filter_and_sum(torch.from_numpy(w), torch.from_numpy(x)).numpy()
     assert_close(yr.reshape(2, 5, 161), ref[:, 0], 1e-6)
     assert_close(yi.reshape(2, 5, 161), ref[:, 1], 1e-6)
+
+
+def _variants():
+    import json
+    import os
+    with open(os.path.join(GOLDEN, "keys_variants.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", sorted(_variants()))
+def test_oracle_constructor_variants_match_reference(name):
+    """The oracle's keyword branches (BN eval, plain U-Net, cnn / miso heads, add skips,
+    non-causal S-TCMs) against outputs of the reference constructed with the same keywords."""
+    e = _variants()[name]
+    g = load(f"var_{name}.npz")
+    P = torch_params(e["M"], int(g["param_seed"]), **e["kwargs"])
+    x = torch.from_numpy(paramgen.make_spec_input(2, 20, 161, e["M"], int(g["input_seed"])))
+    with torch.no_grad():
+        y = orc.eabnet_forward(P, x, **e["kwargs"])
+    assert tuple(y.shape) == tuple(g["out"].shape)
+    assert_close(y.numpy(), g["out"], TOL_ORACLE, name)

@@ -78,10 +78,48 @@ def test_flop_count_close_to_survey_formula():
 
 
 def test_unsupported_topologies_raise():
-    for kw in (dict(norm_type="BN"), dict(is_u2=False), dict(bf_type="cnn"), dict(topo_type="miso"),
-               dict(intra_connect="add"), dict(is_causal=False)):
+    """cLN cannot be constructed in the reference either (EaBNet.py:689-691); the layer geometry
+    (64 channels, (2,3)/(1,3) kernels) is fixed by the kernels."""
+    for kw in (dict(norm_type="cLN"), dict(bf_type="gru"), dict(topo_type="siso"), dict(intra_connect="mul"),
+               dict(c=32), dict(k1=(2, 5)), dict(is_causal=False, kd1=4)):
         with pytest.raises(NotImplementedError):
             param_specs(NetConfig(M=8, **kw))
+
+
+def _variants():
+    import json
+    import os
+    from util import GOLDEN
+    with open(os.path.join(GOLDEN, "keys_variants.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", sorted(_variants()))
+def test_variant_keys_match_reference_inventory(name):
+    e = _variants()[name]
+    specs = param_specs(NetConfig(M=e["M"], **e["kwargs"]))
+    assert [[k, list(s.shape)] for k, s in specs.items()] == e["keys"]
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("name", sorted(_variants()))
+def test_emulated_constructor_variants_match_reference(name, precision):
+    """Every non-default constructor branch (BatchNorm eval as static tables, plain U-Net with
+    PReLU-only layers, cnn/miso heads through the fused linear+filter-sum op, 'add' skips as a
+    duplicated-weight two-source conv, centred S-TCM taps) against outputs of the reference."""
+    e = _variants()[name]
+    g = load(f"var_{name}.npz")
+    cfg = NetConfig(M=e["M"], **e["kwargs"])
+    P = paramgen.make_params(param_specs(cfg), int(g["param_seed"]))
+    x = paramgen.make_spec_input(2, 20, 161, e["M"], int(g["input_seed"]))
+    prog = prg.lower(cfg, P, 2, 20, 161, precision=precision)
+    y = Emulator(prog, x).run()
+    if cfg.topo_type == "miso":
+        y = y.sum(-1)
+    assert_close(y, g["out"], TOL_EMU, name)
+    if cfg.norm_type == "BN":            # no statistics pass at all
+        assert not any(op.kind == prg.OP_IN_FINALIZE for op in prog.ops)
+        assert all(op.stats is None and op.fin_stats is None for op in prog.ops if op.kind == prg.OP_CONV)
 
 
 def test_f16x3_lowering_matches_reference_fixture():
