@@ -295,9 +295,12 @@ def main():
             t_stft = timed(lambda: eabnet_amd.stft_compress(wav, N_FFT, HOP, window))
             wts = torch.randn_like(ns)
             t_fs = timed(lambda: eabnet_amd.filter_and_sum(wts, ns))
+            est = torch.randn(B_PER_GPU, 2, T, 161, device=dev)
+            t_is = timed(lambda: eabnet_amd.istft(est, N_FFT, HOP, window))
         fr = B_PER_GPU * T
         by_stft = fr * (160 * MICS * 4 + 161 * MICS * 2 * 4)
         by_fs = fr * 161 * (4 * MICS + 2) * 4
+        by_is = fr * (2 * 161 + 160) * 4
         by_na = fr * 3 * 64 * 4 * sum(o.P for o in ops if o.kind == prg.OP_NORM_ACT and o.b is not None) / T \
             + fr * 2 * 64 * 4 * sum(o.P for o in ops if o.kind == prg.OP_NORM_ACT and o.b is None) / T
         t_na = 1e-3 * sum(float(ms[k]) for k, o in enumerate(ops) if o.kind == prg.OP_NORM_ACT)
@@ -307,6 +310,8 @@ def main():
                               "bytes_per_frame": 160 * MICS * 4 + 161 * MICS * 2 * 4},
             "filter_sum": {"us": 1e6 * t_fs, "achieved_GBs": by_fs / t_fs / 1e9, "frac": by_fs / t_fs / 1e9 / PEAK_HBM_GBS,
                            "bytes_per_frame": 161 * (4 * MICS + 2) * 4},
+            "istft(back end, next row N2)": {"us": 1e6 * t_is, "achieved_GBs": by_is / t_is / 1e9,
+                                             "frac": by_is / t_is / 1e9 / PEAK_HBM_GBS, "bytes_per_frame": (2 * 161 + 160) * 4},
             "norm_act(all 10 launches)": {"us": 1e6 * t_na, "achieved_GBs": by_na / t_na / 1e9, "frac": by_na / t_na / 1e9 / PEAK_HBM_GBS},
         }
 

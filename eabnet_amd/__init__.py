@@ -8,8 +8,8 @@ Importing the package does not touch the GPU; the HIP library
 error, never a fallback.
 """
 from .spec import NetConfig, param_specs  # noqa: F401
-from .model import (EaBNet, prepare_data, stft_compress, filter_and_sum, numParams,  # noqa: F401
+from .model import (EaBNet, prepare_data, stft_compress, istft, filter_and_sum, numParams,  # noqa: F401
                     com_mag_mse_loss)
 
-__all__ = ["EaBNet", "prepare_data", "stft_compress", "filter_and_sum", "numParams", "com_mag_mse_loss",
+__all__ = ["EaBNet", "prepare_data", "stft_compress", "istft", "filter_and_sum", "numParams", "com_mag_mse_loss",
            "NetConfig", "param_specs"]

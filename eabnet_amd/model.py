@@ -347,6 +347,29 @@ def prepare_data(x: torch.Tensor, target: torch.Tensor, device, args):
     return noisy_stft, target_stft
 
 
+def istft(esti_stft: torch.Tensor, fft_num: int, win_shift: int, window: torch.Tensor) -> torch.Tensor:
+    """The reference's back end (enhance.py:59-62, test.py:189-191, train_distributed.py:128-130)
+    ``torch.istft(view_as_complex(esti.permute(0,3,2,1)), fft_num, win_shift, win_size, hann)`` in one
+    HIP kernel: (B, 2, T, F) -> (B, win_shift*(T-1)).  Like the reference it inverts the estimate as
+    it is (compressed domain)."""
+    if not esti_stft.is_cuda:
+        raise _lib.EabError("istft needs a CUDA (ROCm) tensor; there is no CPU fallback by design.")
+    if esti_stft.ndim != 4 or esti_stft.shape[1] != 2 or esti_stft.shape[3] != fft_num // 2 + 1:
+        raise ValueError(f"expected (B,2,T,{fft_num // 2 + 1}), got {tuple(esti_stft.shape)}")
+    if window.numel() != fft_num or 2 * win_shift != fft_num:
+        raise NotImplementedError("the HIP back end implements win_size == fft_num == 2*win_shift (the reference's 320/160)")
+    lib = _lib.load()
+    B, _, T, _ = esti_stft.shape
+    x = esti_stft.detach().to(torch.float32).contiguous()
+    window = window.to(device=x.device, dtype=torch.float32).contiguous()
+    wav = torch.empty((B, win_shift * (T - 1)), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.eab_istft_f32(x.data_ptr(), window.data_ptr(), _twiddle(fft_num, x.device).data_ptr(),
+                                     wav.data_ptr(), B, T, fft_num, win_shift,
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), "eab_istft_f32")
+    return wav
+
+
 def filter_and_sum(w: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """Stand-alone K13 (reference EaBNet.py:114-117): (B,T,F,M,2)^2 -> (B,2,T,F)."""
     if not (w.is_cuda and x.is_cuda):

@@ -69,6 +69,21 @@ int eab_stft_frames_f32(const float* wav, float* frames, int N, int L, int n_fft
                         eab_stream_t stream);
 
 /* --------------------------------------------------------------------------
+ * ISTFT back end.  Replaces enhance.py:59-62, test.py:189-191,
+ * train_distributed.py:128-130:
+ *     esti.permute(0,3,2,1) -> view_as_complex -> torch.istft(fft_num, win_shift, win_size, hann)
+ * (centre-trimmed, window-envelope normalised overlap-add of the irfft frames; imaginary parts of
+ * the DC / Nyquist bins ignored as in any C2R transform).  Applied, as in the reference, to the
+ * compressed-domain estimate without decompression.
+ *   spec    [B][2][T][F]  estimate, F = n_fft/2+1, T >= 2
+ *   window  [n_fft], twiddle [n_fft][2] as for eab_stft_compress_f32
+ *   wav     [B][hop*(T-1)]
+ * hop must equal n_fft/2 (the reference's 320/160), else EAB_EUNSUPPORTED.
+ * ------------------------------------------------------------------------ */
+int eab_istft_f32(const float* spec, const float* window, const float* twiddle, float* wav, int B, int T,
+                  int n_fft, int hop, eab_stream_t stream);
+
+/* --------------------------------------------------------------------------
  * K13  complex filter-and-sum, stand-alone.   Replaces EaBNet.py:114-117.
  *   w, x [B][T][F][M][2] -> y [B][2][T][F];  Y = sum_m W_m * X_m (no conjugate)
  * ------------------------------------------------------------------------ */

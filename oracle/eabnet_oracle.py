@@ -92,6 +92,24 @@ def prepare_data_oracle(x: torch.Tensor, target: Optional[torch.Tensor], n_fft: 
     return noisy, tgt
 
 
+def istft_oracle(esti: torch.Tensor, n_fft: int = 320, hop: int = 160) -> torch.Tensor:
+    """Back end of enhance.py:59-62 spelled out: (B,2,T,F) -> (B, hop*(T-1)).
+    irfft per frame (imaginary parts of DC/Nyquist ignored), synthesis window, overlap-add,
+    division by the overlap-added squared window, n_fft/2 trimmed from both ends
+    (torch.istft with center=True, length=None)."""
+    B, _, T, Fq = esti.shape
+    X = torch.complex(esti[:, 0], esti[:, 1])                        # (B,T,F)
+    w = hann_periodic(n_fft, esti.dtype)
+    fr = torch.fft.irfft(X, n=n_fft, dim=-1) * w                     # (B,T,n_fft)
+    full = n_fft + hop * (T - 1)
+    y = esti.new_zeros(B, full)
+    env = esti.new_zeros(full)
+    for t in range(T):
+        y[:, t * hop:t * hop + n_fft] += fr[:, t]
+        env[t * hop:t * hop + n_fft] += w * w
+    return y[:, n_fft // 2:full - n_fft // 2] / env[n_fft // 2:full - n_fft // 2]
+
+
 # ----------------------------------------------------------------------------
 # network blocks
 # ----------------------------------------------------------------------------

@@ -179,10 +179,24 @@ def main_variants():
         json.dump(inventory, f)
 
 
+def main_istft():
+    """Back end: the reference's call (enhance.py:59-62) on seeded (B,2,T,F) estimates; the inputs
+    carry non-zero imaginary DC/Nyquist bins, which torch.istft ignores."""
+    for (B, T, seed) in ((1, 2, 20), (2, 9, 21), (3, 40, 22)):
+        esti = torch.from_numpy(paramgen.make_spec_input(B, T, 161, 1, seed)[..., 0, :]).permute(0, 3, 1, 2).contiguous()
+        x = esti.permute(0, 3, 2, 1)
+        wav = torch.istft(torch.view_as_complex(x.contiguous()), N_FFT, HOP, N_FFT, torch.hann_window(N_FFT))
+        assert wav.shape == (B, HOP * (T - 1))
+        save(f"istft_B{B}_T{T}.npz", wav=wav.numpy(), seed=seed)
+
+
 if __name__ == "__main__":
     with torch.no_grad():
         if sys.argv[1:] == ["variants"]:
             main_variants()
+        elif sys.argv[1:] == ["istft"]:
+            main_istft()
         else:
             main()
             main_variants()
+            main_istft()

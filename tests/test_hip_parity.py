@@ -73,6 +73,39 @@ def test_stft_compress_sixteen_mics_vs_oracle(dev):
     assert_compressed_close(got.numpy(), want.numpy(), TOL_HIP)
 
 
+@pytest.mark.parametrize("B,T", [(1, 2), (2, 9), (3, 40)])
+def test_istft_vs_reference_fixtures(dev, B, T):
+    import eabnet_amd
+    g = load(f"istft_B{B}_T{T}.npz")
+    esti = torch.from_numpy(paramgen.make_spec_input(B, T, 161, 1, int(g["seed"]))[..., 0, :]).permute(0, 3, 1, 2)
+    wav = eabnet_amd.istft(esti.to(dev), 320, 160, torch.hann_window(320))          # non-contiguous input on purpose
+    assert wav.shape == (B, 160 * (T - 1))
+    assert_close(wav.cpu().numpy(), g["wav"], 1e-5, "istft")
+
+
+def test_istft_full_size_vs_oracle_and_properties(dev):
+    """C2 size (16 x 401 frames): against the oracle, linearity, and 'a frame only reaches the two
+    segments it overlaps' (locality of the overlap-add)."""
+    import eabnet_amd
+    from oracle import eabnet_oracle as orc
+    B, T = 16, 401
+    win = torch.hann_window(320)
+    a = torch.from_numpy(paramgen.make_spec_input(B, T, 161, 1, 50)[..., 0, :]).permute(0, 3, 1, 2).contiguous()
+    b = torch.from_numpy(paramgen.make_spec_input(B, T, 161, 1, 51)[..., 0, :]).permute(0, 3, 1, 2).contiguous()
+    ya, yb = eabnet_amd.istft(a.to(dev), 320, 160, win), eabnet_amd.istft(b.to(dev), 320, 160, win)
+    assert ya.shape == (B, 64000)
+    assert_close(ya.cpu().numpy(), orc.istft_oracle(a).numpy(), 1e-5, "istft C2")
+    yab = eabnet_amd.istft((2.0 * a - 0.5 * b).to(dev), 320, 160, win)
+    assert_close(yab.cpu().numpy(), (2.0 * ya - 0.5 * yb).cpu().numpy(), 1e-5, "linearity")
+    c = a.clone()
+    c[:, :, 200] += 1.0                                   # perturb one frame
+    yc = eabnet_amd.istft(c.to(dev), 320, 160, win)
+    changed = (yc != ya).any(0).nonzero().flatten()
+    assert changed.min() >= 160 * 199 and changed.max() < 160 * 201
+    with pytest.raises(NotImplementedError):
+        eabnet_amd.istft(a.to(dev), 320, 80, win)
+
+
 def test_filter_sum_vs_oracle_and_linearity(dev):
     import eabnet_amd
     from oracle import eabnet_oracle as orc

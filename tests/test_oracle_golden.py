@@ -186,3 +186,14 @@ def test_oracle_constructor_variants_match_reference(name):
         y = orc.eabnet_forward(P, x, **e["kwargs"])
     assert tuple(y.shape) == tuple(g["out"].shape)
     assert_close(y.numpy(), g["out"], TOL_ORACLE, name)
+
+
+@pytest.mark.parametrize("B,T", [(1, 2), (2, 9), (3, 40)])
+def test_istft_oracle_matches_reference_call(B, T):
+    """Back end: the spelled-out irfft / window / overlap-add / envelope / trim
+    against torch.istft called exactly as enhance.py:59-62 does."""
+    g = load(f"istft_B{B}_T{T}.npz")
+    esti = torch.from_numpy(paramgen.make_spec_input(B, T, 161, 1, int(g["seed"]))[..., 0, :]).permute(0, 3, 1, 2)
+    wav = orc.istft_oracle(esti.contiguous())
+    assert wav.shape == (B, 160 * (T - 1))
+    assert_close(wav.numpy(), g["wav"], TOL_ORACLE, "istft")
