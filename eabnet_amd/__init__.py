@@ -7,9 +7,11 @@ Importing the package does not touch the GPU; the HIP library
 (eabnet_amd/lib/libeabnet_hip.so) is loaded on first use and its absence is an
 error, never a fallback.
 """
-from .spec import NetConfig, param_specs  # noqa: F401
-from .model import (EaBNet, prepare_data, stft_compress, istft, filter_and_sum, numParams,  # noqa: F401
-                    com_mag_mse_loss)
+from .spec import GagConfig, NetConfig, gag_param_specs, param_specs  # noqa: F401
+from .model import (EaBNet, GaGNet, EaBNetWithPostNet, make_gag_net, make_eabnet_with_postnet,  # noqa: F401
+                    prepare_data, stft_compress, istft, filter_and_sum, numParams, com_mag_mse_loss,
+                    stagewise_com_mag_mse_loss)
 
-__all__ = ["EaBNet", "prepare_data", "stft_compress", "istft", "filter_and_sum", "numParams", "com_mag_mse_loss",
-           "NetConfig", "param_specs"]
+__all__ = ["EaBNet", "GaGNet", "EaBNetWithPostNet", "make_gag_net", "make_eabnet_with_postnet", "prepare_data",
+           "stft_compress", "istft", "filter_and_sum", "numParams", "com_mag_mse_loss", "stagewise_com_mag_mse_loss",
+           "NetConfig", "GagConfig", "param_specs", "gag_param_specs"]

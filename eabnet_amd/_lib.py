@@ -56,6 +56,8 @@ _SIGS = {
     "eab_stft_frames_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
     "eab_filter_sum_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
     "eab_istft_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
+    "eab_gag_pack_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
+    "eab_gag_crm_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 6 + [C.c_void_p]),
     "eab_conv_tiles": (C.c_int, [C.c_int] * 3),
     "eab_conv_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "eab_in_finalize_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_float] + [C.c_void_p] * 6 + [C.c_void_p]),

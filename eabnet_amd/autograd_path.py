@@ -145,3 +145,65 @@ def forward_autograd(m, inpt: torch.Tensor) -> torch.Tensor:
     w = F.linear(h, m.get_parameter("bf_map.w_dnn.2.weight"), m.get_parameter("bf_map.w_dnn.2.bias")).view(B, T, Fq, M, 2)
     wr, wi, xr, xi = w[..., 0], w[..., 1], inpt[..., 0], inpt[..., 1]
     return torch.stack(((wr * xr - wi * xi).sum(-1), (wr * xi + wi * xr).sum(-1)), dim=1)
+
+
+# ----------------------------------------------------------------------------
+# GaGNet post-filter (reference GaGNet.py:76-133), differentiable
+# ----------------------------------------------------------------------------
+def _gag_tcm(m, x, pre: str, dilation: int):
+    span = (m.kd1 - 1) * dilation
+    pad = (span, 0) if m.is_causal else (span // 2, span // 2)
+    y = F.conv1d(x, m.get_parameter(f"{pre}.in_conv.weight"))
+    y = _norm(m, F.prelu(y, m.get_parameter(f"{pre}.d_conv.0.weight")), f"{pre}.d_conv.1")
+    y = F.conv1d(F.pad(y, pad), m.get_parameter(f"{pre}.d_conv.3.weight"), dilation=dilation)
+    y = _norm(m, F.prelu(y, m.get_parameter(f"{pre}.out_conv.0.weight")), f"{pre}.out_conv.1")
+    return F.conv1d(y, m.get_parameter(f"{pre}.out_conv.2.weight")) + x
+
+
+def _gag_chain(m, x, pre: str):
+    for j in range(m.p):
+        for k, d in enumerate(m.dilas):
+            x = _gag_tcm(m, x, f"{pre}.{j}.tcns.{k}", d)
+    return x
+
+
+def forward_gagnet(m, inpt: torch.Tensor, pre_x: torch.Tensor) -> list:
+    """inpt, pre_x (B,2,T,F) -> list of q (B,2,F,T), differentiable."""
+    B, _, T, Fq = inpt.shape
+    x = torch.cat([inpt, pre_x], dim=1)
+    if m.is_u2:
+        for i in range(4):
+            x = _unet(m, x, f"en.meta_unet_list.{i}", 4 - i, False)
+        x = _norm_act(m, _gate_conv(m, x, "en.last_conv.0.conv.1"), "en.last_conv.1", "en.last_conv.2")
+    else:
+        for i in range(5):
+            q = f"en.unet_list.{i}"
+            x = _norm_act(m, _gate_conv(m, x, f"{q}.0.conv.1"), f"{q}.1", f"{q}.2")
+    feat = x.transpose(-2, -1).contiguous().view(B, -1, T)
+    pre = pre_x.transpose(-2, -1).contiguous()
+    act = {"sigmoid": torch.sigmoid, "tanh": torch.tanh, "relu": torch.relu}[m.acti_type]
+    outs = []
+    for g in range(m.q):
+        gl, gz = f"gags.{g}.glance_block", f"gags.{g}.gaze_block"
+        cat = torch.cat((feat, pre.view(B, -1, T)), dim=1)
+
+        def gated(pfx):
+            return F.conv1d(cat, m.get_parameter(f"{pfx}.in_conv_main.weight"), m.get_parameter(f"{pfx}.in_conv_main.bias")) \
+                * torch.sigmoid(F.conv1d(cat, m.get_parameter(f"{pfx}.in_conv_gate.0.weight"),
+                                         m.get_parameter(f"{pfx}.in_conv_gate.0.bias")))
+
+        xg = _gag_chain(m, gated(gl), f"{gl}.tcn_g")
+        gain = act(F.conv1d(xg, m.get_parameter(f"{gl}.linear_g.0.weight"), m.get_parameter(f"{gl}.linear_g.0.bias")))
+        xz = gated(gz)
+        if m.is_squeezed:
+            xr = xi = _gag_chain(m, xz, f"{gz}.tcm_ri")
+        else:
+            xr, xi = _gag_chain(m, xz, f"{gz}.tcm_r"), _gag_chain(m, xz, f"{gz}.tcm_i")
+        resi = torch.stack((F.conv1d(xr, m.get_parameter(f"{gz}.linear_r.weight"), m.get_parameter(f"{gz}.linear_r.bias")),
+                            F.conv1d(xi, m.get_parameter(f"{gz}.linear_i.weight"), m.get_parameter(f"{gz}.linear_i.bias"))),
+                           dim=1)
+        mag, ph = torch.norm(pre, dim=1), torch.atan2(pre[:, -1], pre[:, 0])              # GaGNet.py:129-132
+        filt = mag * gain
+        pre = torch.stack((filt * torch.cos(ph), filt * torch.sin(ph)), dim=1) + resi
+        outs.append(pre)
+    return outs

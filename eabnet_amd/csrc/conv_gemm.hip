@@ -912,7 +912,7 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
         return cg_pick_ku<1, 2, CG_DUAL, EAB_XF_PRELU_NORM, true>(d, s, ku == 2 ? 1 : ku);
     }
     if (glu) {
-        if (d->N != 128 || xf == EAB_XF_PRELU_NORM) return EAB_EUNSUPPORTED;
+        if (d->N % 128 != 0 || xf == EAB_XF_PRELU_NORM) return EAB_EUNSUPPORTED;   // N > 128: GaGNet's gated in-convs
         if (!vec) return mi == 2 ? cg_pick_ku<2, 2, CG_GLU, 0, false>(d, s, 1) : cg_pick_ku<1, 2, CG_GLU, 0, false>(d, s, 1);
         if (xf == EAB_XF_NORM_PRELU)    // gated conv on raw producers (plain U-Net, is_u2 = False)
             return mi == 2 ? cg_pick_ku<2, 2, CG_GLU, EAB_XF_NORM_PRELU, true>(d, s, ku)

@@ -1,5 +1,5 @@
-// Program runner + ABI housekeeping.  The op list is the whole
-// EaBNet.forward (reference EaBNet.py:88-117) lowered by eabnet_amd/program.py.
+// Program runner + ABI housekeeping.  The op list is the whole EaBNet.forward (reference
+// EaBNet.py:88-117) or GaGNet.forward (GaGNet.py:76-90) lowered by eabnet_amd/program.py.
 #include "common.h"
 
 // Zero fill as a KERNEL: a hipMemsetAsync captured into a hipGraph was observed (ROCm 7.2, 6.5 MB) not
@@ -66,6 +66,15 @@ extern "C" int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream
                 rc = eab_hip_status(hipGetLastError());
                 break;
             }
+            case EAB_OP_GAG_PACK:
+                rc = eab_gag_pack_f32((const float*)o.p[0], (const float*)o.p[1], (float*)o.p[2], (float*)o.p[3], o.i[0],
+                                      o.i[1], o.i[2], o.i[3], stream);
+                break;
+            case EAB_OP_GAG_CRM:
+                rc = eab_gag_crm_f32((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
+                                     (const float*)o.p[3], (float*)o.p[4], (float*)o.p[5], o.i[0], o.i[1], o.i[2], o.i[3],
+                                     o.i[4], o.i[5], stream);
+                break;
             default:
                 rc = EAB_EINVAL;
         }

@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from . import _lib
 from . import program as prg
-from .spec import NetConfig, ParamSpec, param_specs
+from .spec import GagConfig, NetConfig, ParamSpec, gag_param_specs, param_specs
 
 
 # ----------------------------------------------------------------------------
@@ -87,23 +87,29 @@ class _Bound:
         # hipGraph replay (optional): static boundary buffers + the captured program
         self.graph = None
         self.static_in = None
+        self.static_in2 = None
         self.static_out = None
         self.graph_failed = False
 
-    def capture(self, B: int, T: int, F: int, M: int) -> bool:
+    def capture(self, in_shape, out_shape, in2_shape=None) -> bool:
         """Capture the whole op program into a hipGraph bound to static in/out buffers.  Replaying it
         costs one graph launch instead of ~250 kernel launches enqueued by the host.  Returns False
         (and stays on direct launches) if the runtime refuses the capture."""
         if self.graph is not None or self.graph_failed:
             return self.graph is not None
         try:
-            self.static_in = torch.empty((B, T, F, M, 2), dtype=torch.float32, device=self.device)
-            self.static_out = torch.empty((B, 2, T, F), dtype=torch.float32, device=self.device)
-            self.bind(self.static_in.data_ptr(), self.static_out.data_ptr())
+            self.static_in = torch.empty(in_shape, dtype=torch.float32, device=self.device)
+            self.static_out = torch.empty(out_shape, dtype=torch.float32, device=self.device)
+            if in2_shape is not None:
+                self.static_in2 = torch.empty(in2_shape, dtype=torch.float32, device=self.device)
+            self.bind(self.static_in.data_ptr(), self.static_out.data_ptr(),
+                      self.static_in2.data_ptr() if in2_shape is not None else None)
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                 # warm-up outside the capture
                 self.static_in.zero_()
+                if self.static_in2 is not None:
+                    self.static_in2.zero_()
                 self.run(side.cuda_stream)
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
@@ -114,7 +120,7 @@ class _Bound:
             import warnings
             warnings.warn(f"eabnet_amd: hipGraph capture failed ({e!r}); using direct launches")
             self.graph, self.graph_failed = None, True
-            self._in_ptr = self._out_ptr = None
+            self._in_ptr = None
         return self.graph is not None
 
     def update_weights(self, flat: np.ndarray) -> None:
@@ -125,10 +131,10 @@ class _Bound:
             return None
         return bases[ref.arena] + 4 * ref.off
 
-    def bind(self, in_ptr: int, out_ptr: int) -> None:
-        if (in_ptr, out_ptr) == (self._in_ptr, self._out_ptr):
+    def bind(self, in_ptr: int, out_ptr: int, in2_ptr: Optional[int] = None) -> None:
+        if (in_ptr, out_ptr, in2_ptr) == self._in_ptr:
             return
-        bases = {"w": self.weights.data_ptr(), "a": self.acts.data_ptr(), "in": in_ptr, "out": out_ptr}
+        bases = {"w": self.weights.data_ptr(), "a": self.acts.data_ptr(), "in": in_ptr, "out": out_ptr, "in2": in2_ptr}
         A = lambda r: self._addr(r, bases)  # noqa: E731
         for k, op in enumerate(self.prog.ops):
             o = self.ops[k]
@@ -171,14 +177,55 @@ class _Bound:
                 o.i[0] = C.c_int32(nbytes & 0xFFFFFFFF).value
                 o.i[1] = nbytes >> 32
                 o.p[0] = A(op.ptr)
+            elif op.kind == prg.OP_GAG_PACK:
+                o.i[0:4] = [op.B, op.T, op.F, prg.GAG_PRE_LD]
+                for j, r in enumerate((op.inpt, op.pre_x, op.enc_in, op.pre)):
+                    o.p[j] = A(r)
+            elif op.kind == prg.OP_GAG_CRM:
+                o.i[0:6] = [op.B, op.T, op.F, prg.GAG_PRE_LD, prg.GAG_LIN_LD, op.act]
+                for j, r in enumerate((op.pre, op.g, op.r, op.i, op.pre_out, op.planar)):
+                    o.p[j] = A(r)
             else:
                 raise ValueError(op.kind)
-        self._in_ptr, self._out_ptr = in_ptr, out_ptr
+        self._in_ptr, self._out_ptr = (in_ptr, out_ptr, in2_ptr), None
 
-    def run(self, stream: int, first: int = 0, count: Optional[int] = None) -> None:
-        n = len(self.prog.ops) - first if count is None else count
+    def _launch(self, stream: int, first: int, n: int) -> None:
         ops = C.cast(C.byref(self.ops, first * C.sizeof(_lib.Op)), C.POINTER(_lib.Op))
         _lib.check(_lib.load().eab_run_program(ops, n, C.c_void_p(stream)), "eab_run_program")
+
+    def run(self, stream: int, first: int = 0, count: Optional[int] = None) -> None:
+        """Enqueue ops [first, first+count) on ``stream`` (a raw hipStream_t).  Programs with parallel
+        branches (prog.sync) fork onto side streams with events -- inside a hipGraph capture these become
+        graph edges, so the branches replay concurrently."""
+        n = len(self.prog.ops) - first if count is None else count
+        if not self.prog.sync or count is not None:
+            return self._launch(stream, first, n)         # single lane (or a single-op debug launch)
+        main = torch.cuda.current_stream()
+        assert main.cuda_stream == stream, "multi-lane programs run on torch's current stream"
+        if not hasattr(self, "_side"):
+            self._side = {}
+        lanes, sync = self.prog.lanes, self.prog.sync
+        streams = {0: main}
+        k = first
+        end = first + n
+        while k <= end:
+            for what, ls in sync.get(k, ()):
+                for l in ls:
+                    if l not in self._side:
+                        self._side[l] = torch.cuda.Stream(device=self.device)
+                    streams[l] = self._side[l]
+                    if what == "fork":
+                        streams[l].wait_stream(main)
+                    else:
+                        main.wait_stream(streams[l])
+            if k == end:
+                break
+            j = k + 1
+            while j < end and lanes[j] == lanes[k] and j not in sync:
+                j += 1
+            with torch.cuda.stream(streams[lanes[k]]):
+                self._launch(streams[lanes[k]].cuda_stream, k, j - k)
+            k = j
 
     def view(self, act: prg.Act) -> torch.Tensor:
         """Debug view of a named activation as (B, T, F, C)."""
@@ -191,45 +238,25 @@ class _Bound:
 # ----------------------------------------------------------------------------
 # the module
 # ----------------------------------------------------------------------------
-class EaBNet(nn.Module):
-    """MI355X implementation of the reference ``EaBNet`` (EaBNet.py:9-125).
+class _HipModule(nn.Module):
+    """Shared machinery of the two networks: reference-keyed parameters, the lowered-program cache
+    (one resident shape, re-packed when a parameter or buffer changes) and the replay knobs."""
 
-    Same constructor keywords and defaults, same ``forward`` signature:
-    ``inpt`` (B, T, F, M, 2) [or (B, T, F, 2) for one microphone] ->
-    (B, 2, T, F), same state-dict keys.  ``torch.no_grad()`` / ``requires_grad=False`` calls run
-    the hand-written HIP program (CUDA tensors only, no fallback).  A call that must be
-    differentiable (training: train.py / train_distributed.py) is evaluated by
-    eabnet_amd/autograd_path.py with PyTorch-ROCm operators so that backward, the optimiser and
-    DistributedDataParallel work; hand-written backward kernels are a later row.
-    """
-
-    def __init__(self, k1: tuple = (2, 3), k2: tuple = (1, 3), c: int = 64, M: int = 9, embed_dim: int = 64,
-                 kd1: int = 5, cd1: int = 64, d_feat: int = 256, p: int = 6, q: int = 3, is_causal: bool = True,
-                 is_u2: bool = True, bf_type: str = "lstm", topo_type: str = "mimo", intra_connect: str = "cat",
-                 norm_type: str = "IN"):
-        super().__init__()
-        self.k1, self.k2, self.c, self.M, self.embed_dim = tuple(k1), tuple(k2), c, M, embed_dim
-        self.kd1, self.cd1, self.d_feat, self.p, self.q = kd1, cd1, d_feat, p, q
-        self.is_causal, self.is_u2, self.bf_type = is_causal, is_u2, bf_type
-        self.topo_type, self.intra_connect, self.norm_type = topo_type, intra_connect, norm_type
-        self.cfg = NetConfig(k1=tuple(k1), k2=tuple(k2), c=c, M=M, embed_dim=embed_dim, kd1=kd1, cd1=cd1,
-                             d_feat=d_feat, p=p, q=q, is_causal=is_causal, is_u2=is_u2, bf_type=bf_type,
-                             topo_type=topo_type, intra_connect=intra_connect, norm_type=norm_type)
-        self._specs = param_specs(self.cfg)          # raises NotImplementedError for unsupported topologies
-        for key, spec in self._specs.items():
+    def _init_params(self, specs) -> None:
+        self._specs = specs
+        for key, spec in specs.items():
             t = _default_init(spec)
             _attach(self, key, t if spec.is_buffer else nn.Parameter(t))
         self._bound: Dict[tuple, _Bound] = {}
         self._packed_version: Dict[tuple, tuple] = {}
         self.dump_bfw = False                         # tests: also emit the (B,T,F,M,2) beam-forming weights
         # replay the lowered program as ONE hipGraph launch (static internal in/out buffers, one
-        # device copy of the input and of the output per call); False = ~250 direct kernel launches
+        # device copy of the input and of the output per call); False = direct kernel launches
         self.use_graph = True
         # arithmetic of the MFMA contractions: "f32" = exact fp32 MFMA; "f16x3" = error-compensated
         # fp16 split on the f16 matrix cores (DESIGN.md §4.4), same end-to-end error class as fp32
         self.precision = "f32"
 
-    # -- program cache -----------------------------------------------------------
     def _param_fingerprint(self) -> tuple:
         return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
@@ -255,6 +282,38 @@ class EaBNet(nn.Module):
             self._packed_version[key] = fp
         return bound
 
+    def _needs_graph(self, *inputs) -> bool:
+        needs = torch.is_grad_enabled() and (any(x.requires_grad for x in inputs)
+                                             or any(p.requires_grad for p in self.parameters()))
+        return needs or (self.norm_type == "BN" and self.training)
+
+
+class EaBNet(_HipModule):
+    """MI355X implementation of the reference ``EaBNet`` (EaBNet.py:9-125).
+
+    Same constructor keywords and defaults, same ``forward`` signature:
+    ``inpt`` (B, T, F, M, 2) [or (B, T, F, 2) for one microphone] ->
+    (B, 2, T, F), same state-dict keys.  ``torch.no_grad()`` / ``requires_grad=False`` calls run
+    the hand-written HIP program (CUDA tensors only, no fallback).  A call that must be
+    differentiable (training: train.py / train_distributed.py) is evaluated by
+    eabnet_amd/autograd_path.py with PyTorch-ROCm operators so that backward, the optimiser and
+    DistributedDataParallel work; hand-written backward kernels are a later row.
+    """
+
+    def __init__(self, k1: tuple = (2, 3), k2: tuple = (1, 3), c: int = 64, M: int = 9, embed_dim: int = 64,
+                 kd1: int = 5, cd1: int = 64, d_feat: int = 256, p: int = 6, q: int = 3, is_causal: bool = True,
+                 is_u2: bool = True, bf_type: str = "lstm", topo_type: str = "mimo", intra_connect: str = "cat",
+                 norm_type: str = "IN"):
+        super().__init__()
+        self.k1, self.k2, self.c, self.M, self.embed_dim = tuple(k1), tuple(k2), c, M, embed_dim
+        self.kd1, self.cd1, self.d_feat, self.p, self.q = kd1, cd1, d_feat, p, q
+        self.is_causal, self.is_u2, self.bf_type = is_causal, is_u2, bf_type
+        self.topo_type, self.intra_connect, self.norm_type = topo_type, intra_connect, norm_type
+        self.cfg = NetConfig(k1=tuple(k1), k2=tuple(k2), c=c, M=M, embed_dim=embed_dim, kd1=kd1, cd1=cd1,
+                             d_feat=d_feat, p=p, q=q, is_causal=is_causal, is_u2=is_u2, bf_type=bf_type,
+                             topo_type=topo_type, intra_connect=intra_connect, norm_type=norm_type)
+        self._init_params(param_specs(self.cfg))     # raises NotImplementedError for unsupported topologies
+
     # -- forward -------------------------------------------------------------------
     def forward(self, inpt: torch.Tensor) -> torch.Tensor:
         """:param inpt: (B, T, F, M, 2) compressed multichannel spectrogram
@@ -263,8 +322,7 @@ class EaBNet(nn.Module):
             inpt = inpt.unsqueeze(-2)
         if inpt.ndim != 5 or inpt.shape[-1] != 2 or inpt.shape[-2] != self.M:
             raise ValueError(f"expected (B,T,F,{self.M},2), got {tuple(inpt.shape)}")
-        needs_graph = torch.is_grad_enabled() and (inpt.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if needs_graph or (self.norm_type == "BN" and self.training):
+        if self._needs_graph(inpt):
             # training: autograd needs a graph (or BatchNorm must see and update batch statistics)
             # -> PyTorch-ROCm operator path (autograd_path.py)
             from .autograd_path import forward_autograd
@@ -278,7 +336,7 @@ class EaBNet(nn.Module):
         with torch.cuda.device(x.device):
             bound = self._program(B, T, F, x.device)
             if self.use_graph and not self.dump_bfw and not torch.cuda.is_current_stream_capturing() \
-                    and bound.capture(B, T, F, M):
+                    and bound.capture((B, T, F, M, 2), (B, 2, T, F)):
                 bound.static_in.copy_(x, non_blocking=True)
                 bound.graph.replay()
                 out = bound.static_out.clone()
@@ -292,6 +350,102 @@ class EaBNet(nn.Module):
             # ``.sum(dim=-1)`` on a (B,T,F) tensor) and returns (B,2,T); kept as is
             out = out.sum(dim=-1)
         return out.to(inpt.dtype)
+
+
+class GaGNet(_HipModule):
+    """MI355X implementation of the reference post-filter ``GaGNet`` (GaGNet.py:5-90): same
+    constructor keywords, same state-dict keys, ``forward(inpt, pre_x)`` with both (B, 2, T, F)
+    returning the list of the q stage estimates, each (B, 2, F, T).  Inference runs the HIP program
+    (U2-encoder on the conv kernels, 24 single-branch S-TCMs per stage, fused gain/residual tail);
+    a call that needs autograd goes through autograd_path.forward_gagnet."""
+
+    def __init__(self, cin: int = 2, k1: tuple = (2, 3), k2: tuple = (1, 3), c: int = 64, kd1: int = 3, cd1: int = 64,
+                 d_feat: int = 256, p: int = 2, q: int = 3, dilas=(1, 2, 5, 9), fft_num: int = 320, is_u2: bool = True,
+                 is_causal: bool = True, is_squeezed: bool = False, acti_type: str = "sigmoid",
+                 intra_connect: str = "cat", norm_type: str = "IN"):
+        super().__init__()
+        self.cin, self.k1, self.k2, self.c, self.kd1, self.cd1 = cin, tuple(k1), tuple(k2), c, kd1, cd1
+        self.d_feat, self.p, self.q, self.dilas, self.fft_num = d_feat, p, q, list(dilas), fft_num
+        self.is_u2, self.is_causal, self.is_squeezed = is_u2, is_causal, is_squeezed
+        self.acti_type, self.intra_connect, self.norm_type = acti_type, intra_connect, norm_type
+        self.cfg = GagConfig(cin=cin, k1=tuple(k1), k2=tuple(k2), c=c, kd1=kd1, cd1=cd1, d_feat=d_feat, p=p, q=q,
+                             dilas=tuple(dilas), fft_num=fft_num, is_u2=is_u2, is_causal=is_causal,
+                             is_squeezed=is_squeezed, acti_type=acti_type, intra_connect=intra_connect,
+                             norm_type=norm_type)
+        self._init_params(gag_param_specs(self.cfg))
+
+    def forward(self, inpt: torch.Tensor, pre_x: torch.Tensor) -> list:
+        """:param inpt, pre_x: (B, 2, T, F) noisy reference-microphone spectrum and previous estimate
+        :return: list of q estimates (B, 2, F, T)   (reference GaGNet.py:76-90)"""
+        if inpt.ndim != 4 or inpt.shape[1] != 2 or inpt.shape[3] != self.cfg.freq or pre_x.shape != inpt.shape:
+            raise ValueError(f"expected two (B,2,T,{self.cfg.freq}) tensors, got {tuple(inpt.shape)} and {tuple(pre_x.shape)}")
+        if self._needs_graph(inpt, pre_x):
+            from .autograd_path import forward_gagnet
+            return forward_gagnet(self, inpt, pre_x)
+        if not (inpt.is_cuda and pre_x.is_cuda):
+            raise _lib.EabError("eabnet_amd.GaGNet inference runs on MI355X only: move the inputs (and module) to "
+                                "'cuda'. There is no CPU fallback by design.")
+        _lib.load()
+        B, _, T, F = inpt.shape
+        a = inpt.detach().to(torch.float32).contiguous()
+        b = pre_x.detach().to(torch.float32).contiguous()
+        with torch.cuda.device(a.device):
+            bound = self._program(B, T, F, a.device)
+            if self.use_graph and not torch.cuda.is_current_stream_capturing() \
+                    and bound.capture((B, 2, T, F), (self.q, B, 2, T, F), (B, 2, T, F)):
+                bound.static_in.copy_(a, non_blocking=True)
+                bound.static_in2.copy_(b, non_blocking=True)
+                bound.graph.replay()
+                out = bound.static_out.clone()
+            else:
+                out = torch.empty((self.q, B, 2, T, F), dtype=torch.float32, device=a.device)
+                bound.bind(a.data_ptr(), out.data_ptr(), b.data_ptr())
+                bound.run(torch.cuda.current_stream().cuda_stream)
+        self._last = (bound, a, b)
+        out = out.to(inpt.dtype)
+        return [out[j].permute(0, 1, 3, 2) for j in range(self.q)]
+
+
+def make_gag_net(args) -> GaGNet:
+    """Reference GaGNet.py:651-671 (reads the ``gagnet_*`` fields of ``args``), on cuda:current."""
+    return GaGNet(cin=2, k1=args.gagnet_k1, k2=args.gagnet_k2, c=args.gagnet_c, kd1=args.gagnet_kd1, cd1=args.gagnet_cd1,
+                  d_feat=args.gagnet_d_feat, p=args.gagnet_p, q=args.gagnet_q, dilas=args.gagnet_dilas,
+                  fft_num=args.gagnet_fft_num, is_u2=args.gagnet_is_u2, is_causal=args.gagnet_is_causal,
+                  is_squeezed=args.gagnet_is_squeezed, acti_type=args.gagnet_acti_type,
+                  intra_connect=args.gagnet_intra_connect, norm_type=args.gagnet_norm_type).cuda()
+
+
+class EaBNetWithPostNet(nn.Module):
+    """Reference EaBNet.py:127-155: beam-former, then the GaGNet post-filter on (reference microphone,
+    detached beam-former estimate).  Same ``args`` fields, ``eabnet.`` / ``postnet.`` key prefixes and
+    output dictionary."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.eabnet = EaBNet(k1=args.k1, k2=args.k2, c=args.c, M=args.M, embed_dim=args.embed_dim, kd1=args.kd1,
+                             cd1=args.cd1, d_feat=args.d_feat, p=args.p, q=args.q, is_causal=args.is_causal,
+                             is_u2=args.is_u2, bf_type=args.bf_type, topo_type=args.topo_type,
+                             intra_connect=args.intra_connect, norm_type=args.norm_type)
+        self.ref_mic = args.ref_mic
+        self.postnet = make_gag_net(args)
+        if args.freeze_eabnet:
+            self.freeze_eabnet()
+
+    def forward(self, noisy_stft: torch.Tensor) -> dict:
+        esti0_stft = self.eabnet(noisy_stft)
+        inpt = noisy_stft[..., self.ref_mic, :].permute(0, 3, 1, 2)            # 'b t f c -> b c t f'
+        esti1_stft_list = self.postnet(inpt, esti0_stft.detach())
+        return {"esti0_stft": esti0_stft, "esti1_stft_list": esti1_stft_list,
+                "esti_stft": esti1_stft_list[-1].permute(0, 1, 3, 2)}
+
+    def freeze_eabnet(self) -> None:
+        for p in self.eabnet.parameters():
+            p.requires_grad = False
+
+
+def make_eabnet_with_postnet(args) -> EaBNetWithPostNet:
+    """Reference EaBNet.py:815-816."""
+    return EaBNetWithPostNet(args)
 
 
 # ----------------------------------------------------------------------------
@@ -400,4 +554,21 @@ def com_mag_mse_loss(esti: torch.Tensor, label: torch.Tensor, frame_list) -> tor
     mag_e, mag_l = torch.norm(esti, dim=1), torch.norm(label, dim=1)
     loss1 = (((mag_e - mag_l) ** 2.0) * mask).sum() / mask.sum()
     loss2 = (((esti - label) ** 2.0) * com_mask).sum() / com_mask.sum()
+    return 0.5 * (loss1 + loss2)
+
+
+def stagewise_com_mag_mse_loss(esti_list, label: torch.Tensor, frame_list) -> torch.Tensor:
+    """Reference GaGNet.py:601-619: the complex + magnitude MSE of every stage, weight 0.1 (1 for the
+    last stage).  esti (B,2,F,T) each, label (B,2,F,T)."""
+    B, _, Fq, T = label.shape
+    mask = torch.zeros((B, Fq, T), dtype=label.dtype, device=label.device)
+    for i, n in enumerate(frame_list):
+        mask[i, :, :n] = 1.0
+    com_mask = torch.stack((mask, mask), dim=1)
+    loss1 = loss2 = 0.0
+    mag_label = torch.norm(label, dim=1)
+    for i, e in enumerate(esti_list):
+        alpha = 1.0 if i == len(esti_list) - 1 else 0.1
+        loss1 = loss1 + alpha * (((e - label) ** 2.0) * com_mask).sum() / com_mask.sum()
+        loss2 = loss2 + alpha * (((torch.norm(e, dim=1) - mag_label) ** 2.0) * mask).sum() / mask.sum()
     return 0.5 * (loss1 + loss2)

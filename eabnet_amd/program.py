@@ -26,12 +26,15 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .spec import NetConfig, param_specs, unet_decoder_layers, unet_encoder_layers
+from .spec import GagConfig, NetConfig, gag_param_specs, param_specs, unet_decoder_layers, unet_encoder_layers
 
 # mirrors of the C enums (include/eabnet_hip.h)
 XF_NONE, XF_NORM_PRELU, XF_PRELU_NORM = 0, 1, 2
 EPI_LINEAR, EPI_GLU, EPI_RELU, EPI_MULSIG, EPI_ADD, EPI_DUALGATE = 0, 1, 2, 3, 4, 5
-OP_CONV, OP_IN_FINALIZE, OP_NORM_ACT, OP_LSTM64, OP_BFW_FS, OP_MEMSET0 = 1, 2, 3, 4, 5, 6
+OP_CONV, OP_IN_FINALIZE, OP_NORM_ACT, OP_LSTM64, OP_BFW_FS, OP_MEMSET0, OP_GAG_PACK, OP_GAG_CRM = 1, 2, 3, 4, 5, 6, 7, 8
+ACT_SIGMOID, ACT_TANH, ACT_RELU = 0, 1, 2
+GAG_PRE_LD = 324   # floats per (b, t) row of the interleaved previous estimate: 2*161 rounded up to a float4
+GAG_LIN_LD = 192   # 161 linear outputs padded to three 64-column tiles
 PREC_F32, PREC_F16X3 = 0, 1
 KORDER_TAP, KORDER_CHUNK = 0, 1
 PATCH_MAX = 352    # CG_PMAX in csrc/conv_gemm.hip
@@ -45,7 +48,7 @@ CUS = 256
 @dataclass(frozen=True)
 class Ref:
     """Symbolic device pointer: float offset into one of the arenas
-    'w' (packed weights), 'a' (activations/workspace), 'in', 'out'."""
+    'w' (packed weights), 'a' (activations/workspace), 'in', 'in2' (second network input), 'out'."""
     arena: str
     off: int = 0
 
@@ -61,6 +64,7 @@ class Act:
     xf: Optional[Ref] = None
     slope: Optional[Ref] = None
     mode: int = XF_NONE
+    raw: bool = False          # un-normalised network input: consumed on exact fp32 in every precision mode
 
 
 @dataclass
@@ -191,6 +195,39 @@ class MemsetOp:
     kind: int = OP_MEMSET0
 
 
+@dataclass
+class GagPackOp:
+    """two planar (B,2,T,F) inputs -> enc_in [B][T][F][4] = (in_r, in_i, pre_r, pre_i) and
+    pre [B][T][GAG_PRE_LD] (channel f*2+ri, zero padded)."""
+    inpt: Ref
+    pre_x: Ref
+    enc_in: Ref
+    pre: Ref
+    B: int
+    T: int
+    F: int
+    name: str = ""
+    kind: int = OP_GAG_PACK
+
+
+@dataclass
+class GagCrmOp:
+    """GlanceGazeModule tail (GaGNet.py:127-133): out = pre * act(g) + (r, i) per TF bin;
+    pre/pre_out [B][T][GAG_PRE_LD], g/r/i [B][T][GAG_LIN_LD], planar [B][2][T][F]."""
+    pre: Ref
+    g: Ref
+    r: Ref
+    i: Ref
+    pre_out: Ref
+    planar: Ref
+    B: int
+    T: int
+    F: int
+    act: int
+    name: str = ""
+    kind: int = OP_GAG_CRM
+
+
 def conv_tiles(T: int, No: int, bm: int) -> int:
     return (T * No + bm - 1) // bm
 
@@ -273,7 +310,7 @@ class WeightArena:
 # ----------------------------------------------------------------------------
 @dataclass
 class Program:
-    cfg: NetConfig
+    cfg: object                    # NetConfig or GagConfig
     B: int
     T: int
     F: int
@@ -282,17 +319,25 @@ class Program:
     act_floats: int                # workspace arena size (floats)
     taps: Dict[str, Act]           # named materialised activations (debug / tests)
     flops: int = 0                 # MAC*2 of all MFMA ops (algorithmic, un-padded)
+    # independent branches (GaGNet's three S-TCM chains per stage): lanes[k] = stream lane of op k,
+    # sync[k] = [("fork" | "join", lanes), ...] applied BEFORE op k (index len(ops) = after the last op).
+    # fork: the lanes wait for lane 0; join: lane 0 waits for the lanes.  Program order is always a
+    # valid sequential order, so an executor may ignore both (tests/emulator.py does).
+    lanes: List[int] = field(default_factory=list)
+    sync: Dict[int, list] = field(default_factory=dict)
 
 
 class Lowering:
-    def __init__(self, cfg: NetConfig, params: Dict[str, np.ndarray], B: int, T: int, F: int = 161,
+    spec_fn = staticmethod(param_specs)
+
+    def __init__(self, cfg, params: Dict[str, np.ndarray], B: int, T: int, F: int = 161,
                  dump_bfw: bool = False, precision: str = "f32"):
         cfg.check_supported()
         if precision not in ("f32", "f16x3"):
             raise ValueError(f"precision must be 'f32' or 'f16x3', got {precision!r}")
         self.precision = precision
         self.patch = os.environ.get("EAB_PATCH", "1") != "0"      # tuning knob: 0 = gather pipeline everywhere
-        specs = param_specs(cfg)
+        specs = self.spec_fn(cfg)
         specs = {k: v for k, v in specs.items() if v.kind != "bn_count"}     # the step counter is not arithmetic
         missing = [k for k in specs if k not in params]
         if missing:
@@ -309,6 +354,23 @@ class Lowering:
         self.dump_bfw = dump_bfw
         self.bn = cfg.norm_type == "BN"
         self.add = cfg.intra_connect == "add"
+        self.lane = 0                  # stream lane given to the ops emitted from now on
+        self._lane_marks: List[Tuple[int, int]] = [(0, 0)]      # (first op index, lane)
+        self.sync: Dict[int, list] = {}
+
+    def __setattr__(self, k, v):
+        if k == "lane" and "_lane_marks" in self.__dict__:
+            self._lane_marks.append((len(self.ops), v))
+        object.__setattr__(self, k, v)
+
+    def mark(self, what: str, lanes) -> None:
+        self.sync.setdefault(len(self.ops), []).append((what, list(lanes)))
+
+    def lane_of_ops(self) -> List[int]:
+        out, marks = [], self._lane_marks + [(len(self.ops), 0)]
+        for (a, lane), (b, _) in zip(marks[:-1], marks[1:]):
+            out += [lane] * (b - a)
+        return out
 
     # -- arenas ---------------------------------------------------------------
     def alloc(self, nfloats: int) -> Ref:
@@ -390,8 +452,8 @@ class Lowering:
             w = self.W.add(key + ".chunk", np.ascontiguousarray(wt.transpose(0, 2, 1, 3)).reshape(N, Kpad))
         # f16x3 needs bounded operands: every source except the raw network input is either
         # instance-normalised or a sum of such tensors; the first conv stays on exact fp32.
-        prec = PREC_F16X3 if (self.precision == "f16x3" and s0.ref.arena != "in" and C0 % 4 == 0 and C1 % 4 == 0) \
-            else PREC_F32
+        prec = PREC_F16X3 if (self.precision == "f16x3" and s0.ref.arena != "in" and C0 % 4 == 0 and C1 % 4 == 0
+                              and not any(s.raw for s in srcs)) else PREC_F32
         if prec == PREC_F16X3:
             key = next(k for k, r in self.W.index.items() if r == w)
             wf = self.W.chunks_by_name[key].reshape(N, Kpad)
@@ -644,7 +706,8 @@ class Lowering:
             self.ops.append(BfwOp(y1=e.ref, w2=self.W.add("bf_map.weight#rows", w2), b2=self.W.add("bf_map.bias#rows", b2),
                                   x=Ref("in"), out=Ref("out"), bfw=bfw, B=B, T=T, F=F, M=M, name="bf_map+fs"))
             self.flops += 2 * B * T * F * 64 * wk.shape[0]
-            return Program(cfg, B, T, F, self.ops, self.W.flat(), self.act_size, self.taps, self.flops)
+            return Program(cfg, B, T, F, self.ops, self.W.flat(), self.act_size, self.taps, self.flops,
+                           lanes=[0] * len(self.ops))
 
         # LSTM_BF (EaBNet.py:600-614)
         h = e
@@ -671,9 +734,135 @@ class Lowering:
         self.ops.append(BfwOp(y1=y1, w2=self.vec("bf_map.w_dnn.2.weight"), b2=self.vec("bf_map.w_dnn.2.bias"),
                               x=Ref("in"), out=Ref("out"), bfw=bfw, B=B, T=T, F=F, M=M, name="bf_map.w_dnn.2+fs"))
         self.flops += 2 * B * T * F * 64 * 2 * M
-        return Program(cfg, B, T, F, self.ops, self.W.flat(), self.act_size, self.taps, self.flops)
+        return Program(cfg, B, T, F, self.ops, self.W.flat(), self.act_size, self.taps, self.flops,
+                       lanes=[0] * len(self.ops))
 
 
-def lower(cfg: NetConfig, params: Dict[str, np.ndarray], B: int, T: int, F: int = 161,
+class GagLowering(Lowering):
+    """GaGNet.forward (reference GaGNet.py:76-90) on the same op vocabulary.  Arenas: 'in' = inpt,
+    'in2' = pre_x, both planar (B,2,T,F); 'out' = the q stage outputs [q][B][2][T][F] (the reference's
+    (B,2,F,T) tensors are permuted views of it).  Every 1-D tensor is [B][T][1][C]."""
+    spec_fn = staticmethod(gag_param_specs)
+
+    def tcm1(self, pre: str, x: Act, dilation: int) -> Act:
+        """GaGNet's single-branch SqueezedTCM (GaGNet.py:303-327): in_conv -> PReLU/norm/dilated conv ->
+        PReLU/norm/out_conv + residual, three launches, InstanceNorm partials reduced by the consumer."""
+        cfg, T, B = self.cfg, self.T, self.B
+        D, cd, kd = cfg.d_feat, cfg.cd1, cfg.kd1
+        bm, bn = 64, self.bn
+        tiles = conv_tiles(T, 1, bm)
+        assert bn or tiles <= 64
+        nD, nO = f"{pre}.d_conv.1", f"{pre}.out_conv.1"
+        slD, slO = self.vec(f"{pre}.d_conv.0.weight"), self.vec(f"{pre}.out_conv.0.weight")
+        wref = self.W.add(f"{pre}.in_conv.weight#packed", pack_taps(self.P[f"{pre}.in_conv.weight"], [0]))
+        y = self.alloc_act(1, cd)
+        st = None if bn else self.alloc(B * tiles * cd * 4)
+        self.emit_conv(f"{pre}.in_conv", [x], wref, None, cd, D, 1, 1, 1, 0, 1, [0], [0], EPI_LINEAR, y,
+                       st, 0 if bn else 1, (None, None) if bn else (slD, None), 0 if bn else tiles, 0, bm)
+        span = (kd - 1) * dilation
+        lead = span if cfg.is_causal else span // 2
+        dts = [j * dilation - lead for j in range(kd)]
+        wd = self.W.add(f"{pre}.d_conv.3.weight#packed", pack_taps(self.P[f"{pre}.d_conv.3.weight"], range(kd)))
+        z = self.alloc_act(1, cd)
+        st2 = None if bn else self.alloc(B * tiles * cd * 4)
+        self.emit_conv(f"{pre}.d_conv", [Act(y, 1, cd, self.bn_xf(nD) if bn else None, slD, XF_PRELU_NORM)], wd, None, cd,
+                       kd * ((cd + 15) // 16) * 16, 1, 1, 1, 0, 1, dts, [0] * kd, EPI_LINEAR, z, st2, 0 if bn else 1,
+                       (None, None) if bn else (slO, None), 0 if bn else tiles, 0, bm,
+                       fin=None if bn else dict(stats=st, tiles=tiles, nsets=1, count=T, norms=[nD]))
+        wo = self.W.add(f"{pre}.out_conv.2.weight#packed", pack_taps(self.P[f"{pre}.out_conv.2.weight"], [0]))
+        xn = self.alloc_act(1, D)
+        self.emit_conv(f"{pre}.out_conv", [Act(z, 1, cd, self.bn_xf(nO) if bn else None, slO, XF_PRELU_NORM)], wo, None,
+                       D, cd, 1, 1, 1, 0, 1, [0], [0], EPI_ADD, xn, bm=bm, aux=x.ref,
+                       fin=None if bn else dict(stats=st2, tiles=tiles, nsets=1, count=T, norms=[nO]))
+        return Act(xn, 1, D)
+
+    def chain(self, pre: str, x: Act) -> Act:
+        for j in range(self.cfg.p):
+            for k, d in enumerate(self.cfg.dilas):
+                x = self.tcm1(f"{pre}.{j}.tcns.{k}", x, d)
+        return x
+
+    def gated_in(self, pfx: str, feat: Act, pre: Act, feat_perm: np.ndarray) -> Act:
+        """in_conv_main(cat) * sigmoid(in_conv_gate(cat)) (GaGNet.py:191,251) as ONE gated 1x1 conv over the
+        two sources; the concatenation (:190,250) is the kernel's two-pointer K loop."""
+        D, Fq = self.cfg.d_feat, self.cfg.freq
+        cols_pre = np.arange(2 * Fq)
+        cols_pre = D + (cols_pre % 2) * Fq + cols_pre // 2          # memory channel f*2+ri <- reference ri*F+f
+        w = np.concatenate([self.P[f"{pfx}.in_conv_main.weight"], self.P[f"{pfx}.in_conv_gate.0.weight"]], axis=0)[:, :, 0]
+        wk = np.zeros((2 * D, D + GAG_PRE_LD), np.float32)
+        wk[:, :D] = w[:, feat_perm]
+        wk[:, D:D + 2 * Fq] = w[:, cols_pre]
+        order = glu_row_order(2 * D)
+        wref = self.W.add(f"{pfx}.in_conv#packed", pack_taps(wk[order][:, :, None], [0]))
+        bias = np.concatenate([self.P[f"{pfx}.in_conv_main.bias"], self.P[f"{pfx}.in_conv_gate.0.bias"]])[order]
+        dst = self.alloc_act(1, D)
+        Kpad = ((D + GAG_PRE_LD + 15) // 16) * 16
+        self.emit_conv(f"{pfx}.in_conv", [feat, pre], wref, self.W.add(f"{pfx}.in_conv.bias#packed", bias), 2 * D, Kpad,
+                       1, 1, 1, 0, 1, [0], [0], EPI_GLU, dst, bm=64, patch_ok=False)
+        return Act(dst, 1, D)
+
+    def linear(self, key: str, x: Act) -> Ref:
+        """Conv1d(d_feat -> 161, 1) (GaGNet.py:176,241), rows padded to GAG_LIN_LD."""
+        D, Fq = self.cfg.d_feat, self.cfg.freq
+        w = np.zeros((GAG_LIN_LD, D, 1), np.float32)
+        b = np.zeros(GAG_LIN_LD, np.float32)
+        w[:Fq], b[:Fq] = self.P[f"{key}.weight"], self.P[f"{key}.bias"]
+        dst = self.alloc_act(1, GAG_LIN_LD)
+        self.emit_conv(key, [x], self.W.add(f"{key}.weight#packed", pack_taps(w, [0])), self.W.add(f"{key}.bias#packed", b),
+                       GAG_LIN_LD, D, 1, 1, 1, 0, 1, [0], [0], EPI_LINEAR, dst, bm=64)
+        return dst
+
+    def build(self) -> Program:
+        cfg, B, T, F = self.cfg, self.B, self.T, self.F
+        assert F == cfg.freq
+        c = cfg.c
+        enc_in = Act(self.alloc_act(F, 4), F, 4, raw=True)
+        pre = Act(self.alloc(B * T * GAG_PRE_LD), 1, GAG_PRE_LD, raw=True)
+        self.ops.append(GagPackOp(inpt=Ref("in"), pre_x=Ref("in2"), enc_in=enc_in.ref, pre=pre.ref, B=B, T=T, F=F, name="pack"))
+        x = enc_in
+        if cfg.is_u2:
+            for i in range(4):
+                x = self.unet_module(f"en.meta_unet_list.{i}", [x], 4 - i, False)
+            g = self.conv2d_fwd("en.last_conv", [x], "en.last_conv.0.conv.1", True, "en.last_conv.1", "en.last_conv.2")
+        else:
+            for i in range(5):
+                q = f"en.unet_list.{i}"
+                x = g = self.conv2d_fwd(q, [x], f"{q}.0.conv.1", True, f"{q}.1", f"{q}.2")
+        x = self.materialise("en.last_conv", g)
+        assert x.F * x.C == cfg.d_feat
+        k = np.arange(cfg.d_feat)
+        feat_perm = (k % c) * x.F + k // c                 # memory channel f*64+c <- reference c*4+f (GaGNet.py:83-84)
+        feat = Act(x.ref, 1, cfg.d_feat)
+        act = {"sigmoid": ACT_SIGMOID, "tanh": ACT_TANH, "relu": ACT_RELU}[cfg.acti_type]
+        for gi in range(cfg.q):
+            gl, gz = f"gags.{gi}.glance_block", f"gags.{gi}.gaze_block"
+            # the glance chain and the gaze chain(s) only meet again in the tail: they run as parallel
+            # branches (each S-TCM launch fills less than half of the chip on its own)
+            xg0 = self.gated_in(gl, feat, pre, feat_perm)
+            xz = self.gated_in(gz, feat, pre, feat_perm)
+            branches = [1] if cfg.is_squeezed else [1, 2]
+            self.mark("fork", branches)
+            gain = self.linear(f"{gl}.linear_g.0", self.chain(f"{gl}.tcn_g", xg0))
+            self.lane = 1
+            if cfg.is_squeezed:
+                xr = self.chain(f"{gz}.tcm_ri", xz)
+                lr, li = self.linear(f"{gz}.linear_r", xr), self.linear(f"{gz}.linear_i", xr)
+            else:
+                lr = self.linear(f"{gz}.linear_r", self.chain(f"{gz}.tcm_r", xz))
+                self.lane = 2
+                li = self.linear(f"{gz}.linear_i", self.chain(f"{gz}.tcm_i", xz))
+            self.lane = 0
+            self.mark("join", branches)
+            nxt = Act(self.alloc(B * T * GAG_PRE_LD), 1, GAG_PRE_LD, raw=True)
+            self.ops.append(GagCrmOp(pre=pre.ref, g=gain, r=lr, i=li, pre_out=nxt.ref, planar=Ref("out", gi * B * 2 * T * F),
+                                     B=B, T=T, F=F, act=act, name=f"gags.{gi}.crm"))
+            pre = nxt
+        return Program(cfg, B, T, F, self.ops, self.W.flat(), self.act_size, self.taps, self.flops,
+                       lanes=self.lane_of_ops(), sync=self.sync)
+
+
+def lower(cfg, params: Dict[str, np.ndarray], B: int, T: int, F: int = 161,
           dump_bfw: bool = False, precision: str = "f32") -> Program:
+    if isinstance(cfg, GagConfig):
+        return GagLowering(cfg, params, B, T, F, False, precision).build()
     return Lowering(cfg, params, B, T, F, dump_bfw, precision).build()

@@ -229,3 +229,116 @@ def unet_decoder_layers(cfg: NetConfig):
     c = cfg.c
     return [(2 * cfg.c_end, c, cfg.k1), (2 * c, c, cfg.k1), (2 * c, c, cfg.k1), (2 * c, c, cfg.k1),
             (2 * c, cfg.embed_dim, cfg.k_beg)]
+
+
+# ----------------------------------------------------------------------------
+# GaGNet post-filter (reference GaGNet.py), the second stage of EaBNetWithPostNet
+# ----------------------------------------------------------------------------
+@dataclass(frozen=True)
+class GagConfig:
+    """Hyper-parameters of GaGNet.__init__ (reference GaGNet.py:6-24; defaults = the ``gagnet_*``
+    arguments of train_distributed.py:303-318)."""
+    cin: int = 2
+    k1: Tuple[int, int] = (2, 3)
+    k2: Tuple[int, int] = (1, 3)
+    c: int = 64
+    kd1: int = 3
+    cd1: int = 64
+    d_feat: int = 256
+    p: int = 2
+    q: int = 3
+    dilas: Tuple[int, ...] = (1, 2, 5, 9)
+    fft_num: int = 320
+    is_u2: bool = True
+    is_causal: bool = True
+    is_squeezed: bool = False
+    acti_type: str = "sigmoid"
+    intra_connect: str = "cat"
+    norm_type: str = "IN"
+
+    k_beg: Tuple[int, int] = (2, 5)
+    c_end: int = 64
+
+    @property
+    def freq(self) -> int:
+        return self.fft_num // 2 + 1
+
+    def check_supported(self) -> None:
+        bad = []
+        if self.cin != 2:
+            bad.append(f"cin={self.cin} (the post-filter runs on real/imag pairs)")
+        if self.acti_type not in ("sigmoid", "tanh", "relu"):
+            bad.append(f"acti_type={self.acti_type!r}")
+        if self.intra_connect not in ("cat", "add"):
+            bad.append(f"intra_connect={self.intra_connect!r}")
+        if self.norm_type not in ("IN", "BN"):
+            bad.append(f"norm_type={self.norm_type!r}")
+        if tuple(self.k1) != (2, 3) or tuple(self.k2) != (1, 3) or self.c != 64 or self.cd1 != 64:
+            bad.append("k1/k2/c/cd1 away from (2,3)/(1,3)/64/64")
+        if self.d_feat != self.c_end * 4 or self.fft_num != 320:
+            bad.append("d_feat != 256 or fft_num != 320")
+        if not self.is_causal and any(((self.kd1 - 1) * d) % 2 for d in self.dilas):
+            bad.append("is_causal=False with an odd (kd1-1)*dilation (the reference's residual add fails)")
+        if self.kd1 < 1 or self.p < 1 or self.q < 1 or not self.dilas:
+            bad.append("kd1/p/q/dilas")
+        if bad:
+            raise NotImplementedError("eabnet_amd.GaGNet: unsupported option(s): " + ", ".join(bad))
+
+
+def gag_param_specs(cfg: GagConfig) -> "OrderedDict[str, ParamSpec]":
+    """Ordered ``key -> ParamSpec`` of GaGNet (reference GaGNet.py:68-74 and the block constructors
+    :136-327)."""
+    cfg.check_supported()
+    tab: "OrderedDict[str, ParamSpec]" = OrderedDict()
+    c = cfg.c
+    bn, add = cfg.norm_type == "BN", cfg.intra_connect == "add"
+    if cfg.is_u2:
+        en_k = [cfg.k_beg, cfg.k1, cfg.k1, cfg.k1]
+        en_cin = [2 * cfg.cin, c, c, c]
+        for i in range(4):
+            _unet_module(tab, f"en.meta_unet_list.{i}", en_cin[i], c, en_k[i], cfg.k2, 4 - i, False, bn, add)
+        _gate_conv(tab, "en.last_conv.0", c, cfg.c_end, cfg.k1, False)
+        _norm_prelu(tab, "en.last_conv.1", "en.last_conv.2", cfg.c_end, bn)
+    else:
+        # GaGNet's plain encoder normalises every layer (GaGNet.py:383-406), unlike EaBNet's
+        for i in range(5):
+            _gate_conv(tab, f"en.unet_list.{i}.0", 2 * cfg.cin if i == 0 else c, cfg.c_end if i == 4 else c,
+                       cfg.k_beg if i == 0 else cfg.k1, False)
+            _norm_prelu(tab, f"en.unet_list.{i}.1", f"en.unet_list.{i}.2", cfg.c_end if i == 4 else c, bn)
+
+    D, cd, kd, Fq = cfg.d_feat, cfg.cd1, cfg.kd1, cfg.freq
+    ci = 2 * Fq + D
+
+    def gated_in(p):
+        tab[f"{p}.in_conv_main.weight"] = ParamSpec((D, ci, 1), "conv_w", ci)
+        tab[f"{p}.in_conv_main.bias"] = ParamSpec((D,), "bias", ci)
+        tab[f"{p}.in_conv_gate.0.weight"] = ParamSpec((D, ci, 1), "conv_w", ci)
+        tab[f"{p}.in_conv_gate.0.bias"] = ParamSpec((D,), "bias", ci)
+
+    def tcn_chain(p):
+        for j in range(cfg.p):
+            for k in range(len(cfg.dilas)):
+                t = f"{p}.{j}.tcns.{k}"
+                tab[f"{t}.in_conv.weight"] = ParamSpec((cd, D, 1), "conv_w", D)
+                tab[f"{t}.d_conv.0.weight"] = ParamSpec((cd,), "prelu", cd)
+                _norm(tab, f"{t}.d_conv.1", cd, bn)
+                tab[f"{t}.d_conv.3.weight"] = ParamSpec((cd, cd, kd), "conv_w", cd * kd)
+                tab[f"{t}.out_conv.0.weight"] = ParamSpec((cd,), "prelu", cd)
+                _norm(tab, f"{t}.out_conv.1", cd, bn)
+                tab[f"{t}.out_conv.2.weight"] = ParamSpec((D, cd, 1), "conv_w", cd)
+
+    def linear(p):
+        tab[f"{p}.weight"] = ParamSpec((Fq, D, 1), "conv_w", D)
+        tab[f"{p}.bias"] = ParamSpec((Fq,), "bias", D)
+
+    for g in range(cfg.q):
+        gl, gz = f"gags.{g}.glance_block", f"gags.{g}.gaze_block"
+        gated_in(gl)
+        tcn_chain(f"{gl}.tcn_g")
+        linear(f"{gl}.linear_g.0")
+        gated_in(gz)
+        for name in (("tcm_ri",) if cfg.is_squeezed else ("tcm_r", "tcm_i")):
+            tcn_chain(f"{gz}.{name}")
+        linear(f"{gz}.linear_r")
+        linear(f"{gz}.linear_i")
+    return tab

@@ -84,6 +84,27 @@ int eab_istft_f32(const float* spec, const float* window, const float* twiddle, 
                   int n_fft, int hop, eab_stream_t stream);
 
 /* --------------------------------------------------------------------------
+ * GaGNet post-filter glue (reference GaGNet.py).  The convolutions of the post-filter
+ * run on eab_conv_f32; these are the two elementwise passes around them.
+ *
+ * eab_gag_pack_f32: GaGNet.forward's two concatenations (GaGNet.py:80-85, 189-190, 249-250) as one
+ * re-layout of the planar inputs:
+ *   inpt, pre_x [B][2][T][F] -> enc_in [B][T][F][4] = (in_r, in_i, pre_r, pre_i)
+ *                               pre    [B][T][ld], channel f*2+ri, zero padded (ld % 4 == 0, ld >= 2F)
+ * eab_gag_crm_f32: GlanceGazeModule.forward tail (GaGNet.py:127-133), coarse filtering by the gain plus
+ * the complex residual:  y = pre * act(g) + (r, i)   (the reference's polar form, algebraically)
+ *   pre [B][T][ld];  g, r, i [B][T][lin_ld] (first F entries used; biases already added)
+ *   -> pre_out [B][T][ld] (next module's pre)  and  planar [B][2][T][F] (the stage output)
+ * ------------------------------------------------------------------------ */
+#define EAB_ACT_SIGMOID 0
+#define EAB_ACT_TANH    1
+#define EAB_ACT_RELU    2
+int eab_gag_pack_f32(const float* inpt, const float* pre_x, float* enc_in, float* pre, int B, int T, int F,
+                     int ld, eab_stream_t stream);
+int eab_gag_crm_f32(const float* pre, const float* g, const float* r, const float* i, float* pre_out,
+                    float* planar, int B, int T, int F, int ld, int lin_ld, int act, eab_stream_t stream);
+
+/* --------------------------------------------------------------------------
  * K13  complex filter-and-sum, stand-alone.   Replaces EaBNet.py:114-117.
  *   w, x [B][T][F][M][2] -> y [B][2][T][F];  Y = sum_m W_m * X_m (no conjugate)
  * ------------------------------------------------------------------------ */
@@ -264,6 +285,8 @@ int eab_bfw_filter_sum_f32(const float* y1, const float* w2, const float* b2, co
 #define EAB_OP_LSTM64      4
 #define EAB_OP_BFW_FS      5
 #define EAB_OP_MEMSET0     6
+#define EAB_OP_GAG_PACK    7
+#define EAB_OP_GAG_CRM     8
 
 typedef struct eab_op {
     int32_t kind;
@@ -279,6 +302,8 @@ typedef struct eab_op {
  *  LSTM64      i = {B, T, F, precision}  f = {ln_eps}  p = {x, ln_g, ln_b, wcat, bias, h_out}
  *  BFW_FS      i = {B, T, F, M}  p = {y1, w2, b2, x, out, bfw}
  *  MEMSET0     p = {ptr}  i = {bytes_lo, bytes_hi}
+ *  GAG_PACK    i = {B, T, F, ld}  p = {inpt, pre_x, enc_in, pre}
+ *  GAG_CRM     i = {B, T, F, ld, lin_ld, act}  p = {pre, g, r, i, pre_out, planar}
  */
 int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream);
 

@@ -338,3 +338,96 @@ def com_mag_mse_loss(esti: torch.Tensor, label: torch.Tensor, frame_list) -> tor
     l1 = (((mag_e - mag_l) ** 2) * mask).sum() / mask.sum()
     l2 = (((esti - label) ** 2) * mask.unsqueeze(1)).sum() / (2.0 * mask.sum())
     return 0.5 * (l1 + l2)
+
+
+# ----------------------------------------------------------------------------
+# GaGNet post-filter (reference GaGNet.py) and the two-stage wrapper (EaBNet.py:127-148)
+# ----------------------------------------------------------------------------
+def gag_tcm(x, P: Params, pre: str, dilation: int, kd: int, bn: bool, causal: bool):
+    """GaGNet's single-branch SqueezedTCM.forward (GaGNet.py:321-327)."""
+    span = (kd - 1) * dilation
+    pad = (span, 0) if causal else (span // 2, span // 2)
+    y = F.conv1d(x, P[f"{pre}.in_conv.weight"])
+    y = _norm(F.prelu(y, P[f"{pre}.d_conv.0.weight"]), P, f"{pre}.d_conv.1", bn)
+    y = F.conv1d(F.pad(y, pad), P[f"{pre}.d_conv.3.weight"], dilation=dilation)
+    y = _norm(F.prelu(y, P[f"{pre}.out_conv.0.weight"]), P, f"{pre}.out_conv.1", bn)
+    return F.conv1d(y, P[f"{pre}.out_conv.2.weight"]) + x
+
+
+def gag_chain(x, P: Params, pre: str, p: int, dilas, kd, bn, causal):
+    for j in range(p):
+        for k, d in enumerate(dilas):
+            x = gag_tcm(x, P, f"{pre}.{j}.tcns.{k}", d, kd, bn, causal)
+    return x
+
+
+def gagnet_forward(P: Params, inpt: torch.Tensor, pre_x: torch.Tensor, *, kd1: int = 3, p: int = 2, q: int = 3,
+                   dilas=(1, 2, 5, 9), is_u2: bool = True, is_causal: bool = True, is_squeezed: bool = False,
+                   acti_type: str = "sigmoid", intra_connect: str = "cat", norm_type: str = "IN") -> List[torch.Tensor]:
+    """GaGNet.forward (GaGNet.py:76-90): inpt, pre_x (B,2,T,F) -> q stage outputs (B,2,F,T)."""
+    B, _, T, Fq = inpt.shape
+    bn, add = norm_type == "BN", intra_connect == "add"
+    x = torch.cat([inpt, pre_x], dim=1)
+    if is_u2:
+        for i in range(4):
+            x = unet_module(x, P, f"en.meta_unet_list.{i}", 4 - i, False, None, bn, add)
+        x = _in_prelu(gate_conv2d(x, P["en.last_conv.0.conv.1.weight"], P["en.last_conv.0.conv.1.bias"]), P,
+                      "en.last_conv.1", "en.last_conv.2", bn)
+    else:
+        for i in range(5):
+            x = _in_prelu(gate_conv2d(x, P[f"en.unet_list.{i}.0.conv.1.weight"], P[f"en.unet_list.{i}.0.conv.1.bias"]), P,
+                          f"en.unet_list.{i}.1", f"en.unet_list.{i}.2", bn)
+    feat = x.transpose(-2, -1).contiguous().view(B, -1, T)
+    pre = pre_x.transpose(-2, -1).contiguous()                       # (B,2,F,T)
+    act = {"sigmoid": torch.sigmoid, "tanh": torch.tanh, "relu": torch.relu}[acti_type]
+    outs = []
+    for g in range(q):
+        gl, gz = f"gags.{g}.glance_block", f"gags.{g}.gaze_block"
+        cat = torch.cat((feat, pre.view(B, -1, T)), dim=1)
+
+        def gated(pfx):
+            return F.conv1d(cat, P[f"{pfx}.in_conv_main.weight"], P[f"{pfx}.in_conv_main.bias"]) * torch.sigmoid(
+                F.conv1d(cat, P[f"{pfx}.in_conv_gate.0.weight"], P[f"{pfx}.in_conv_gate.0.bias"]))
+
+        xg = gag_chain(gated(gl), P, f"{gl}.tcn_g", p, dilas, kd1, bn, is_causal)
+        gain = act(F.conv1d(xg, P[f"{gl}.linear_g.0.weight"], P[f"{gl}.linear_g.0.bias"]))          # (B,F,T)
+        xz = gated(gz)
+        if is_squeezed:
+            xr = xi = gag_chain(xz, P, f"{gz}.tcm_ri", p, dilas, kd1, bn, is_causal)
+        else:
+            xr = gag_chain(xz, P, f"{gz}.tcm_r", p, dilas, kd1, bn, is_causal)
+            xi = gag_chain(xz, P, f"{gz}.tcm_i", p, dilas, kd1, bn, is_causal)
+        resi = torch.stack((F.conv1d(xr, P[f"{gz}.linear_r.weight"], P[f"{gz}.linear_r.bias"]),
+                            F.conv1d(xi, P[f"{gz}.linear_i.weight"], P[f"{gz}.linear_i.bias"])), dim=1)
+        # GaGNet.py:128-133: polar form of "previous estimate times gain" plus the complex residual
+        mag, ph = torch.norm(pre, dim=1), torch.atan2(pre[:, -1], pre[:, 0])
+        filt = mag * gain
+        pre = torch.stack((filt * torch.cos(ph), filt * torch.sin(ph)), dim=1) + resi
+        outs.append(pre)
+    return outs
+
+
+def eabnet_postnet_forward(P: Params, noisy: torch.Tensor, ref_mic: int = 0, eab_kw: Optional[dict] = None,
+                           gag_kw: Optional[dict] = None, fast_lstm: bool = False) -> dict:
+    """EaBNetWithPostNet.forward (EaBNet.py:138-148); P holds ``eabnet.*`` and ``postnet.*`` keys."""
+    Pe = {k[len("eabnet."):]: v for k, v in P.items() if k.startswith("eabnet.")}
+    Pg = {k[len("postnet."):]: v for k, v in P.items() if k.startswith("postnet.")}
+    esti0 = eabnet_forward(Pe, noisy, fast_lstm=fast_lstm, **(eab_kw or {}))
+    inpt = noisy[..., ref_mic, :].permute(0, 3, 1, 2)
+    lst = gagnet_forward(Pg, inpt, esti0, **(gag_kw or {}))
+    return {"esti0_stft": esti0, "esti1_stft_list": lst, "esti_stft": lst[-1].permute(0, 1, 3, 2)}
+
+
+def stagewise_com_mag_mse_loss(esti_list, label, frame_list) -> torch.Tensor:
+    """GaGNet.py:601-619: stage weights 0.1 (last stage 1); esti (B,2,F,T), label (B,2,F,T)."""
+    B, _, Fq, T = label.shape
+    mask = torch.zeros(B, Fq, T, dtype=label.dtype)
+    for i, n in enumerate(frame_list):
+        mask[i, :, :n] = 1.0
+    l1 = l2 = 0.0
+    mag_l = torch.norm(label, dim=1)
+    for i, e in enumerate(esti_list):
+        a = 1.0 if i == len(esti_list) - 1 else 0.1
+        l1 = l1 + a * (((e - label) ** 2) * mask.unsqueeze(1)).sum() / (2.0 * mask.sum())
+        l2 = l2 + a * (((torch.norm(e, dim=1) - mag_l) ** 2) * mask).sum() / mask.sum()
+    return 0.5 * (l1 + l2)

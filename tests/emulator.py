@@ -52,15 +52,18 @@ def unpack_f16x3(w_store, N, K):
 
 
 class Emulator:
-    def __init__(self, prog: prg.Program, x_in: np.ndarray):
+    def __init__(self, prog: prg.Program, x_in: np.ndarray, x_in2: np.ndarray = None):
         self.p = prog
         B, T, F = prog.B, prog.T, prog.F
+        self.stages = getattr(prog.cfg, "q", 1) if x_in2 is not None else 1     # GaGNet: one planar output per stage
         self.arena = {
             "w": prog.weights.astype(np.float32),
             "a": np.full(prog.act_floats, np.nan, dtype=np.float32),   # NaN-poisoned: reads of unwritten memory show
             "in": np.ascontiguousarray(x_in, dtype=np.float32).reshape(-1),
-            "out": np.full(B * 2 * T * F, np.nan, dtype=np.float32),
+            "out": np.full(self.stages * B * 2 * T * F, np.nan, dtype=np.float32),
         }
+        if x_in2 is not None:
+            self.arena["in2"] = np.ascontiguousarray(x_in2, dtype=np.float32).reshape(-1)
 
     def v(self, ref, shape):
         if ref is None:
@@ -245,16 +248,40 @@ class Emulator:
         out[:, 0] = (w[..., 0] * x[..., 0] - w[..., 1] * x[..., 1]).sum(-1)
         out[:, 1] = (w[..., 0] * x[..., 1] + w[..., 1] * x[..., 0]).sum(-1)
 
+    def gag_pack(self, op: prg.GagPackOp):
+        B, T, F = op.B, op.T, op.F
+        a, b = self.v(op.inpt, (B, 2, T, F)), self.v(op.pre_x, (B, 2, T, F))
+        enc = self.v(op.enc_in, (B, T, F, 4))
+        enc[..., 0], enc[..., 1], enc[..., 2], enc[..., 3] = a[:, 0], a[:, 1], b[:, 0], b[:, 1]
+        pre = self.v(op.pre, (B, T, prg.GAG_PRE_LD))
+        pre[:] = 0.0
+        pre[:, :, 0:2 * F:2], pre[:, :, 1:2 * F:2] = b[:, 0], b[:, 1]
+
+    def gag_crm(self, op: prg.GagCrmOp):
+        B, T, F = op.B, op.T, op.F
+        pre = self.v(op.pre, (B, T, prg.GAG_PRE_LD))[:, :, :2 * F].reshape(B, T, F, 2)
+        g, r, i = (self.v(x, (B, T, prg.GAG_LIN_LD))[:, :, :F] for x in (op.g, op.r, op.i))
+        gain = {prg.ACT_SIGMOID: _sig, prg.ACT_TANH: np.tanh, prg.ACT_RELU: lambda v: np.maximum(v, 0)}[op.act](g)
+        yr, yi = pre[..., 0] * gain + r, pre[..., 1] * gain + i
+        nxt = self.v(op.pre_out, (B, T, prg.GAG_PRE_LD))
+        nxt[:] = 0.0
+        nxt[:, :, 0:2 * F:2], nxt[:, :, 1:2 * F:2] = yr, yi
+        out = self.v(op.planar, (B, 2, T, F))
+        out[:, 0], out[:, 1] = yr, yi
+
     def step(self, op):
         with np.errstate(over="ignore"):
             {prg.OP_CONV: self.conv, prg.OP_IN_FINALIZE: self.finalize, prg.OP_NORM_ACT: self.norm_act,
-             prg.OP_LSTM64: self.lstm, prg.OP_BFW_FS: self.bfw,
+             prg.OP_LSTM64: self.lstm, prg.OP_BFW_FS: self.bfw, prg.OP_GAG_PACK: self.gag_pack,
+             prg.OP_GAG_CRM: self.gag_crm,
              prg.OP_MEMSET0: lambda o: self.v(o.ptr, (o.nfloats,)).fill(0)}[op.kind](op)
 
     def run(self):
         for op in self.p.ops:
             self.step(op)
         p = self.p
+        if self.stages > 1 or "in2" in self.arena:
+            return self.arena["out"].reshape(self.stages, p.B, 2, p.T, p.F)
         return self.arena["out"].reshape(p.B, 2, p.T, p.F)
 
     def act(self, a: prg.Act) -> np.ndarray:

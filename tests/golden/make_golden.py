@@ -190,9 +190,63 @@ def main_istft():
         save(f"istft_B{B}_T{T}.npz", wav=wav.numpy(), seed=seed)
 
 
+GAG_BASE = dict(cin=2, k1=(2, 3), k2=(1, 3), c=64, kd1=3, cd1=64, d_feat=256, p=2, q=3, dilas=(1, 2, 5, 9), fft_num=320,
+                is_u2=True, is_causal=True, is_squeezed=False, acti_type="sigmoid", intra_connect="cat", norm_type="IN")
+GAG_VARIANTS = {
+    "default": dict(),
+    "bn_squeezed_tanh": dict(norm_type="BN", is_squeezed=True, acti_type="tanh", p=1, q=2),
+    "unet_add_noncausal_relu": dict(is_u2=False, intra_connect="add", is_causal=False, acti_type="relu", p=1, q=2,
+                                    dilas=(1, 2)),
+}
+
+
+def main_gagnet():
+    """Post-filter: the reference's GaGNet on CPU (its factory make_gag_net calls
+    .cuda(), the class itself does not) and the two-stage composition of EaBNetWithPostNet.forward
+    (EaBNet.py:138-148) spelled out with the reference's two classes."""
+    from GaGNet import GaGNet as RefGaGNet, stagewise_com_mag_mse_loss as ref_stage_loss
+    from eabnet_amd.spec import GagConfig, gag_param_specs
+    inventory = {}
+    for i, (name, kw) in enumerate(GAG_VARIANTS.items()):
+        full = dict(GAG_BASE); full.update(kw)
+        net = RefGaGNet(**{**full, "dilas": list(full["dilas"])}).eval()
+        specs = gag_param_specs(GagConfig(**full))
+        sd = net.state_dict()
+        assert list(sd.keys()) == list(specs.keys())
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in paramgen.make_params(specs, 500 + i).items()}, strict=True)
+        inventory[name] = dict(kwargs={k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()},
+                               keys=[[k, list(v.shape)] for k, v in sd.items()])
+        B, T = 2, 14
+        inpt = torch.from_numpy(paramgen.make_spec_input(B, T, 161, 1, 600 + i)[..., 0, :]).permute(0, 3, 1, 2).contiguous()
+        pre = torch.from_numpy(paramgen.make_spec_input(B, T, 161, 1, 700 + i)[..., 0, :]).permute(0, 3, 1, 2).contiguous()
+        outs = net(inpt, pre)
+        extra = {}
+        if name == "default":
+            label = torch.from_numpy(paramgen.make_spec_input(B, T, 161, 1, 800)[..., 0, :]).permute(0, 3, 2, 1).contiguous()
+            extra["stage_loss"] = ref_stage_loss(outs, label, [T, 9]).numpy()
+        save(f"gag_{name}.npz", param_seed=500 + i, inpt_seed=600 + i, pre_seed=700 + i,
+             **{f"out{j}": o.numpy() for j, o in enumerate(outs)}, **extra)
+    with open(os.path.join(HERE, "keys_gagnet.json"), "w") as f:
+        json.dump(inventory, f)
+
+    # two-stage wrapper: reference EaBNet -> reference GaGNet, composed as EaBNetWithPostNet.forward does
+    M, B, T, ref_mic = 4, 1, 12, 1
+    eab, _ = ref_model(M, seed=520)
+    gag = RefGaGNet(**{**GAG_BASE, "dilas": list(GAG_BASE["dilas"])}).eval()
+    gag.load_state_dict({k: torch.from_numpy(v) for k, v in
+                         paramgen.make_params(gag_param_specs(GagConfig(**GAG_BASE)), 521).items()}, strict=True)
+    noisy = torch.from_numpy(paramgen.make_spec_input(B, T, 161, M, 522))
+    esti0 = eab(noisy)
+    lst = gag(noisy[..., ref_mic, :].permute(0, 3, 1, 2), esti0)
+    save("postnet_M4_T12.npz", esti0=esti0.numpy(), esti=lst[-1].permute(0, 1, 3, 2).numpy(), eab_seed=520, gag_seed=521,
+         input_seed=522, ref_mic=ref_mic, **{f"stage{j}": o.numpy() for j, o in enumerate(lst)})
+
+
 if __name__ == "__main__":
     with torch.no_grad():
-        if sys.argv[1:] == ["variants"]:
+        if sys.argv[1:] == ["gagnet"]:
+            main_gagnet()
+        elif sys.argv[1:] == ["variants"]:
             main_variants()
         elif sys.argv[1:] == ["istft"]:
             main_istft()
@@ -200,3 +254,4 @@ if __name__ == "__main__":
             main()
             main_variants()
             main_istft()
+            main_gagnet()

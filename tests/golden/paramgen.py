@@ -20,10 +20,10 @@ def _rng(seed: int, key: str) -> np.random.Generator:
     return np.random.default_rng([seed, zlib.crc32(key.encode())])
 
 
-def make_param(key: str, shape: Tuple[int, ...], kind: str, fan_in: int, seed: int) -> np.ndarray:
+def make_param(key: str, shape: Tuple[int, ...], kind: str, fan_in: int, seed: int, gain: float = 1.7) -> np.ndarray:
     g = _rng(seed, key)
     if kind in ("conv_w", "convT_w", "lin_w", "lstm"):
-        a = 1.7 / np.sqrt(max(fan_in, 1))        # a little hotter than PyTorch's default
+        a = gain / np.sqrt(max(fan_in, 1))       # 1.7: a little hotter than PyTorch's default (gain 1)
         return g.uniform(-a, a, size=shape).astype(np.float32)
     if kind == "bias":
         return g.uniform(-0.2, 0.2, size=shape).astype(np.float32)
@@ -42,9 +42,9 @@ def make_param(key: str, shape: Tuple[int, ...], kind: str, fan_in: int, seed: i
     raise ValueError(kind)
 
 
-def make_params(specs: Mapping[str, object], seed: int) -> Dict[str, np.ndarray]:
+def make_params(specs: Mapping[str, object], seed: int, gain: float = 1.7) -> Dict[str, np.ndarray]:
     """specs: key -> object with .shape/.kind/.fan_in (eabnet_amd.spec.ParamSpec)."""
-    return {k: make_param(k, tuple(s.shape), s.kind, s.fan_in, seed) for k, s in specs.items()}
+    return {k: make_param(k, tuple(s.shape), s.kind, s.fan_in, seed, gain) for k, s in specs.items()}
 
 
 def make_spec_input(B: int, T: int, F: int, M: int, seed: int, scale: float = 0.3) -> np.ndarray:

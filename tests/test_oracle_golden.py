@@ -197,3 +197,55 @@ def test_istft_oracle_matches_reference_call(B, T):
     wav = orc.istft_oracle(esti.contiguous())
     assert wav.shape == (B, 160 * (T - 1))
     assert_close(wav.numpy(), g["wav"], TOL_ORACLE, "istft")
+
+
+def _gag_variants():
+    import json
+    import os
+    with open(os.path.join(GOLDEN, "keys_gagnet.json")) as f:
+        return json.load(f)
+
+
+def _gag_case(name):
+    from eabnet_amd.spec import GagConfig, gag_param_specs
+    e = _gag_variants()[name]
+    g = load(f"gag_{name}.npz")
+    kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in e["kwargs"].items()}
+    cfg = GagConfig(**kw)
+    P = {k: torch.from_numpy(v) for k, v in paramgen.make_params(gag_param_specs(cfg), int(g["param_seed"])).items()}
+    mk = lambda seed: torch.from_numpy(paramgen.make_spec_input(2, 14, 161, 1, seed)[..., 0, :]).permute(0, 3, 1, 2).contiguous()  # noqa: E731
+    return cfg, kw, P, mk(int(g["inpt_seed"])), mk(int(g["pre_seed"])), g, e
+
+
+@pytest.mark.parametrize("name", sorted(_gag_variants()))
+def test_gagnet_oracle_matches_reference(name):
+    """Post-filter: functional GaGNet against the reference class run on CPU
+    (default topology; BN + squeezed + tanh; plain encoder + add + non-causal + relu)."""
+    from eabnet_amd.spec import gag_param_specs
+    cfg, kw, P, inpt, pre, g, e = _gag_case(name)
+    assert [[k, list(s.shape)] for k, s in gag_param_specs(cfg).items()] == e["keys"]
+    with torch.no_grad():
+        outs = orc.gagnet_forward(P, inpt, pre, **kw)
+    assert len(outs) == cfg.q
+    for j, o in enumerate(outs):
+        assert_close(o.numpy(), g[f"out{j}"], TOL_ORACLE, f"{name} stage {j}")
+    if name == "default":
+        label = torch.from_numpy(paramgen.make_spec_input(2, 14, 161, 1, 800)[..., 0, :]).permute(0, 3, 2, 1).contiguous()
+        assert abs(float(orc.stagewise_com_mag_mse_loss(outs, label, [14, 9])) - float(g["stage_loss"])) < 1e-5 * float(g["stage_loss"])
+
+
+def test_two_stage_oracle_matches_reference_composition():
+    """EaBNetWithPostNet.forward (EaBNet.py:138-148): beam-former -> post-filter on (reference mic,
+    estimate).  The post-filter amplifies a 3e-7 difference of its input ~100x (random hot weights,
+    12 frames), hence the looser bar on the final stage; the beam-former stage is at the oracle bar."""
+    from eabnet_amd.spec import GagConfig, gag_param_specs
+    g = load("postnet_M4_T12.npz")
+    P = {"eabnet." + k: v for k, v in torch_params(4, int(g["eab_seed"])).items()}
+    P.update({"postnet." + k: torch.from_numpy(v) for k, v in
+              paramgen.make_params(gag_param_specs(GagConfig()), int(g["gag_seed"])).items()})
+    noisy = torch.from_numpy(paramgen.make_spec_input(1, 12, 161, 4, int(g["input_seed"])))
+    with torch.no_grad():
+        o = orc.eabnet_postnet_forward(P, noisy, ref_mic=int(g["ref_mic"]))
+    assert_close(o["esti0_stft"].numpy(), g["esti0"], TOL_ORACLE, "esti0")
+    assert o["esti_stft"].shape == (1, 2, 12, 161)
+    assert_close(o["esti_stft"].numpy(), g["esti"], 2e-4, "esti")

@@ -147,3 +147,29 @@ def test_pack_f16x3_round_trip():
     w[0, 0] = 1e5
     with pytest.raises(ValueError):
         prg.pack_f16x3(w)
+
+
+def _gag_variants():
+    import json
+    import os
+    from util import GOLDEN
+    with open(os.path.join(GOLDEN, "keys_gagnet.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("name", sorted(_gag_variants()))
+def test_emulated_gagnet_matches_reference(name, precision):
+    """GaGNet lowering (pack -> U2 encoder -> per stage: two gated two-source in-convs, 24 single-branch
+    S-TCMs, three padded linears, gain/residual tail) against the reference's stage outputs."""
+    from eabnet_amd.spec import GagConfig, gag_param_specs
+    e = _gag_variants()[name]
+    g = load(f"gag_{name}.npz")
+    cfg = GagConfig(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in e["kwargs"].items()})
+    P = paramgen.make_params(gag_param_specs(cfg), int(g["param_seed"]))
+    mk = lambda seed: np.ascontiguousarray(paramgen.make_spec_input(2, 14, 161, 1, seed)[..., 0, :].transpose(0, 3, 1, 2))  # noqa: E731
+    prog = prg.lower(cfg, P, 2, 14, 161, precision=precision)
+    y = Emulator(prog, mk(int(g["inpt_seed"])), mk(int(g["pre_seed"]))).run()
+    assert y.shape == (cfg.q, 2, 2, 14, 161)
+    for j in range(cfg.q):
+        assert_close(y[j].transpose(0, 1, 3, 2), g[f"out{j}"], TOL_EMU, f"{name} stage {j}")
