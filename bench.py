@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary f16x3 measurement")
     ap.add_argument("--no-c1", action="store_true", help="skip the single-utterance (B=1) latency measurement")
     ap.add_argument("--no-graph", action="store_true", help="direct kernel launches instead of hipGraph replay")
+    ap.add_argument("--no-next", action="store_true", help="skip the next-row measurements (post-filter, ISTFT)")
     ap.add_argument("--precision", choices=("f32", "f16x3"), default="f32",
                     help="MFMA arithmetic of the timed path (DESIGN.md §4.4)")
     ap.add_argument("--per-op", type=str, default="", help="write the per-op timing table (instrumented replay) here")
@@ -333,6 +334,52 @@ def main():
             c1[prec] = {"ms_per_utterance": 1e3 * dt1, "rtf": dt1 / SECONDS, "frames_per_s": T / dt1}
         net.precision = a.precision
         out["single_utterance_c1"] = c1
+
+    if rank == 0 and not a.no_next:
+        # SURVEY §8f rows built after the hot path: what enhance.py actually runs -- wave -> STFT ->
+        # EaBNetWithPostNet (beam-former + GaGNet post-filter) -> ISTFT -> wave, same batch, same protocol
+        net = None
+        torch.cuda.empty_cache()
+        pa = argparse.Namespace(
+            k1=(2, 3), k2=(1, 3), c=64, M=MICS, embed_dim=64, kd1=5, cd1=64, d_feat=256, p=6, q=3, is_causal=True,
+            is_u2=True, bf_type="lstm", topo_type="mimo", intra_connect="cat", norm_type="IN", ref_mic=0,
+            freeze_eabnet=False, gagnet_k1=(2, 3), gagnet_k2=(1, 3), gagnet_c=64, gagnet_kd1=3, gagnet_cd1=64,
+            gagnet_d_feat=256, gagnet_p=2, gagnet_q=3, gagnet_dilas=[1, 2, 5, 9], gagnet_fft_num=320, gagnet_is_u2=True,
+            gagnet_is_causal=True, gagnet_is_squeezed=False, gagnet_acti_type="sigmoid", gagnet_intra_connect="cat",
+            gagnet_norm_type="IN")
+        torch.manual_seed(1)
+        two = eabnet_amd.make_eabnet_with_postnet(pa).to(dev).eval()
+        two.eabnet.load_state_dict(state, strict=True)
+        nxt = {"pipeline": "wave -> stft_compress -> EaBNetWithPostNet -> istft -> wave (enhance.py:45-62)",
+               "params": eabnet_amd.numParams(two)}
+        for prec in (("f32", "f16x3") if not a.no_alt else ("f32",)):
+            two.eabnet.precision = two.postnet.precision = prec
+
+            def step():
+                o = two(eabnet_amd.stft_compress(wav, N_FFT, HOP, window))
+                return eabnet_amd.istft(o["esti_stft"], N_FFT, HOP, window)
+            with torch.no_grad():
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    w_out = step()
+                torch.cuda.synchronize()
+                dtw = (time.perf_counter() - t0) / 10
+                inp = two.postnet._last[1:]
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    two.postnet(*inp)
+                e1.record()
+                torch.cuda.synchronize()
+            assert bool(torch.isfinite(w_out).all())
+            nxt[prec] = {"ms_per_step": 1e3 * dtw, "frames_per_s": B_PER_GPU * T / dtw,
+                         "postfilter_ms_per_step": e0.elapsed_time(e1) / 10}
+        out["next_rows"] = nxt
+        two = None
+        torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(state, MICS, L)
