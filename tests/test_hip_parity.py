@@ -609,3 +609,41 @@ def test_enhance_pipeline_wave_to_wave(dev):
         stages = orc.gagnet_forward(Pg, n_cpu[..., 0, :].permute(0, 3, 1, 2), out["esti0_stft"].cpu(), p=1, q=2)
         assert_close(out["esti_stft"].cpu().numpy(), stages[-1].permute(0, 1, 3, 2).numpy(), TOL_HIP, "esti")
         assert_close(enhanced.cpu().numpy(), orc.istft_oracle(out["esti_stft"].cpu()).numpy(), 1e-5, "wave")
+
+
+def test_config4_two_stage_ddp_bf16_training_step(dev):
+    """BASELINE config 4 on one rank: train_distributed.py's loop (:181-230) -- the two-stage model with the
+    beam-former frozen, DistributedDataParallel over the RCCL backend, bf16 autocast, stage-wise loss,
+    gradient clipping, Adam -- then inference with the updated post-filter on the HIP program."""
+    import os
+    import torch.distributed as dist
+    import eabnet_amd
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        args = _postnet_args(4, p=1, q=1, gagnet_p=1, gagnet_q=2, gagnet_dilas=[1, 2], freeze_eabnet=True)
+        torch.manual_seed(3)
+        net = eabnet_amd.make_eabnet_with_postnet(args).to(dev).train()
+        ddp = torch.nn.parallel.DistributedDataParallel(net, device_ids=[dev.index])
+        opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=5e-4)
+        x = torch.from_numpy(paramgen.make_spec_input(2, 24, 161, 4, 170)).to(dev)
+        label = torch.from_numpy(paramgen.make_spec_input(2, 24, 161, 1, 171)[..., 0, :]).permute(0, 3, 2, 1).contiguous().to(dev)
+        before = {k: v.clone() for k, v in net.postnet.state_dict().items()}
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = ddp(x)
+            loss = eabnet_amd.stagewise_com_mag_mse_loss([o.float() for o in out["esti1_stft_list"]], label, [24, 24])
+        assert out["esti0_stft"].dtype == torch.float32 and not out["esti0_stft"].requires_grad   # frozen stage: HIP program
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+        opt.step()
+        assert torch.isfinite(loss)
+        assert all(p.grad is None for p in net.eabnet.parameters())
+        assert any(not torch.equal(before[k], v) for k, v in net.postnet.state_dict().items())
+        with torch.no_grad():
+            y = net.eval()(x)["esti_stft"]
+        assert y.shape == (2, 2, 24, 161) and torch.isfinite(y).all()
+    finally:
+        dist.destroy_process_group()
