@@ -12,9 +12,14 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libeabnet_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_TAPS = 16
 _fp = C.POINTER(C.c_float)
+
+
+class TimeWindow(C.Structure):
+    """mirror of eab_time_window: device pointer to the current frame position + frames per chunk"""
+    _fields_ = [("pos", C.c_void_p), ("count", C.c_int32)]
 
 
 class ConvDesc(C.Structure):
@@ -37,12 +42,13 @@ class ConvDesc(C.Structure):
         ("fin_gamma1", C.c_void_p), ("fin_beta1", C.c_void_p),
         ("fin_tiles", C.c_int32), ("fin_nsets", C.c_int32), ("fin_count", C.c_int32), ("fin_eps", C.c_float),
         ("precision", C.c_int32), ("korder", C.c_int32),
+        ("win", TimeWindow),
     ]
 
 
 class Op(C.Structure):
     _fields_ = [("kind", C.c_int32), ("i", C.c_int32 * 8), ("f", C.c_float * 2), ("p", C.c_void_p * 10),
-                ("conv", ConvDesc)]
+                ("win", TimeWindow), ("conv", ConvDesc)]
 
 
 class EabError(RuntimeError):
@@ -56,6 +62,11 @@ _SIGS = {
     "eab_stft_frames_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
     "eab_filter_sum_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
     "eab_istft_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
+    "eab_norm_act_win_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [TimeWindow, C.c_void_p]),
+    "eab_lstm64_stream_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_float] + [C.c_void_p] * 4 + [C.c_int] * 4
+                              + [TimeWindow, C.c_void_p]),
+    "eab_bfw_filter_sum_win_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [TimeWindow, C.c_void_p]),
+    "eab_zero_rows_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [TimeWindow, C.c_void_p]),
     "eab_gag_pack_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
     "eab_gag_crm_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 6 + [C.c_void_p]),
     "eab_conv_tiles": (C.c_int, [C.c_int] * 3),

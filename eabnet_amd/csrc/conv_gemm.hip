@@ -121,11 +121,14 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
 
-    const int Q = d.T * d.No;                       // rows per batch element
-    const int tiles_per_b = (Q + BM - 1) / BM;
+    // rows per batch element: all of them, or the streaming window [t_lo, t_lo + count) (eab_time_window)
+    const int t_lo = d.win.pos ? *d.win.pos : 0;
+    const int t_hi = d.win.pos ? (t_lo + d.win.count < d.T ? t_lo + d.win.count : d.T) : d.T;
+    const int Q = t_hi * d.No;                      // first row NOT computed
+    const int tiles_per_b = ((d.win.pos ? d.win.count : d.T) * d.No + BM - 1) / BM;
     const int b = blockIdx.x / tiles_per_b;
     const int tile = blockIdx.x - b * tiles_per_b;
-    const int q0 = tile * BM;
+    const int q0 = t_lo * d.No + tile * BM;
     const int n_blk = blockIdx.y * BN;
     const float inv_no = 1.0f / (float)d.No;
 
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
         const int Fp = d.Fin + halo_lo + (hi_need > 0 ? hi_need : 0);
         const float inv_fp = 1.0f / (float)Fp;
         const int t_first = cg_div(q0, d.No, inv_no);
-        const int t_last = cg_div((q0 + BM < Q ? q0 + BM : Q) - 1, d.No, inv_no);
+        const int t_last = cg_div((q0 + BM < Q ? q0 + BM : (Q > q0 ? Q : q0 + 1)) - 1, d.No, inv_no);
         const int P = (t_last - t_first + 1 - dt_min) * Fp;          // <= CG_PMAX (checked on the host)
 
         int p_tf[PP];
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             int q = q0 + (wm * MI + mi) * 32 + li;
-            q = q < Q ? q : Q - 1;                                   // tile tail: any valid row (masked in the epilogue)
+            q = q < Q ? q : (Q > q0 ? Q - 1 : q0);                   // tile tail: any row of the tile's patch (masked in the epilogue)
             const int t = cg_div(q, d.No, inv_no), o = q - t * d.No;
             fa[mi] = ((t - t_first - dt_min) * Fp + o * d.istride + halo_lo) * LDK + 4 * lh;
         }
@@ -771,7 +774,7 @@ extern "C" int eab_conv_tiles(int T, int No, int bm) {
 template <int MI, int NI, int KU, int MODE, int XF, bool VEC>
 static int cg_launch(const eab_conv_desc* d, hipStream_t s) {
     constexpr int BM = 64 * MI, BN = 64 * NI;
-    const int tiles = eab_conv_tiles(d->T, d->No, BM);
+    const int tiles = eab_conv_tiles(d->win.pos ? d->win.count : d->T, d->No, BM);
     dim3 grid((unsigned)(d->B * tiles), (unsigned)(d->N / BN));
     constexpr bool can_patch = KU == 1 && MODE != CG_DUAL && VEC && XF != EAB_XF_PRELU_NORM;
     if (d->korder == EAB_KORDER_CHUNK) {
@@ -861,6 +864,10 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
     if (d->korder == EAB_KORDER_CHUNK) {   // patch pipeline: the tile's input patch must fit its LDS area
         EAB_CHECK_ARG(cg_patch_positions(d) <= CG_PMAX && d->epi != EAB_EPI_DUALGATE);
         EAB_CHECK_ARG(d->C0 % 4 == 0 && d->C1 % 4 == 0 && d->xf_mode != EAB_XF_PRELU_NORM);
+    }
+    if (d->win.pos) {    // streaming window: no data-dependent statistics, causal taps only
+        EAB_CHECK_ARG(d->win.count > 0 && d->stats == nullptr && d->fin_stats == nullptr);
+        for (int j = 0; j < d->ntaps; ++j) EAB_CHECK_ARG(d->dt[j] <= 0);
     }
     const bool dual = d->epi == EAB_EPI_DUALGATE;
     const bool glu = d->epi == EAB_EPI_GLU;

@@ -43,12 +43,20 @@ extern "C" int eab_filter_sum_f32(const float* w, const float* x, float* y, int 
 __global__ __launch_bounds__(256) void bfw_filter_sum_kernel(
     const float* __restrict__ y1, const float* __restrict__ w2, const float* __restrict__ b2,
     const float* __restrict__ x, float* __restrict__ out, float* __restrict__ bfw, int T, int F, int M,
-    long long bins) {
+    long long bins, const int* __restrict__ t_pos, int t_count) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* ytile = smem;                            // [BFW_ROWS][BFW_K + 4]
     float* wl = smem + BFW_ROWS * (BFW_K + 4);      // [2M][BFW_K + 4]
     const int tid = threadIdx.x;
     const long long row0 = (long long)blockIdx.x * BFW_ROWS;
+    // `bins` counts the TF bins computed.  Streaming window: index j runs over [B][t_count][F] and maps to
+    // bin (b*T + *t_pos)*F + rem; rows past the utterance end are dropped.
+    const long long per_b = (long long)(t_pos ? t_count : T) * F, p_lo = t_pos ? (long long)*t_pos * F : 0;
+    auto to_bin = [&](long long j) -> long long {
+        if (j >= bins) return -1;
+        const long long b = j / per_b, rem = j - b * per_b;
+        return p_lo + rem < (long long)T * F ? b * T * F + p_lo + rem : -1;
+    };
     // stage weights and activations (float4, coalesced)
     for (int e = tid; e < 2 * M * (BFW_K / 4); e += 256) {
         int r = e / (BFW_K / 4), c4 = e % (BFW_K / 4);
@@ -58,13 +66,14 @@ __global__ __launch_bounds__(256) void bfw_filter_sum_kernel(
     for (int e = tid; e < BFW_ROWS * (BFW_K / 4); e += 256) {
         int r = e / (BFW_K / 4), c4 = e % (BFW_K / 4);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row0 + r < bins) v = *reinterpret_cast<const f32x4*>(&y1[(size_t)(row0 + r) * BFW_K + c4 * 4]);
+        const long long bn = to_bin(row0 + r);
+        if (bn >= 0) v = *reinterpret_cast<const f32x4*>(&y1[(size_t)bn * BFW_K + c4 * 4]);
         *reinterpret_cast<f32x4*>(&ytile[r * (BFW_K + 4) + c4 * 4]) = v;
     }
     __syncthreads();
     const int r = tid >> 2, p = tid & 3;
-    const long long bin = row0 + r;
-    const bool valid = bin < bins;
+    const long long bin = to_bin(row0 + r);
+    const bool valid = bin >= 0;
     const float* yr_ = &ytile[r * (BFW_K + 4)];
     float accr = 0.0f, acci = 0.0f;
     for (int m = p; m < M; m += 4) {
@@ -97,12 +106,19 @@ __global__ __launch_bounds__(256) void bfw_filter_sum_kernel(
 
 extern "C" int eab_bfw_filter_sum_f32(const float* y1, const float* w2, const float* b2, const float* x, float* out,
                                       float* bfw, int B, int T, int F, int M, eab_stream_t stream) {
+    return eab_bfw_filter_sum_win_f32(y1, w2, b2, x, out, bfw, B, T, F, M, eab_time_window{nullptr, 0}, stream);
+}
+
+extern "C" int eab_bfw_filter_sum_win_f32(const float* y1, const float* w2, const float* b2, const float* x, float* out,
+                                          float* bfw, int B, int T, int F, int M, eab_time_window win,
+                                          eab_stream_t stream) {
     EAB_CHECK_ARG(y1 && w2 && b2 && x && out && B > 0 && T > 0 && F > 0 && M > 0 && M <= BFW_MAXM);
-    long long bins = (long long)B * T * F;
+    EAB_CHECK_ARG(win.pos == nullptr || win.count > 0);
+    long long bins = (long long)B * (win.pos ? win.count : T) * F;
     long long grid = (bins + BFW_ROWS - 1) / BFW_ROWS;
     EAB_CHECK_ARG(grid < (1ll << 31));
     size_t shmem = (size_t)(BFW_ROWS + 2 * M) * (BFW_K + 4) * sizeof(float);
     hipLaunchKernelGGL(bfw_filter_sum_kernel, dim3((unsigned)grid), dim3(256), shmem, eab_stream(stream), y1, w2, b2, x,
-                       out, bfw, T, F, M, bins);
+                       out, bfw, T, F, M, bins, win.pos, win.count);
     EAB_RETURN_LAUNCH_STATUS();
 }

@@ -55,12 +55,17 @@ template <bool LN>
 __global__ __launch_bounds__(256) void lstm64_kernel(const float* __restrict__ x, const float* __restrict__ ln_g,
                                                      const float* __restrict__ ln_b, float ln_eps,
                                                      const float* __restrict__ wcat, const float* __restrict__ bias,
-                                                     float* __restrict__ h_out, int T, int F, int S) {
+                                                     float* __restrict__ h_out, int T, int F, int S,
+                                                     const int* __restrict__ t_pos, int t_count,
+                                                     float* __restrict__ c_state) {
     __shared__ __attribute__((aligned(16))) float xs[2][LS_SEQ * LS_LD];
     __shared__ __attribute__((aligned(16))) float hs[2][LS_SEQ * LS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ln = lane & 15, lk = lane >> 4;
     const int s0 = blockIdx.x * LS_SEQ;
+    // streaming (eab_time_window): steps [t_lo, t_hi) only; h_{t_lo-1} comes back from h_out, c from c_state
+    const int t_lo = t_pos ? *t_pos : 0;
+    const int t_hi = t_pos ? (t_lo + t_count < T ? t_lo + t_count : T) : T;
 
     // ---- stationary weights: w?[g][4j+s] = Wcat[g*64 + 16w + ln][(x:0 | h:64) + 16j + 4*lk + s]
     float wx[4][16], wh[4][16];
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(256) void lstm64_kernel(const float* __restrict__ x
     }
 
     auto load_x = [&](int t) -> f32x4 {
-        const unsigned off = (sv && t < T) ? seq_off + (unsigned)t * t_stride : LS_OOB;
+        const unsigned off = (sv && t < t_hi) ? seq_off + (unsigned)t * t_stride : LS_OOB;
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
     };
     auto norm_store = [&](f32x4 v, int buf) {
@@ -134,11 +139,19 @@ __global__ __launch_bounds__(256) void lstm64_kernel(const float* __restrict__ x
     using I2 = std::integral_constant<int, 2>;
     using I4 = std::integral_constant<int, 4>;
 
-    // prologue: h_{-1} = 0, c_{-1} = 0, x_0 and x_1 normalised in LDS, accx = b + W_x x_0
-    *reinterpret_cast<f32x4*>(&hs[0][ls * LS_LD + lc]) = f32x4{0.f, 0.f, 0.f, 0.f};
-    norm_store(load_x(0), 0);
-    norm_store(load_x(1), 1);
+    // prologue: h_{t_lo-1}, c_{t_lo-1} (zero at the start of the utterance), x_{t_lo} and x_{t_lo+1}
+    // normalised in LDS, accx = b + W_x x_{t_lo}
+    *reinterpret_cast<f32x4*>(&hs[0][ls * LS_LD + lc]) = __builtin_bit_cast(
+        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rh, (sv && t_lo > 0) ? seq_off + (unsigned)(t_lo - 1) * t_stride : LS_OOB, 0, 0));
+    norm_store(load_x(t_lo), 0);
+    norm_store(load_x(t_lo + 1), 1);
+    const int u = wave * 16 + ln;
     float cst[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c_state && t_lo > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (s0 + 4 * lk + r < S) cst[r] = c_state[(size_t)(s0 + 4 * lk + r) * LS_H + u];
+    }
     __syncthreads();
     f32x4 accx[4], hf[4], xf[4];
 #pragma unroll
@@ -146,11 +159,10 @@ __global__ __launch_bounds__(256) void lstm64_kernel(const float* __restrict__ x
     frags(xs[0], xf);
     mma(xf, wx, accx, I0{}, I4{});
     frags(hs[0], hf);
-    f32x4 xq = load_x(2), xr = load_x(3);               // x_{t+2}, x_{t+3}: raw, in registers
+    f32x4 xq = load_x(t_lo + 2), xr = load_x(t_lo + 3); // x_{t+2}, x_{t+3}: raw, in registers
 
-    const int u = wave * 16 + ln;
-    for (int t = 0; t < T; ++t) {
-        const int cur = t & 1, nxt = cur ^ 1;
+    for (int t = t_lo; t < t_hi; ++t) {
+        const int cur = (t - t_lo) & 1, nxt = cur ^ 1;
         const f32x4 xn = load_x(t + 4);                 // four steps ahead: two full steps of HBM latency cover
 
         // ---- H: recurrent half (critical path) + LayerNorm of x_{t+2} on the VALU
@@ -227,6 +239,11 @@ __global__ __launch_bounds__(256) void lstm64_kernel(const float* __restrict__ x
         xq = xr;
         xr = xn;
     }
+    if (c_state) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (s0 + 4 * lk + r < S) c_state[(size_t)(s0 + 4 * lk + r) * LS_H + u] = cst[r];
+    }
 }
 
 int eab_lstm64_h3_launch(const float* x, const float* ln_g, const float* ln_b, float ln_eps, const float* wcat,
@@ -240,7 +257,16 @@ extern "C" int eab_lstm64_f32(const float* x, const float* ln_g, const float* ln
 extern "C" int eab_lstm64_prec_f32(const float* x, const float* ln_g, const float* ln_b, float ln_eps,
                                    const float* wcat, const float* bias, float* h_out, int B, int T, int F,
                                    int precision, eab_stream_t stream) {
+    return eab_lstm64_stream_f32(x, ln_g, ln_b, ln_eps, wcat, bias, h_out, nullptr, B, T, F, precision,
+                                 eab_time_window{nullptr, 0}, stream);
+}
+
+extern "C" int eab_lstm64_stream_f32(const float* x, const float* ln_g, const float* ln_b, float ln_eps,
+                                     const float* wcat, const float* bias, float* h_out, float* c_state, int B, int T,
+                                     int F, int precision, eab_time_window win, eab_stream_t stream) {
     EAB_CHECK_ARG(x && wcat && bias && h_out && B > 0 && T > 0 && F > 0);
+    EAB_CHECK_ARG(win.pos == nullptr || (win.count > 0 && c_state));
+    if (win.pos && precision != EAB_PREC_F32) return EAB_EUNSUPPORTED;   // streaming state is carried in fp32
     EAB_CHECK_ARG(precision == EAB_PREC_F32 || precision == EAB_PREC_F16X3);
     EAB_CHECK_ARG((ln_g == nullptr) == (ln_b == nullptr));
     const long long S = (long long)B * F;
@@ -248,11 +274,12 @@ extern "C" int eab_lstm64_prec_f32(const float* x, const float* ln_g, const floa
     if (precision == EAB_PREC_F16X3)
         return eab_lstm64_h3_launch(x, ln_g, ln_b, ln_eps, wcat, bias, h_out, T, F, (int)S, eab_stream(stream));
     const int grid = (int)((S + LS_SEQ - 1) / LS_SEQ);
+    float* cs = win.pos ? c_state : nullptr;
     if (ln_g)
         hipLaunchKernelGGL(lstm64_kernel<true>, dim3(grid), dim3(256), 0, eab_stream(stream), x, ln_g, ln_b, ln_eps,
-                           wcat, bias, h_out, T, F, (int)S);
+                           wcat, bias, h_out, T, F, (int)S, win.pos, win.count, cs);
     else
         hipLaunchKernelGGL(lstm64_kernel<false>, dim3(grid), dim3(256), 0, eab_stream(stream), x, ln_g, ln_b, ln_eps,
-                           wcat, bias, h_out, T, F, (int)S);
+                           wcat, bias, h_out, T, F, (int)S, win.pos, win.count, cs);
     EAB_RETURN_LAUNCH_STATUS();
 }

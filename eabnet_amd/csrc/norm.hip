@@ -81,13 +81,20 @@ extern "C" int eab_in_finalize_f32(const float* stats, int B, int C, int nsets, 
 __global__ __launch_bounds__(256) void norm_act_kernel(const float* __restrict__ a, const float* __restrict__ xfa,
                                                        const float* __restrict__ sla, const float* __restrict__ bb,
                                                        const float* __restrict__ xfb, const float* __restrict__ slb,
-                                                       float* __restrict__ out, int P, int C, long long total4) {
+                                                       float* __restrict__ out, int P, int C, long long total4,
+                                                       const int* __restrict__ t_pos, int rows_per_t, int Pw) {
+    // total4 counts float4 of the rows computed: all P rows per batch element, or the Pw rows of the
+    // streaming window starting at row *t_pos * rows_per_t
     const int C4 = C >> 2;
-    const long long per_b = (long long)P * C4;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int b = (int)(i / per_b);
-        const int c = (int)(i % C4) * 4;
+    const int p_lo = t_pos ? *t_pos * rows_per_t : 0;
+    const long long per_b = (long long)(t_pos ? Pw : P) * C4;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < total4;
+         j += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(j / per_b);
+        const long long rem = j - (long long)b * per_b;
+        if (p_lo + rem / C4 >= P) continue;                      // last chunk shorter than the window
+        const long long i = ((long long)b * P + p_lo) * C4 + rem;
+        const int c = (int)(rem % C4) * 4;
         const f32x4 va = reinterpret_cast<const f32x4*>(a)[i];
         const float* xp = xfa + ((size_t)b * C + c) * 2;
         const f32x4 s01 = *reinterpret_cast<const f32x4*>(xp), s23 = *reinterpret_cast<const f32x4*>(xp + 4);
@@ -111,15 +118,24 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const float* __restrict__
     }
 }
 
-extern "C" int eab_norm_act_f32(const float* a, const float* xfa, const float* slopea, const float* b,
-                                const float* xfb, const float* slopeb, float* out, int B, int P, int C,
-                                eab_stream_t stream) {
-    EAB_CHECK_ARG(a && xfa && slopea && out && B > 0 && P > 0 && C > 0 && (C % 4) == 0);
+extern "C" int eab_norm_act_win_f32(const float* a, const float* xfa, const float* slopea, const float* b,
+                                    const float* xfb, const float* slopeb, float* out, int B, int T, int rows_per_t,
+                                    int C, eab_time_window win, eab_stream_t stream) {
+    EAB_CHECK_ARG(a && xfa && slopea && out && B > 0 && T > 0 && rows_per_t > 0 && C > 0 && (C % 4) == 0);
     EAB_CHECK_ARG(b == nullptr || (xfb && slopeb));
-    const long long total4 = (long long)B * P * (C / 4);
+    EAB_CHECK_ARG(win.pos == nullptr || win.count > 0);
+    const long long P = (long long)T * rows_per_t, Pw = (long long)(win.pos ? win.count : T) * rows_per_t;
+    EAB_CHECK_ARG(P < (1ll << 31));
+    const long long total4 = (long long)B * Pw * (C / 4);
     long long g = (total4 + 255) / 256;
     if (g > 256 * 8) g = 256 * 8;   // <= 8 blocks per CU, grid-stride the rest
     hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)g), dim3(256), 0, eab_stream(stream), a, xfa, slopea, b, xfb,
-                       slopeb, out, P, C, total4);
+                       slopeb, out, (int)P, C, total4, win.pos, rows_per_t, (int)Pw);
     EAB_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int eab_norm_act_f32(const float* a, const float* xfa, const float* slopea, const float* b,
+                                const float* xfb, const float* slopeb, float* out, int B, int P, int C,
+                                eab_stream_t stream) {
+    return eab_norm_act_win_f32(a, xfa, slopea, b, xfb, slopeb, out, B, P, 1, C, eab_time_window{nullptr, 0}, stream);
 }

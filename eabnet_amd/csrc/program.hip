@@ -12,6 +12,36 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ p, s
     for (size_t k = 4 * n4 + i; k < n; k += stride) p[k] = 0.0f;
 }
 
+// rows [*t_pos, *t_pos + count) of a [B][T][row] tensor (row % 4 == 0): the streaming form of the fill
+__global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ p, int T, int row4, const int* __restrict__ t_pos,
+                                                        int count, long long total4) {
+    const int t_lo = *t_pos;
+    const long long per_b = (long long)count * row4;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < total4; j += (long long)gridDim.x * blockDim.x) {
+        const long long b = j / per_b, rem = j - b * per_b;
+        if (t_lo + rem / row4 >= T) continue;
+        reinterpret_cast<f32x4*>(p)[(b * T + t_lo) * row4 + rem] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+extern "C" int eab_zero_rows_f32(float* ptr, int B, int T, int row_floats, eab_time_window win, eab_stream_t stream) {
+    EAB_CHECK_ARG(ptr && B > 0 && T > 0 && row_floats > 0 && (row_floats % 4) == 0 && ((uintptr_t)ptr & 15) == 0);
+    EAB_CHECK_ARG(win.pos == nullptr || win.count > 0);
+    if (!win.pos) {
+        const size_t n = (size_t)B * T * row_floats, n4 = n / 4;
+        size_t g = (n4 + 255) / 256;
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)g), dim3(256), 0, eab_stream(stream), ptr, n4, n);
+        EAB_RETURN_LAUNCH_STATUS();
+    }
+    const long long total4 = (long long)B * win.count * (row_floats / 4);
+    long long g = (total4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)g), dim3(256), 0, eab_stream(stream), ptr, T, row_floats / 4, win.pos,
+                       win.count, total4);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
 extern "C" int eab_abi_version(void) { return EAB_ABI_VERSION; }
 
 extern "C" const char* eab_error_string(int code) {
@@ -37,21 +67,32 @@ extern "C" int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream
                                          (const float*)o.p[4], (const float*)o.p[5], (float*)o.p[6], stream);
                 break;
             case EAB_OP_NORM_ACT:
-                rc = eab_norm_act_f32((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
-                                      (const float*)o.p[3], (const float*)o.p[4], (const float*)o.p[5],
-                                      (float*)o.p[6], o.i[0], o.i[1], o.i[2], stream);
+                if (o.win.pos)
+                    rc = o.i[3] > 0 && o.i[1] % o.i[3] == 0
+                             ? eab_norm_act_win_f32((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
+                                                    (const float*)o.p[3], (const float*)o.p[4], (const float*)o.p[5],
+                                                    (float*)o.p[6], o.i[0], o.i[3], o.i[1] / o.i[3], o.i[2], o.win, stream)
+                             : EAB_EINVAL;
+                else
+                    rc = eab_norm_act_f32((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
+                                          (const float*)o.p[3], (const float*)o.p[4], (const float*)o.p[5],
+                                          (float*)o.p[6], o.i[0], o.i[1], o.i[2], stream);
                 break;
             case EAB_OP_LSTM64:
-                rc = eab_lstm64_prec_f32((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2], o.f[0],
-                                         (const float*)o.p[3], (const float*)o.p[4], (float*)o.p[5], o.i[0], o.i[1],
-                                         o.i[2], o.i[3], stream);
+                rc = eab_lstm64_stream_f32((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2], o.f[0],
+                                           (const float*)o.p[3], (const float*)o.p[4], (float*)o.p[5], (float*)o.p[6],
+                                           o.i[0], o.i[1], o.i[2], o.i[3], o.win, stream);
                 break;
             case EAB_OP_BFW_FS:
-                rc = eab_bfw_filter_sum_f32((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
-                                            (const float*)o.p[3], (float*)o.p[4], (float*)o.p[5], o.i[0], o.i[1],
-                                            o.i[2], o.i[3], stream);
+                rc = eab_bfw_filter_sum_win_f32((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
+                                                (const float*)o.p[3], (float*)o.p[4], (float*)o.p[5], o.i[0], o.i[1],
+                                                o.i[2], o.i[3], o.win, stream);
                 break;
             case EAB_OP_MEMSET0: {
+                if (o.win.pos) {
+                    rc = eab_zero_rows_f32((float*)const_cast<void*>(o.p[0]), o.i[2], o.i[3], o.i[4], o.win, stream);
+                    break;
+                }
                 const size_t bytes = ((size_t)(uint32_t)o.i[1] << 32) | (uint32_t)o.i[0];
                 if (!o.p[0] || (bytes & 3) || ((uintptr_t)o.p[0] & 15)) {
                     rc = EAB_EINVAL;

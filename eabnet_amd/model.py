@@ -82,6 +82,9 @@ class _Bound:
         self.weights = torch.from_numpy(prog.weights).to(device)
         self.acts = torch.empty(max(prog.act_floats, 1), dtype=torch.float32, device=device)
         self.ops = (_lib.Op * len(prog.ops))()
+        # streaming programs: the frame position every windowed op reads (device memory, so one captured
+        # graph serves all chunks)
+        self.t_pos = torch.zeros(1, dtype=torch.int32, device=device) if prog.chunk else None
         self._in_ptr = None
         self._out_ptr = None
         # hipGraph replay (optional): static boundary buffers + the captured program
@@ -139,6 +142,9 @@ class _Bound:
         for k, op in enumerate(self.prog.ops):
             o = self.ops[k]
             o.kind = op.kind
+            if getattr(op, "win", False):
+                w = o.conv.win if op.kind == prg.OP_CONV else o.win
+                w.pos, w.count = self.t_pos.data_ptr(), self.prog.chunk
             if op.kind == prg.OP_CONV:
                 d = o.conv
                 for f in ("src0", "src1", "xf0", "xf1", "slope0", "slope1", "w", "bias", "aux", "dst", "dst_acc",
@@ -160,13 +166,13 @@ class _Bound:
                 for j, r in enumerate((op.stats, op.gamma0, op.beta0, op.xf0, op.gamma1, op.beta1, op.xf1)):
                     o.p[j] = A(r)
             elif op.kind == prg.OP_NORM_ACT:
-                o.i[0:3] = [op.B, op.P, op.C]
+                o.i[0:4] = [op.B, op.P, op.C, op.T]
                 for j, r in enumerate((op.a, op.xfa, op.slopea, op.b, op.xfb, op.slopeb, op.out)):
                     o.p[j] = A(r)
             elif op.kind == prg.OP_LSTM64:
                 o.i[0:4] = [op.B, op.T, op.F, op.precision]
                 o.f[0] = op.ln_eps
-                for j, r in enumerate((op.x, op.ln_g, op.ln_b, op.wcat, op.bias, op.h_out)):
+                for j, r in enumerate((op.x, op.ln_g, op.ln_b, op.wcat, op.bias, op.h_out, op.c_state)):
                     o.p[j] = A(r)
             elif op.kind == prg.OP_BFW_FS:
                 o.i[0:4] = [op.B, op.T, op.F, op.M]
@@ -176,6 +182,7 @@ class _Bound:
                 nbytes = 4 * op.nfloats
                 o.i[0] = C.c_int32(nbytes & 0xFFFFFFFF).value
                 o.i[1] = nbytes >> 32
+                o.i[2:5] = [op.B, op.T, op.row]
                 o.p[0] = A(op.ptr)
             elif op.kind == prg.OP_GAG_PACK:
                 o.i[0:4] = [op.B, op.T, op.F, prg.GAG_PRE_LD]
@@ -314,6 +321,24 @@ class EaBNet(_HipModule):
                              topo_type=topo_type, intra_connect=intra_connect, norm_type=norm_type)
         self._init_params(param_specs(self.cfg))     # raises NotImplementedError for unsupported topologies
 
+    # -- streaming ------------------------------------------------------------------
+    def stream_begin(self, B: int, T_max: int, chunk: int = 1, F: int = 161, device=None) -> EaBNetStream:
+        """Frame-synchronous inference (BASELINE config 5): returns a stream object whose
+        ``step`` takes ``chunk`` new frames (B, chunk, F, M, 2) and returns the matching output frames.
+        Needs the configuration in which the network really is causal -- ``norm_type="BN"`` in eval mode
+        (running statistics) and ``is_causal=True`` -- and raises NotImplementedError otherwise."""
+        if self.training:
+            raise RuntimeError("stream_begin: call .eval() first (BatchNorm must use its running statistics)")
+        _lib.load()
+        device = torch.device(device) if device is not None else next(self.parameters()).device
+        if device.type != "cuda":
+            raise _lib.EabError("streaming inference runs on MI355X only: move the module to 'cuda'")
+        if chunk < 1 or T_max < 1:
+            raise ValueError("chunk and T_max must be positive")
+        with torch.cuda.device(device):
+            prog = prg.lower(self.cfg, self._numpy_params(), B, T_max, F, precision=self.precision, chunk=chunk)
+            return EaBNetStream(self, _Bound(prog, device), B, T_max, F, chunk)
+
     # -- forward -------------------------------------------------------------------
     def forward(self, inpt: torch.Tensor) -> torch.Tensor:
         """:param inpt: (B, T, F, M, 2) compressed multichannel spectrogram
@@ -350,6 +375,62 @@ class EaBNet(_HipModule):
             # ``.sum(dim=-1)`` on a (B,T,F) tensor) and returns (B,2,T); kept as is
             out = out.sum(dim=-1)
         return out.to(inpt.dtype)
+
+
+class EaBNetStream:
+    """Frame-synchronous inference state of one batch of utterances (``EaBNet.stream_begin``).
+
+    The activations of the whole utterance stay resident in HBM ([B][T_max][..] per layer; 288 GB make
+    that cheap) and are the state: each ``step`` appends ``chunk`` frames of input, replays the captured
+    program restricted to those time rows (eab_time_window: every kernel reads the frame position from
+    device memory) and returns the new output frames.  Results are bit-identical to one offline call
+    on the concatenated input, because every kernel computes a row independently of the tile or launch
+    it falls into and the LSTM state is carried exactly."""
+
+    def __init__(self, net: "EaBNet", bound: _Bound, B: int, T_max: int, F: int, chunk: int):
+        self.net, self.bound, self.B, self.T_max, self.F, self.chunk = net, bound, B, T_max, F, chunk
+        self.pos = 0
+        self._closed = False
+        M = net.M
+        if not (net.use_graph and bound.capture((B, T_max, F, M, 2), (B, 2, T_max, F))):
+            self._in = torch.zeros((B, T_max, F, M, 2), dtype=torch.float32, device=bound.device)
+            self._out = torch.zeros((B, 2, T_max, F), dtype=torch.float32, device=bound.device)
+            bound.bind(self._in.data_ptr(), self._out.data_ptr())
+        else:
+            self._in, self._out = bound.static_in, bound.static_out
+
+    def reset(self) -> None:
+        """Start a new batch of utterances (no buffer needs clearing: position 0 ignores all state)."""
+        self.pos, self._closed = 0, False
+
+    def step(self, x: torch.Tensor) -> torch.Tensor:
+        """x: (B, n, F, M, 2) new frames -> (B, 2, n, F) [(B, 2, n) for topo_type='miso'].  n == chunk, except
+        for the LAST step of an utterance (n < chunk): the recurrent state then sits past the end, so the
+        stream accepts no further frames until ``reset``."""
+        n = x.shape[1]
+        if self._closed:
+            raise RuntimeError("the previous step was a short final chunk: call reset() before the next utterance")
+        if x.ndim != 5 or x.shape[0] != self.B or not 0 < n <= self.chunk or tuple(x.shape[2:]) != (self.F, self.net.M, 2):
+            raise ValueError(f"expected (B={self.B}, n<={self.chunk}, {self.F}, {self.net.M}, 2), got {tuple(x.shape)}")
+        if self.pos + n > self.T_max:
+            raise ValueError(f"utterance longer than the T_max={self.T_max} given to stream_begin")
+        if not x.is_cuda:
+            raise _lib.EabError("EaBNetStream.step needs a CUDA (ROCm) tensor; there is no CPU fallback by design.")
+        with torch.cuda.device(x.device), torch.no_grad():
+            self._in[:, self.pos:self.pos + n].copy_(x, non_blocking=True)
+            if n < self.chunk:                        # rows the kernels touch beyond the new frames must be defined
+                self._in[:, self.pos + n:self.pos + self.chunk].zero_()
+            self.bound.t_pos.fill_(self.pos)
+            if self.bound.graph is not None:
+                self.bound.graph.replay()
+            else:
+                self.bound.run(torch.cuda.current_stream().cuda_stream)
+            out = self._out[:, :, self.pos:self.pos + n].clone()
+        self.pos += n
+        self._closed = n < self.chunk
+        if self.net.topo_type == "miso":
+            out = out.sum(dim=-1)
+        return out.to(x.dtype)
 
 
 class GaGNet(_HipModule):

@@ -115,6 +115,7 @@ class ConvOp:
     fin_eps: float = 0.0
     precision: int = PREC_F32
     korder: int = KORDER_TAP
+    win: bool = False                    # streaming: only the time rows of the current chunk
     name: str = ""
     kind: int = OP_CONV
 
@@ -150,6 +151,8 @@ class NormActOp:
     B: int
     P: int
     C: int
+    T: int = 0
+    win: bool = False
     name: str = ""
     kind: int = OP_NORM_ACT
 
@@ -167,6 +170,8 @@ class LstmOp:
     T: int
     F: int
     precision: int = PREC_F32
+    c_state: Optional[Ref] = None        # streaming: cell state [B*F][64] carried between chunks
+    win: bool = False
     name: str = ""
     kind: int = OP_LSTM64
 
@@ -183,6 +188,7 @@ class BfwOp:
     T: int
     F: int
     M: int
+    win: bool = False
     name: str = ""
     kind: int = OP_BFW_FS
 
@@ -191,6 +197,10 @@ class BfwOp:
 class MemsetOp:
     ptr: Ref
     nfloats: int
+    B: int = 0                           # streaming: the tensor is [B][T][row] and only the chunk's rows are cleared
+    T: int = 0
+    row: int = 0
+    win: bool = False
     name: str = ""
     kind: int = OP_MEMSET0
 
@@ -325,14 +335,24 @@ class Program:
     # valid sequential order, so an executor may ignore both (tests/emulator.py does).
     lanes: List[int] = field(default_factory=list)
     sync: Dict[int, list] = field(default_factory=dict)
+    chunk: int = 0                 # > 0: streaming program, every op works on `chunk` frames from a device-side position
 
 
 class Lowering:
     spec_fn = staticmethod(param_specs)
 
     def __init__(self, cfg, params: Dict[str, np.ndarray], B: int, T: int, F: int = 161,
-                 dump_bfw: bool = False, precision: str = "f32"):
+                 dump_bfw: bool = False, precision: str = "f32", chunk: int = 0):
         cfg.check_supported()
+        self.chunk = chunk
+        if chunk:
+            # streaming = the same program restricted to a moving window of `chunk` frames (eab_time_window):
+            # needs every op to be causal with data-independent statistics
+            if cfg.norm_type != "BN" or not cfg.is_causal:
+                raise NotImplementedError("streaming needs norm_type='BN' (eval) and is_causal=True: InstanceNorm "
+                                          "statistics and centred S-TCM taps look at the whole utterance")
+            if precision != "f32":
+                raise NotImplementedError("streaming carries its recurrent state in fp32: precision must be 'f32'")
         if precision not in ("f32", "f16x3"):
             raise ValueError(f"precision must be 'f32' or 'f16x3', got {precision!r}")
         self.precision = precision
@@ -473,7 +493,8 @@ class Lowering:
                     istride=istride, dt=list(dt), ioff=list(ioff), epi=epi, aux=aux, dst=dst, dst_acc=dst_acc,
                     Cout=N // 2 if epi in (EPI_GLU, EPI_DUALGATE) else N, stats=stats, nsets=nsets,
                     stat_slope0=stat_slopes[0], stat_slope1=stat_slopes[1], stat_tiles=stat_tiles,
-                    stat_tile0=stat_tile0, bm=bm, name=name, precision=prec, korder=korder, **finkw)
+                    stat_tile0=stat_tile0, bm=bm, name=name, precision=prec, korder=korder, win=bool(self.chunk),
+                    **finkw)
         self.ops.append(op)
         self.flops += 2 * self.B * self.T * No * N * len(dt) * (C0 + C1)
         return op
@@ -564,7 +585,7 @@ class Lowering:
         out = self.alloc_act(a.F, a.C)
         self.ops.append(NormActOp(a=a.ref, xfa=a.xf, slopea=a.slope, b=b.ref if b else None,
                                   xfb=b.xf if b else None, slopeb=b.slope if b else None, out=out, B=self.B,
-                                  P=self.T * a.F, C=a.C, name=name))
+                                  P=self.T * a.F, C=a.C, T=self.T, win=bool(self.chunk), name=name))
         act = Act(out, a.F, a.C)
         self.taps[name] = act
         return act
@@ -670,7 +691,8 @@ class Lowering:
         perm = (k % c) * Fb + k // c
         xt = Act(x.ref, 1, cfg.d_feat)
         x_acc = self.alloc_act(1, cfg.d_feat)
-        self.ops.append(MemsetOp(x_acc, B * T * cfg.d_feat, name="stcns.acc0"))
+        self.ops.append(MemsetOp(x_acc, B * T * cfg.d_feat, B=B, T=T, row=cfg.d_feat, win=bool(self.chunk),
+                                 name="stcns.acc0"))
         for gi in range(cfg.q):
             for i in range(cfg.p):
                 xt = self.tcm(f"stcns.{gi}.tcm_list.{i}", xt, 2 ** i, x_acc if i == cfg.p - 1 else None, perm)
@@ -704,10 +726,11 @@ class Lowering:
             if bfw is not None:
                 self.taps["bf_w"] = Act(bfw, F, 2 * M)
             self.ops.append(BfwOp(y1=e.ref, w2=self.W.add("bf_map.weight#rows", w2), b2=self.W.add("bf_map.bias#rows", b2),
-                                  x=Ref("in"), out=Ref("out"), bfw=bfw, B=B, T=T, F=F, M=M, name="bf_map+fs"))
+                                  x=Ref("in"), out=Ref("out"), bfw=bfw, B=B, T=T, F=F, M=M, win=bool(self.chunk),
+                                  name="bf_map+fs"))
             self.flops += 2 * B * T * F * 64 * wk.shape[0]
             return Program(cfg, B, T, F, self.ops, self.W.flat(), self.act_size, self.taps, self.flops,
-                           lanes=[0] * len(self.ops))
+                           lanes=[0] * len(self.ops), chunk=self.chunk)
 
         # LSTM_BF (EaBNet.py:600-614)
         h = e
@@ -720,7 +743,8 @@ class Lowering:
                                    ln_b=self.vec("bf_map.norm.bias") if li == 0 else None, ln_eps=EPS_LN,
                                    wcat=self.W.add(f"{p}#wcat", wcat), bias=self.W.add(f"{p}#bias", bias),
                                    h_out=out, B=B, T=T, F=F, name=p,
-                                   precision=PREC_F16X3 if self.precision == "f16x3" else PREC_F32))
+                                   precision=PREC_F16X3 if self.precision == "f16x3" else PREC_F32,
+                                   c_state=self.alloc(B * F * 64) if self.chunk else None, win=bool(self.chunk)))
             self.flops += 2 * B * T * F * 256 * 128
             h = Act(out, F, 64)
             self.taps[p] = h
@@ -732,10 +756,11 @@ class Lowering:
         if bfw is not None:
             self.taps["bf_w"] = Act(bfw, F, 2 * M)
         self.ops.append(BfwOp(y1=y1, w2=self.vec("bf_map.w_dnn.2.weight"), b2=self.vec("bf_map.w_dnn.2.bias"),
-                              x=Ref("in"), out=Ref("out"), bfw=bfw, B=B, T=T, F=F, M=M, name="bf_map.w_dnn.2+fs"))
+                              x=Ref("in"), out=Ref("out"), bfw=bfw, B=B, T=T, F=F, M=M, win=bool(self.chunk),
+                              name="bf_map.w_dnn.2+fs"))
         self.flops += 2 * B * T * F * 64 * 2 * M
         return Program(cfg, B, T, F, self.ops, self.W.flat(), self.act_size, self.taps, self.flops,
-                       lanes=[0] * len(self.ops))
+                       lanes=[0] * len(self.ops), chunk=self.chunk)
 
 
 class GagLowering(Lowering):
@@ -862,7 +887,11 @@ class GagLowering(Lowering):
 
 
 def lower(cfg, params: Dict[str, np.ndarray], B: int, T: int, F: int = 161,
-          dump_bfw: bool = False, precision: str = "f32") -> Program:
+          dump_bfw: bool = False, precision: str = "f32", chunk: int = 0) -> Program:
+    """chunk > 0 lowers the streaming form (EaBNet only): T is then the longest utterance the resident
+    activations can hold and every op advances `chunk` frames per replay."""
     if isinstance(cfg, GagConfig):
+        if chunk:
+            raise NotImplementedError("streaming is implemented for the beam-former (EaBNet)")
         return GagLowering(cfg, params, B, T, F, False, precision).build()
-    return Lowering(cfg, params, B, T, F, dump_bfw, precision).build()
+    return Lowering(cfg, params, B, T, F, dump_bfw, precision, chunk).build()

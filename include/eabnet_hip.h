@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EAB_ABI_VERSION 1
+#define EAB_ABI_VERSION 2
 
 #define EAB_OK          0
 #define EAB_EINVAL      1   /* bad argument (shape, alignment, limit) */
@@ -143,6 +143,18 @@ int eab_filter_sum_f32(const float* w, const float* x, float* y, int B, int T, i
                                * [Cout,2Cout) through transform 1 (xf1/slope1) of the SAME tensor;
                                * out[c] = acc[c] * sigmoid(acc[Cout + c]); rows interleaved as for GLU */
 
+/* Time window for streaming inference (causal programs without data-dependent statistics, i.e.
+ * norm_type = "BN" in eval mode; SURVEY §8f N4 / BASELINE config 5).  The activations of the whole
+ * utterance [B][T][..] stay resident; when `pos` is non-NULL an op computes only the time rows
+ *     t in [*pos, min(*pos + count, T))
+ * of its output and leaves every other row as it is -- older rows are the "state" later chunks read.
+ * `pos` points to DEVICE memory, so ONE captured hipGraph is replayed for successive chunks after a
+ * 4-byte update of the position; the launch geometry depends on `count` only. */
+typedef struct eab_time_window {
+    const int32_t* pos;
+    int32_t count;
+} eab_time_window;
+
 typedef struct eab_conv_desc {
     /* sources, channels-last [B][T][Fin][C*]; src1 == NULL when there is no concat */
     const float* src0;
@@ -207,6 +219,9 @@ typedef struct eab_conv_desc {
      * which stages the input patch of one 16-channel chunk once in LDS and lets every tap
      * read it at a shifted position.  Requires eab_conv_patch_positions(d) <= 352. */
     int32_t korder;
+    /* streaming: restrict the launch to a window of time rows (see eab_time_window below);
+     * needs stats == NULL, fin_stats == NULL and causal taps (dt <= 0) */
+    eab_time_window win;
 } eab_conv_desc;
 
 #define EAB_PREC_F32   0
@@ -293,19 +308,34 @@ typedef struct eab_op {
     int32_t i[8];
     float   f[2];
     const void* p[10];
+    eab_time_window win;    /* every kind except CONV (which carries it in conv.win) and IN_FINALIZE */
     eab_conv_desc conv;     /* EAB_OP_CONV only */
 } eab_op;
 /* field use per kind:
  *  IN_FINALIZE i = {B, C, nsets, stat_tiles, count}       f = {eps}
  *              p = {stats, gamma0, beta0, xf0, gamma1, beta1, xf1}
- *  NORM_ACT    i = {B, P, C}  p = {a, xfa, slopea, b, xfb, slopeb, out}
- *  LSTM64      i = {B, T, F, precision}  f = {ln_eps}  p = {x, ln_g, ln_b, wcat, bias, h_out}
+ *  NORM_ACT    i = {B, P, C, T}  p = {a, xfa, slopea, b, xfb, slopeb, out}   (T only read when windowed)
+ *  LSTM64      i = {B, T, F, precision}  f = {ln_eps}  p = {x, ln_g, ln_b, wcat, bias, h_out, c_state}
  *  BFW_FS      i = {B, T, F, M}  p = {y1, w2, b2, x, out, bfw}
- *  MEMSET0     p = {ptr}  i = {bytes_lo, bytes_hi}
+ *  MEMSET0     p = {ptr}  i = {bytes_lo, bytes_hi, B, T, row_floats}   (B, T, row_floats only when windowed)
  *  GAG_PACK    i = {B, T, F, ld}  p = {inpt, pre_x, enc_in, pre}
  *  GAG_CRM     i = {B, T, F, ld, lin_ld, act}  p = {pre, g, r, i, pre_out, planar}
  */
 int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream);
+
+/* Windowed twins of the non-conv ops (same semantics restricted to the rows of `win`; win.pos == NULL
+ * = the whole utterance).  eab_lstm64_stream_f32 additionally carries the recurrent state: the hidden
+ * state of row *pos-1 is read back from h_out, the cell state lives in c_state [B*F][64] (read when
+ * *pos > 0, always written).  eab_zero_rows_f32 clears rows of a [B][T][row_floats] tensor. */
+int eab_norm_act_win_f32(const float* a, const float* xfa, const float* slopea, const float* b,
+                         const float* xfb, const float* slopeb, float* out, int B, int T, int rows_per_t, int C,
+                         eab_time_window win, eab_stream_t stream);
+int eab_lstm64_stream_f32(const float* x, const float* ln_g, const float* ln_b, float ln_eps, const float* wcat,
+                          const float* bias, float* h_out, float* c_state, int B, int T, int F, int precision,
+                          eab_time_window win, eab_stream_t stream);
+int eab_bfw_filter_sum_win_f32(const float* y1, const float* w2, const float* b2, const float* x, float* out,
+                               float* bfw, int B, int T, int F, int M, eab_time_window win, eab_stream_t stream);
+int eab_zero_rows_f32(float* ptr, int B, int T, int row_floats, eab_time_window win, eab_stream_t stream);
 
 /* struct-layout handshake for foreign-function mirrors of the structs above */
 int eab_sizeof_conv_desc(void);

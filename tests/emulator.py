@@ -276,6 +276,47 @@ class Emulator:
              prg.OP_GAG_CRM: self.gag_crm,
              prg.OP_MEMSET0: lambda o: self.v(o.ptr, (o.nfloats,)).fill(0)}[op.kind](op)
 
+    def _outputs(self, op):
+        """(ref, shape, time axis) of everything an op writes, for the streaming window emulation"""
+        p = self.p
+        if op.kind == prg.OP_CONV:
+            o = [(op.dst, (op.B, op.T, op.Fout * op.Cout), 1)]
+            return o + ([(op.dst_acc, (op.B, op.T, op.Fout * op.Cout), 1)] if op.dst_acc is not None else [])
+        if op.kind == prg.OP_NORM_ACT:
+            return [(op.out, (op.B, op.T, (op.P // op.T) * op.C), 1)]
+        if op.kind == prg.OP_LSTM64:
+            return [(op.h_out, (op.B, op.T, op.F * 64), 1)]
+        if op.kind == prg.OP_BFW_FS:
+            o = [(op.out, (op.B, 2, op.T, op.F), 2)]
+            return o + ([(op.bfw, (op.B, op.T, op.F * op.M * 2), 1)] if op.bfw is not None else [])
+        if op.kind == prg.OP_MEMSET0:
+            return [(op.ptr, (op.B, op.T, op.row), 1)]
+        raise ValueError(op.kind)
+
+    def run_stream(self):
+        """Streaming semantics (eab_time_window): for each chunk every op may only change the time rows
+        [pos, pos + chunk) of its outputs.  Emulated by running the op on the whole utterance (rows it has
+        not reached yet hold NaN poison; causality keeps that out of the window) and restoring every row
+        outside the window.  The LSTM's carried state equals a recomputation from t = 0, so it needs no
+        special case here; the device kernel's state handling is what the GPU test checks against this."""
+        p = self.p
+        assert p.chunk > 0 and all(getattr(op, "win", False) for op in p.ops)
+        for pos in range(0, p.T, p.chunk):
+            hi = min(pos + p.chunk, p.T)
+            for op in p.ops:
+                outs = self._outputs(op)
+                saved = [self.v(r, shp).copy() for r, shp, _ in outs]
+                with np.errstate(invalid="ignore"):
+                    self.step(op)
+                for (r, shp, ax), old in zip(outs, saved):
+                    cur = self.v(r, shp)
+                    idx = [slice(None)] * len(shp)
+                    idx[ax] = slice(pos, hi)
+                    new = cur[tuple(idx)].copy()
+                    cur[:] = old
+                    cur[tuple(idx)] = new
+        return self.arena["out"].reshape(p.B, 2, p.T, p.F)
+
     def run(self):
         for op in self.p.ops:
             self.step(op)

@@ -647,3 +647,52 @@ def test_config4_two_stage_ddp_bf16_training_step(dev):
         assert y.shape == (2, 2, 24, 161) and torch.isfinite(y).all()
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------ streaming (BASELINE config 5)
+@pytest.mark.parametrize("chunk,use_graph", [(1, True), (7, True), (16, False)])
+def test_streaming_equals_offline_bit_for_bit(dev, chunk, use_graph):
+    """Frame-synchronous inference with BatchNorm (eval) norms: feeding the utterance chunk by chunk
+    (kernels windowed through the device-side frame position, LSTM state carried) returns exactly the
+    frames of one offline call, which is pinned to the reference by the var_bn fixture.  T = 45 makes
+    the last chunk short for chunk 7 and 16."""
+    net = _model(4, 201, dev, norm_type="BN")              # parameters of the var_bn fixture
+    net.use_graph = use_graph
+    B, T = 2, 45
+    x = torch.from_numpy(paramgen.make_spec_input(B, T, 161, 4, 600)).to(dev)
+    with torch.no_grad():
+        off = net(x)
+    st = net.stream_begin(B, T_max=48, chunk=chunk)
+    outs = [st.step(x[:, t:t + chunk]) for t in range(0, T, chunk)]
+    y = torch.cat(outs, dim=2)
+    assert y.shape == off.shape
+    assert torch.equal(y, off)
+    if T % chunk:
+        with pytest.raises(RuntimeError):
+            st.step(x[:, :chunk])
+    st.reset()                                              # second utterance on the same stream object
+    x2 = torch.from_numpy(paramgen.make_spec_input(B, T, 161, 4, 601)).to(dev)
+    with torch.no_grad():
+        off2 = net(x2)
+    y2 = torch.cat([st.step(x2[:, t:t + chunk]) for t in range(0, T, chunk)], dim=2)
+    assert torch.equal(y2, off2)
+
+
+def test_streaming_variants_and_refusals(dev):
+    """cnn head + plain U-Net encoder stream too; InstanceNorm / non-causal / f16x3 are refused."""
+    kw = dict(is_u2=False, norm_type="BN", bf_type="cnn")
+    net = _model(4, 207, dev, **kw)
+    x = torch.from_numpy(paramgen.make_spec_input(1, 21, 161, 4, 602)).to(dev)
+    with torch.no_grad():
+        off = net(x)
+    st = net.stream_begin(1, T_max=21, chunk=3)
+    assert torch.equal(torch.cat([st.step(x[:, t:t + 3]) for t in range(0, 21, 3)], dim=2), off)
+    with pytest.raises(ValueError):
+        st.step(x[:, :3])                                   # past T_max
+    with pytest.raises(NotImplementedError):
+        _model(4, 1, dev).stream_begin(1, 8)                # InstanceNorm looks at the whole utterance
+    with pytest.raises(NotImplementedError):
+        _model(4, 1, dev, norm_type="BN", is_causal=False).stream_begin(1, 8)
+    net.precision = "f16x3"
+    with pytest.raises(NotImplementedError):
+        net.stream_begin(1, 8)

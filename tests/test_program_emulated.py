@@ -173,3 +173,24 @@ def test_emulated_gagnet_matches_reference(name, precision):
     assert y.shape == (cfg.q, 2, 2, 14, 161)
     for j in range(cfg.q):
         assert_close(y[j].transpose(0, 1, 3, 2), g[f"out{j}"], TOL_EMU, f"{name} stage {j}")
+
+
+@pytest.mark.parametrize("chunk", [1, 5])
+def test_emulated_streaming_program_equals_offline(chunk):
+    """Streaming lowering (BN eval + causal): the same op list with every op windowed to the current
+    chunk reproduces the offline result of the same parameters exactly (and through it the reference
+    fixture var_bn)."""
+    g = load("var_bn.npz")
+    cfg = NetConfig(M=4, norm_type="BN")
+    P = paramgen.make_params(param_specs(cfg), int(g["param_seed"]))
+    x = paramgen.make_spec_input(2, 20, 161, 4, int(g["input_seed"]))[:, :12]
+    off = Emulator(prg.lower(cfg, P, 2, 12, 161), x).run()
+    prog = prg.lower(cfg, P, 2, 12, 161, chunk=chunk)
+    assert prog.chunk == chunk and all(op.win for op in prog.ops)
+    y = Emulator(prog, x).run_stream()
+    assert np.array_equal(y, off)
+    for bad in (dict(), dict(norm_type="BN", is_causal=False)):
+        with pytest.raises(NotImplementedError):
+            prg.lower(NetConfig(M=4, **bad), paramgen.make_params(param_specs(NetConfig(M=4, **bad)), 1), 1, 8, 161, chunk=2)
+    with pytest.raises(NotImplementedError):
+        prg.lower(cfg, P, 1, 8, 161, chunk=2, precision="f16x3")
