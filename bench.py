@@ -377,6 +377,29 @@ def main():
             assert bool(torch.isfinite(w_out).all())
             nxt[prec] = {"ms_per_step": 1e3 * dtw, "frames_per_s": B_PER_GPU * T / dtw,
                          "postfilter_ms_per_step": e0.elapsed_time(e1) / 10}
+        # BASELINE config 5 shape: 16 microphones, 8-s utterance, frame-synchronous (BatchNorm norms, causal):
+        # latency of one step of `chunk` 10-ms frames = one hipGraph replay of the windowed program
+        torch.manual_seed(2)
+        sn = eabnet_amd.EaBNet(M=16, norm_type="BN").to(dev).eval()
+        stream_rows = {"config": "B=1, M=16, T_max=801 (8 s), norm_type=BN, fp32", "hop_ms": 10.0}
+        for chunk in (1, 16):
+            st = sn.stream_begin(1, T_max=801, chunk=chunk)
+            xs = 0.3 * torch.randn(1, chunk, 161, 16, 2, device=dev)
+            for _ in range(3):
+                st.step(xs)
+            torch.cuda.synchronize()
+            nstep = min(40, (801 - 3 * chunk) // chunk)
+            t0 = time.perf_counter()
+            for _ in range(nstep):
+                ys = st.step(xs)
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - t0) / nstep
+            assert bool(torch.isfinite(ys).all())
+            stream_rows[f"chunk{chunk}"] = {"ms_per_step": 1e3 * dts, "rtf": dts / (chunk * 0.010),
+                                            "algorithmic_latency_ms": 10.0 * chunk + 10.0}
+            st = None
+        nxt["streaming"] = stream_rows
+        sn = None
         out["next_rows"] = nxt
         two = None
         torch.cuda.empty_cache()
