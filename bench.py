@@ -48,8 +48,8 @@ def mac_per_frame(M: int) -> int:
 
 def conv_kernel_mac_per_frame(M: int) -> int:
     """The share executed by conv_gemm_kernel: everything except the two LSTM
-    layers (2*161*256*128) and w_dnn[2] (161*64*2M)."""
-    return mac_per_frame(M) - 2 * 161 * 256 * 128 - 161 * 64 * 2 * M
+    layers (2*161*256*128) and the w_dnn MLP (161*64*(64 + 2M), fused with the filter-and-sum)."""
+    return mac_per_frame(M) - 2 * 161 * 256 * 128 - 161 * 64 * (64 + 2 * M)
 
 
 def make_model(M: int, device, seed: int = 0):
@@ -260,7 +260,9 @@ def main():
             tag = "conv_gemm_kernel<2, 2, 1, 1, 0, true, %d, true>" % (0 if a.precision == "f32" else 1)
             ent = next(v for k, v in pmc.items() if tag in k)
             c = ent["counters"]
-            traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / ent["dispatches"]
+            nd = ent.get("dispatches_of", {})
+            traffic = (2.0 * c["FETCH_SIZE"] / nd.get("FETCH_SIZE", ent["dispatches"])
+                       + c["WRITE_SIZE"] / nd.get("WRITE_SIZE", ent["dispatches"])) * 1024.0
         except Exception:                                   # noqa: BLE001 - no committed profile: leave null
             traffic = None
         out["roofline"] = {

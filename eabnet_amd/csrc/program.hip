@@ -84,9 +84,10 @@ extern "C" int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream
                                            o.i[0], o.i[1], o.i[2], o.i[3], o.win, stream);
                 break;
             case EAB_OP_BFW_FS:
-                rc = eab_bfw_filter_sum_win_f32((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
-                                                (const float*)o.p[3], (float*)o.p[4], (float*)o.p[5], o.i[0], o.i[1],
-                                                o.i[2], o.i[3], o.win, stream);
+                rc = eab_mlp_bfw_filter_sum_f32((const float*)o.p[0], (const float*)o.p[6], (const float*)o.p[7],
+                                                (const float*)o.p[1], (const float*)o.p[2], (const float*)o.p[3],
+                                                (float*)o.p[4], (float*)o.p[5], o.i[0], o.i[1], o.i[2], o.i[3], o.win,
+                                                stream);
                 break;
             case EAB_OP_MEMSET0: {
                 if (o.win.pos) {

@@ -176,7 +176,7 @@ class _Bound:
                     o.p[j] = A(r)
             elif op.kind == prg.OP_BFW_FS:
                 o.i[0:4] = [op.B, op.T, op.F, op.M]
-                for j, r in enumerate((op.y1, op.w2, op.b2, op.x, op.out, op.bfw)):
+                for j, r in enumerate((op.y1, op.w2, op.b2, op.x, op.out, op.bfw, op.w1, op.b1)):
                     o.p[j] = A(r)
             elif op.kind == prg.OP_MEMSET0:
                 nbytes = 4 * op.nfloats

@@ -188,6 +188,8 @@ class BfwOp:
     T: int
     F: int
     M: int
+    w1: Optional[Ref] = None             # first Linear of the MLP fused in (then y1 is the LSTM output h)
+    b1: Optional[Ref] = None
     win: bool = False
     name: str = ""
     kind: int = OP_BFW_FS
@@ -748,17 +750,16 @@ class Lowering:
             self.flops += 2 * B * T * F * 256 * 128
             h = Act(out, F, 64)
             self.taps[p] = h
-        w1 = self.W.add("bf_map.w_dnn.0.weight#packed", pack_taps(self.P["bf_map.w_dnn.0.weight"][:, :, None], [0]))
-        y1 = self.alloc_act(F, 64)
-        self.emit_conv("bf_map.w_dnn.0", [h], w1, self.vec("bf_map.w_dnn.0.bias"), 64, 64, F, F, 1, 0, 1, [0], [0],
-                       EPI_RELU, y1)
+        # w_dnn (Linear 64->64, ReLU, Linear 64->2M; EaBNet.py:594-596) + filter-and-sum: one kernel, the
+        # hidden layer lives in LDS only
         bfw = self.alloc(B * T * F * 2 * M) if self.dump_bfw else None
         if bfw is not None:
             self.taps["bf_w"] = Act(bfw, F, 2 * M)
-        self.ops.append(BfwOp(y1=y1, w2=self.vec("bf_map.w_dnn.2.weight"), b2=self.vec("bf_map.w_dnn.2.bias"),
+        self.ops.append(BfwOp(y1=h.ref, w1=self.vec("bf_map.w_dnn.0.weight"), b1=self.vec("bf_map.w_dnn.0.bias"),
+                              w2=self.vec("bf_map.w_dnn.2.weight"), b2=self.vec("bf_map.w_dnn.2.bias"),
                               x=Ref("in"), out=Ref("out"), bfw=bfw, B=B, T=T, F=F, M=M, win=bool(self.chunk),
-                              name="bf_map.w_dnn.2+fs"))
-        self.flops += 2 * B * T * F * 64 * 2 * M
+                              name="bf_map.w_dnn+fs"))
+        self.flops += 2 * B * T * F * 64 * (64 + 2 * M)
         return Program(cfg, B, T, F, self.ops, self.W.flat(), self.act_size, self.taps, self.flops,
                        lanes=[0] * len(self.ops), chunk=self.chunk)
 

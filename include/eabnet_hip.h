@@ -316,7 +316,7 @@ typedef struct eab_op {
  *              p = {stats, gamma0, beta0, xf0, gamma1, beta1, xf1}
  *  NORM_ACT    i = {B, P, C, T}  p = {a, xfa, slopea, b, xfb, slopeb, out}   (T only read when windowed)
  *  LSTM64      i = {B, T, F, precision}  f = {ln_eps}  p = {x, ln_g, ln_b, wcat, bias, h_out, c_state}
- *  BFW_FS      i = {B, T, F, M}  p = {y1, w2, b2, x, out, bfw}
+ *  BFW_FS      i = {B, T, F, M}  p = {y1 | h, w2, b2, x, out, bfw, w1, b1}   (w1, b1 NULL: y1 given)
  *  MEMSET0     p = {ptr}  i = {bytes_lo, bytes_hi, B, T, row_floats}   (B, T, row_floats only when windowed)
  *  GAG_PACK    i = {B, T, F, ld}  p = {inpt, pre_x, enc_in, pre}
  *  GAG_CRM     i = {B, T, F, ld, lin_ld, act}  p = {pre, g, r, i, pre_out, planar}
@@ -336,6 +336,14 @@ int eab_lstm64_stream_f32(const float* x, const float* ln_g, const float* ln_b, 
 int eab_bfw_filter_sum_win_f32(const float* y1, const float* w2, const float* b2, const float* x, float* out,
                                float* bfw, int B, int T, int F, int M, eab_time_window win, eab_stream_t stream);
 int eab_zero_rows_f32(float* ptr, int B, int T, int row_floats, eab_time_window win, eab_stream_t stream);
+
+/* K12 complete + K13: the whole w_dnn MLP of LSTM_BF (EaBNet.py:594-596,612-613) and the filter-and-sum in one
+ * kernel:  y1 = relu(h W1^T + b1) (fp32 MFMA per 64-bin tile, never written to HBM), W = y1 W2^T + b2,
+ * out = sum_m W_m X_m.   h [B][T][F][64] (the second LSTM's output), w1 [64][64], b1 [64]; the rest as
+ * eab_bfw_filter_sum_win_f32.  w1 == b1 == NULL: y1 is read from `h` as is (the pointwise cnn / miso heads). */
+int eab_mlp_bfw_filter_sum_f32(const float* h, const float* w1, const float* b1, const float* w2, const float* b2,
+                               const float* x, float* out, float* bfw, int B, int T, int F, int M,
+                               eab_time_window win, eab_stream_t stream);
 
 /* struct-layout handshake for foreign-function mirrors of the structs above */
 int eab_sizeof_conv_desc(void);

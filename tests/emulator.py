@@ -239,6 +239,8 @@ class Emulator:
     def bfw(self, op: prg.BfwOp):
         B, T, F, M = op.B, op.T, op.F, op.M
         y1 = self.v(op.y1, (B, T, F, 64))
+        if op.w1 is not None:           # fused first Linear + ReLU (exact fp32 in every precision mode)
+            y1 = np.maximum(y1 @ self.v(op.w1, (64, 64)).T + self.v(op.b1, (64,)), 0.0).astype(np.float32)
         w = y1 @ self.v(op.w2, (2 * M, 64)).T + self.v(op.b2, (2 * M,))
         w = w.reshape(B, T, F, M, 2)
         if op.bfw is not None:

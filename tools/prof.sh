@@ -16,7 +16,7 @@ if [ -n "$2" ]; then
   i=0
   for grp in $2; do
     i=$((i+1))
-    timeout -k 10 200 rocprofv3 --kernel-trace --pmc ${grp//,/ } --output-format csv -d $OUT/pmc$i -o pmc -- \
+    timeout -k 10 420 rocprofv3 --kernel-trace --pmc ${grp//,/ } --output-format csv -d $OUT/pmc$i -o pmc -- \
       python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline $BENCH_ARGS >> $OUT/log.txt 2>&1
     echo "[prof] pmc$i ($grp) rc=$?" | tee -a $OUT/log.txt
   done

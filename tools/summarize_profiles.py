@@ -22,13 +22,17 @@ for d in sorted(glob.glob(os.path.join(src, "pmc*"))):
     if not cc:
         continue
     disp = collections.defaultdict(set)
+    names = collections.defaultdict(set)
     for r in csv.DictReader(open(cc[0])):
         k = r["Kernel_Name"]
-        e = out.setdefault(k, {"counters": collections.defaultdict(float)})
+        e = out.setdefault(k, {"counters": collections.defaultdict(float), "dispatches_of": {}})
         e["counters"][r["Counter_Name"]] += float(r["Counter_Value"])
         disp[k].add(r["Dispatch_Id"])
+        names[k].add(r["Counter_Name"])
     for k, s in disp.items():
-        out[k]["dispatches"] = len(s)
+        out[k]["dispatches"] = len(s)                 # of the last pass read; per counter: dispatches_of
+        for c in names[k]:
+            out[k]["dispatches_of"][c] = len(s)       # passes may come from runs with different step counts
     if kt:
         dur = collections.defaultdict(float)
         for r in csv.DictReader(open(kt[0])):
