@@ -402,6 +402,25 @@ def main():
             st = None
         nxt["streaming"] = stream_rows
         sn = None
+        # the same, wave in -> wave out through the two-stage model (StreamingEnhancer: STFT windows, streamed
+        # beam-former + post-filter, ISTFT windows), one 10-ms hop of 16-microphone samples per push
+        pb = argparse.Namespace(**{**vars(pa), "M": 16, "norm_type": "BN", "gagnet_norm_type": "BN"})
+        tw = eabnet_amd.make_eabnet_with_postnet(pb).to(dev).eval()
+        enh = eabnet_amd.StreamingEnhancer(tw, B=1, seconds=8.0, chunk=1)
+        hop_samples = 0.05 * torch.randn(1, 16, 160, device=dev)
+        for _ in range(5):
+            enh.push(hop_samples)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(40):
+            wv = enh.push(hop_samples)
+        torch.cuda.synchronize()
+        dtp = (time.perf_counter() - t0) / 40
+        assert wv.shape == (1, 160) and bool(torch.isfinite(wv).all())
+        nxt["streaming_wave_to_wave"] = {"config": "B=1, M=16, two-stage model with BN norms, one hop (160 samples) per push",
+                                         "ms_per_push": 1e3 * dtp, "rtf": dtp / 0.010,
+                                         "latency_ms": 20.0 + 1e3 * dtp}
+        tw = enh = None
         out["next_rows"] = nxt
         two = None
         torch.cuda.empty_cache()

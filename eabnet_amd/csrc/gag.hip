@@ -15,11 +15,15 @@
 
 #define GAG_THREADS 256
 
+// Both kernels: one (b, t) row per workgroup; with a streaming window (eab_time_window) the grid covers
+// [B][count] rows starting at frame *t_pos and rows past the utterance end exit.
 __global__ __launch_bounds__(GAG_THREADS) void gag_pack_kernel(const float* __restrict__ inpt, const float* __restrict__ pre_x,
                                                                float* __restrict__ enc_in, float* __restrict__ pre,
-                                                               int T, int F, int ld) {
-    const int bt = blockIdx.x;                       // one (b, t) row per workgroup
-    const int b = bt / T, t = bt - b * T;
+                                                               int T, int F, int ld, const int* __restrict__ t_pos, int t_count) {
+    const int Tw = t_pos ? t_count : T;
+    const int b = blockIdx.x / Tw, t = (t_pos ? *t_pos : 0) + (blockIdx.x - b * Tw);
+    if (t >= T) return;
+    const int bt = b * T + t;
     const size_t plane = (size_t)T * F;
     const float* ir = inpt + ((size_t)b * 2) * plane + (size_t)t * F;
     const float* pr = pre_x + ((size_t)b * 2) * plane + (size_t)t * F;
@@ -41,9 +45,12 @@ __device__ __forceinline__ float gag_act(float v, int act) {
 __global__ __launch_bounds__(GAG_THREADS) void gag_crm_kernel(const float* __restrict__ pre, const float* __restrict__ g,
                                                               const float* __restrict__ r, const float* __restrict__ i,
                                                               float* __restrict__ pre_out, float* __restrict__ planar,
-                                                              int T, int F, int ld, int lin_ld, int act) {
-    const int bt = blockIdx.x;
-    const int b = bt / T, t = bt - b * T;
+                                                              int T, int F, int ld, int lin_ld, int act,
+                                                              const int* __restrict__ t_pos, int t_count) {
+    const int Tw = t_pos ? t_count : T;
+    const int b = blockIdx.x / Tw, t = (t_pos ? *t_pos : 0) + (blockIdx.x - b * Tw);
+    if (t >= T) return;
+    const int bt = b * T + t;
     const size_t plane = (size_t)T * F;
     float* o_r = planar + ((size_t)b * 2) * plane + (size_t)t * F;
     for (int f = threadIdx.x; f < ld / 2; f += GAG_THREADS) {
@@ -60,20 +67,23 @@ __global__ __launch_bounds__(GAG_THREADS) void gag_crm_kernel(const float* __res
 }
 
 extern "C" int eab_gag_pack_f32(const float* inpt, const float* pre_x, float* enc_in, float* pre, int B, int T, int F,
-                                int ld, eab_stream_t stream) {
+                                int ld, eab_time_window win, eab_stream_t stream) {
     EAB_CHECK_ARG(inpt && pre_x && enc_in && pre && B > 0 && T > 0 && F > 0);
     EAB_CHECK_ARG(ld >= 2 * F && (ld % 4) == 0 && (long long)B * T < (1ll << 31));
-    hipLaunchKernelGGL(gag_pack_kernel, dim3(B * T), dim3(GAG_THREADS), 0, eab_stream(stream), inpt, pre_x, enc_in, pre, T,
-                       F, ld);
+    EAB_CHECK_ARG(win.pos == nullptr || win.count > 0);
+    hipLaunchKernelGGL(gag_pack_kernel, dim3(B * (win.pos ? win.count : T)), dim3(GAG_THREADS), 0, eab_stream(stream), inpt,
+                       pre_x, enc_in, pre, T, F, ld, win.pos, win.count);
     EAB_RETURN_LAUNCH_STATUS();
 }
 
 extern "C" int eab_gag_crm_f32(const float* pre, const float* g, const float* r, const float* i, float* pre_out,
-                               float* planar, int B, int T, int F, int ld, int lin_ld, int act, eab_stream_t stream) {
+                               float* planar, int B, int T, int F, int ld, int lin_ld, int act, eab_time_window win,
+                               eab_stream_t stream) {
     EAB_CHECK_ARG(pre && g && r && i && pre_out && planar && B > 0 && T > 0 && F > 0);
     EAB_CHECK_ARG(ld >= 2 * F && (ld % 4) == 0 && lin_ld >= F && (long long)B * T < (1ll << 31));
     EAB_CHECK_ARG(act == EAB_ACT_SIGMOID || act == EAB_ACT_TANH || act == EAB_ACT_RELU);
-    hipLaunchKernelGGL(gag_crm_kernel, dim3(B * T), dim3(GAG_THREADS), 0, eab_stream(stream), pre, g, r, i, pre_out, planar,
-                       T, F, ld, lin_ld, act);
+    EAB_CHECK_ARG(win.pos == nullptr || win.count > 0);
+    hipLaunchKernelGGL(gag_crm_kernel, dim3(B * (win.pos ? win.count : T)), dim3(GAG_THREADS), 0, eab_stream(stream), pre, g,
+                       r, i, pre_out, planar, T, F, ld, lin_ld, act, win.pos, win.count);
     EAB_RETURN_LAUNCH_STATUS();
 }

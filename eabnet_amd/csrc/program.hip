@@ -110,12 +110,12 @@ extern "C" int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream
             }
             case EAB_OP_GAG_PACK:
                 rc = eab_gag_pack_f32((const float*)o.p[0], (const float*)o.p[1], (float*)o.p[2], (float*)o.p[3], o.i[0],
-                                      o.i[1], o.i[2], o.i[3], stream);
+                                      o.i[1], o.i[2], o.i[3], o.win, stream);
                 break;
             case EAB_OP_GAG_CRM:
                 rc = eab_gag_crm_f32((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
                                      (const float*)o.p[3], (float*)o.p[4], (float*)o.p[5], o.i[0], o.i[1], o.i[2], o.i[3],
-                                     o.i[4], o.i[5], stream);
+                                     o.i[4], o.i[5], o.win, stream);
                 break;
             default:
                 rc = EAB_EINVAL;

@@ -289,6 +289,24 @@ class _HipModule(nn.Module):
             self._packed_version[key] = fp
         return bound
 
+    # -- streaming ------------------------------------------------------------------
+    def stream_begin(self, B: int, T_max: int, chunk: int = 1, F: int = 161, device=None) -> EaBNetStream:
+        """Frame-synchronous inference (BASELINE config 5; SURVEY §8f N4): returns a stream object whose
+        ``step`` takes ``chunk`` new frames and returns the matching output frames (see EaBNetStream.step).
+        Needs the configuration in which the network really is causal -- ``norm_type="BN"`` in eval mode
+        (running statistics) and ``is_causal=True`` -- and raises NotImplementedError otherwise."""
+        if self.training:
+            raise RuntimeError("stream_begin: call .eval() first (BatchNorm must use its running statistics)")
+        _lib.load()
+        device = torch.device(device) if device is not None else next(self.parameters()).device
+        if device.type != "cuda":
+            raise _lib.EabError("streaming inference runs on MI355X only: move the module to 'cuda'")
+        if chunk < 1 or T_max < 1:
+            raise ValueError("chunk and T_max must be positive")
+        with torch.cuda.device(device):
+            prog = prg.lower(self.cfg, self._numpy_params(), B, T_max, F, precision=self.precision, chunk=chunk)
+            return EaBNetStream(self, _Bound(prog, device), B, T_max, F, chunk)
+
     def _needs_graph(self, *inputs) -> bool:
         needs = torch.is_grad_enabled() and (any(x.requires_grad for x in inputs)
                                              or any(p.requires_grad for p in self.parameters()))
@@ -320,24 +338,6 @@ class EaBNet(_HipModule):
                              d_feat=d_feat, p=p, q=q, is_causal=is_causal, is_u2=is_u2, bf_type=bf_type,
                              topo_type=topo_type, intra_connect=intra_connect, norm_type=norm_type)
         self._init_params(param_specs(self.cfg))     # raises NotImplementedError for unsupported topologies
-
-    # -- streaming ------------------------------------------------------------------
-    def stream_begin(self, B: int, T_max: int, chunk: int = 1, F: int = 161, device=None) -> EaBNetStream:
-        """Frame-synchronous inference (BASELINE config 5; SURVEY §8f N4): returns a stream object whose
-        ``step`` takes ``chunk`` new frames (B, chunk, F, M, 2) and returns the matching output frames.
-        Needs the configuration in which the network really is causal -- ``norm_type="BN"`` in eval mode
-        (running statistics) and ``is_causal=True`` -- and raises NotImplementedError otherwise."""
-        if self.training:
-            raise RuntimeError("stream_begin: call .eval() first (BatchNorm must use its running statistics)")
-        _lib.load()
-        device = torch.device(device) if device is not None else next(self.parameters()).device
-        if device.type != "cuda":
-            raise _lib.EabError("streaming inference runs on MI355X only: move the module to 'cuda'")
-        if chunk < 1 or T_max < 1:
-            raise ValueError("chunk and T_max must be positive")
-        with torch.cuda.device(device):
-            prog = prg.lower(self.cfg, self._numpy_params(), B, T_max, F, precision=self.precision, chunk=chunk)
-            return EaBNetStream(self, _Bound(prog, device), B, T_max, F, chunk)
 
     # -- forward -------------------------------------------------------------------
     def forward(self, inpt: torch.Tensor) -> torch.Tensor:
@@ -378,7 +378,8 @@ class EaBNet(_HipModule):
 
 
 class EaBNetStream:
-    """Frame-synchronous inference state of one batch of utterances (``EaBNet.stream_begin``).
+    """Frame-synchronous inference state of one batch of utterances (``EaBNet.stream_begin``,
+    ``GaGNet.stream_begin``).
 
     The activations of the whole utterance stay resident in HBM ([B][T_max][..] per layer; 288 GB make
     that cheap) and are the state: each ``step`` appends ``chunk`` frames of input, replays the captured
@@ -387,47 +388,62 @@ class EaBNetStream:
     on the concatenated input, because every kernel computes a row independently of the tile or launch
     it falls into and the LSTM state is carried exactly."""
 
-    def __init__(self, net: "EaBNet", bound: _Bound, B: int, T_max: int, F: int, chunk: int):
+    def __init__(self, net, bound: _Bound, B: int, T_max: int, F: int, chunk: int):
         self.net, self.bound, self.B, self.T_max, self.F, self.chunk = net, bound, B, T_max, F, chunk
         self.pos = 0
         self._closed = False
-        M = net.M
-        if not (net.use_graph and bound.capture((B, T_max, F, M, 2), (B, 2, T_max, F))):
-            self._in = torch.zeros((B, T_max, F, M, 2), dtype=torch.float32, device=bound.device)
-            self._out = torch.zeros((B, 2, T_max, F), dtype=torch.float32, device=bound.device)
-            bound.bind(self._in.data_ptr(), self._out.data_ptr())
+        self.post = isinstance(net, GaGNet)           # post-filter: two planar inputs, q stage outputs
+        if self.post:
+            in_shape, out_shape, in2_shape = (B, 2, T_max, F), (net.q, B, 2, T_max, F), (B, 2, T_max, F)
         else:
-            self._in, self._out = bound.static_in, bound.static_out
+            in_shape, out_shape, in2_shape = (B, T_max, F, net.M, 2), (B, 2, T_max, F), None
+        if not (net.use_graph and bound.capture(in_shape, out_shape, in2_shape)):
+            self._in = torch.zeros(in_shape, dtype=torch.float32, device=bound.device)
+            self._out = torch.zeros(out_shape, dtype=torch.float32, device=bound.device)
+            self._in2 = torch.zeros(in2_shape, dtype=torch.float32, device=bound.device) if in2_shape else None
+            bound.bind(self._in.data_ptr(), self._out.data_ptr(), self._in2.data_ptr() if in2_shape else None)
+        else:
+            self._in, self._out, self._in2 = bound.static_in, bound.static_out, bound.static_in2
 
     def reset(self) -> None:
         """Start a new batch of utterances (no buffer needs clearing: position 0 ignores all state)."""
         self.pos, self._closed = 0, False
 
-    def step(self, x: torch.Tensor) -> torch.Tensor:
-        """x: (B, n, F, M, 2) new frames -> (B, 2, n, F) [(B, 2, n) for topo_type='miso'].  n == chunk, except
-        for the LAST step of an utterance (n < chunk): the recurrent state then sits past the end, so the
-        stream accepts no further frames until ``reset``."""
-        n = x.shape[1]
+    def step(self, x: torch.Tensor, pre_x: Optional[torch.Tensor] = None):
+        """Beam-former: x (B, n, F, M, 2) new frames -> (B, 2, n, F) [(B, 2, n) for topo_type='miso'].
+        Post-filter: x, pre_x (B, 2, n, F) -> list of q (B, 2, F, n).  n == chunk, except for the LAST step
+        of an utterance (n < chunk): the recurrent state then sits past the end, so the stream accepts no
+        further frames until ``reset``."""
+        tdim = 2 if self.post else 1
+        n = x.shape[tdim]
         if self._closed:
             raise RuntimeError("the previous step was a short final chunk: call reset() before the next utterance")
-        if x.ndim != 5 or x.shape[0] != self.B or not 0 < n <= self.chunk or tuple(x.shape[2:]) != (self.F, self.net.M, 2):
-            raise ValueError(f"expected (B={self.B}, n<={self.chunk}, {self.F}, {self.net.M}, 2), got {tuple(x.shape)}")
+        want = (self.B, 2, n, self.F) if self.post else (self.B, n, self.F, self.net.M, 2)
+        if tuple(x.shape) != want or not 0 < n <= self.chunk or (self.post and (pre_x is None or pre_x.shape != x.shape)):
+            raise ValueError(f"expected {want} with n <= {self.chunk}, got {tuple(x.shape)}")
         if self.pos + n > self.T_max:
             raise ValueError(f"utterance longer than the T_max={self.T_max} given to stream_begin")
         if not x.is_cuda:
-            raise _lib.EabError("EaBNetStream.step needs a CUDA (ROCm) tensor; there is no CPU fallback by design.")
+            raise _lib.EabError("stream.step needs CUDA (ROCm) tensors; there is no CPU fallback by design.")
+        lo, hi, end = self.pos, self.pos + n, self.pos + self.chunk
         with torch.cuda.device(x.device), torch.no_grad():
-            self._in[:, self.pos:self.pos + n].copy_(x, non_blocking=True)
-            if n < self.chunk:                        # rows the kernels touch beyond the new frames must be defined
-                self._in[:, self.pos + n:self.pos + self.chunk].zero_()
-            self.bound.t_pos.fill_(self.pos)
+            for buf, src in ((self._in, x), (self._in2, pre_x)):
+                if buf is None:
+                    continue
+                buf.narrow(tdim, lo, n).copy_(src, non_blocking=True)
+                if n < self.chunk and end > hi:       # rows the kernels touch beyond the new frames must be defined
+                    buf.narrow(tdim, hi, min(end, self.T_max) - hi).zero_()
+            self.bound.t_pos.fill_(lo)
             if self.bound.graph is not None:
                 self.bound.graph.replay()
             else:
                 self.bound.run(torch.cuda.current_stream().cuda_stream)
-            out = self._out[:, :, self.pos:self.pos + n].clone()
+            out = self._out[..., lo:hi, :].clone()
         self.pos += n
         self._closed = n < self.chunk
+        if self.post:
+            out = out.to(x.dtype)
+            return [out[j].permute(0, 1, 3, 2) for j in range(self.net.q)]
         if self.net.topo_type == "miso":
             out = out.sum(dim=-1)
         return out.to(x.dtype)
@@ -522,6 +538,90 @@ class EaBNetWithPostNet(nn.Module):
     def freeze_eabnet(self) -> None:
         for p in self.eabnet.parameters():
             p.requires_grad = False
+
+    def stream_begin(self, B: int, T_max: int, chunk: int = 1) -> "TwoStageStream":
+        """Frame-synchronous two-stage inference: both stages need BatchNorm norms and causal S-TCMs."""
+        return TwoStageStream(self, self.eabnet.stream_begin(B, T_max, chunk), self.postnet.stream_begin(B, T_max, chunk))
+
+
+class TwoStageStream:
+    """EaBNetWithPostNet.forward (EaBNet.py:138-148) chunk by chunk: beam-former step, then post-filter
+    step on (reference microphone, estimate)."""
+
+    def __init__(self, net: EaBNetWithPostNet, first: EaBNetStream, second: EaBNetStream):
+        self.net, self.first, self.second = net, first, second
+
+    def reset(self) -> None:
+        self.first.reset()
+        self.second.reset()
+
+    def step(self, noisy: torch.Tensor) -> dict:
+        esti0 = self.first.step(noisy)
+        inpt = noisy[..., self.net.ref_mic, :].permute(0, 3, 1, 2)
+        lst = self.second.step(inpt, esti0)
+        return {"esti0_stft": esti0, "esti1_stft_list": lst, "esti_stft": lst[-1].permute(0, 1, 3, 2)}
+
+
+class StreamingEnhancer:
+    """enhance.py:45-62 as a real-time loop on the device: ``push`` takes the next ``chunk`` hops of
+    multichannel samples (B, M, chunk*hop) and returns the enhanced samples that became final.
+
+    Frame t of the centred STFT needs samples up to (t+1)*hop and output segment k of the ISTFT needs frames
+    k and k+1, so the enhanced wave trails the input by two hops (20 ms at 16 kHz) plus the compute time of a
+    step.  Front and back end are the offline kernels on short windows (a frame / segment is computed
+    identically wherever its window starts), so the streamed wave is bit-identical to the offline
+    wave -> prepare_data -> model -> istft chain."""
+
+    def __init__(self, model, B: int, seconds: float, chunk: int = 1, sr: int = 16000, fft_num: int = 320, hop: int = 160):
+        self.model, self.B, self.chunk, self.fft, self.hop = model, B, chunk, fft_num, hop
+        self.T_max = 1 + int(seconds * sr) // hop
+        self.stream = model.stream_begin(B, self.T_max, chunk)
+        self.window = torch.hann_window(fft_num)
+        self.reset()
+
+    def reset(self) -> None:
+        self.stream.reset()
+        self._tail = None          # the last hop samples (B, M, hop): left half of the next frame
+        self._hold = None          # samples of a first push too short to form frame 0
+        self._frames = 0           # frames handed to the model so far
+        self._spec_prev = None     # last estimate frame, for the overlap-add with the next one
+
+    def push(self, samples: torch.Tensor, last: bool = False) -> torch.Tensor:
+        """samples (B, M, n*hop), n == chunk (any 0 <= n <= chunk with last=True).  Returns (B, k*hop)
+        enhanced samples, k = frames that became final in this call."""
+        B, M, L = samples.shape
+        if L % self.hop or L // self.hop > self.chunk or (L // self.hop != self.chunk and not last):
+            raise ValueError(f"push takes chunk*hop = {self.chunk * self.hop} samples per call (fewer only with last=True)")
+        first = self._tail is None
+        if first and self._hold is not None:
+            samples, self._hold = torch.cat((self._hold, samples), dim=2), None
+        if first and samples.shape[2] <= self.fft // 2 and not last:
+            self._hold = samples                      # frame 0 reflects about sample 0 and needs sample fft_num/2
+            return samples.new_zeros((B, 0))
+        buf = samples if first else torch.cat((self._tail, samples), dim=2)
+        # window of `buf`: as an utterance of its own, its interior frames are exact; its first frame is exact only
+        # at the true start (reflection), its last one only at the true end
+        if buf.shape[2] <= self.fft // 2:
+            raise ValueError("an utterance must be longer than fft_num/2 samples")
+        spec = stft_compress(buf, self.fft, self.hop, self.window)                # (B, T', F, M, 2)
+        lo = 0 if first else 1
+        hi = spec.shape[1] if last else spec.shape[1] - 1
+        new = spec[:, lo:hi]
+        self._tail = buf[:, :, buf.shape[2] - self.hop:]       # the next window starts one hop before its first new frame
+        outs = []
+        for a in range(0, new.shape[1], self.chunk):
+            blk = new[:, a:a + self.chunk]
+            o = self.stream.step(blk)
+            outs.append(o["esti_stft"] if isinstance(o, dict) else o)
+        if not outs:
+            return samples.new_zeros((B, 0))
+        est = torch.cat(outs, dim=2)                                                # (B, 2, k, F)
+        self._frames += est.shape[2]
+        seq = est if self._spec_prev is None else torch.cat((self._spec_prev, est), dim=2)
+        self._spec_prev = est[:, :, -1:].clone()
+        if seq.shape[2] < 2:
+            return samples.new_zeros((B, 0))
+        return istft(seq, self.fft, self.hop, self.window)
 
 
 def make_eabnet_with_postnet(args) -> EaBNetWithPostNet:

@@ -218,6 +218,7 @@ class GagPackOp:
     B: int
     T: int
     F: int
+    win: bool = False
     name: str = ""
     kind: int = OP_GAG_PACK
 
@@ -236,6 +237,7 @@ class GagCrmOp:
     T: int
     F: int
     act: int
+    win: bool = False
     name: str = ""
     kind: int = OP_GAG_CRM
 
@@ -844,7 +846,8 @@ class GagLowering(Lowering):
         c = cfg.c
         enc_in = Act(self.alloc_act(F, 4), F, 4, raw=True)
         pre = Act(self.alloc(B * T * GAG_PRE_LD), 1, GAG_PRE_LD, raw=True)
-        self.ops.append(GagPackOp(inpt=Ref("in"), pre_x=Ref("in2"), enc_in=enc_in.ref, pre=pre.ref, B=B, T=T, F=F, name="pack"))
+        self.ops.append(GagPackOp(inpt=Ref("in"), pre_x=Ref("in2"), enc_in=enc_in.ref, pre=pre.ref, B=B, T=T, F=F,
+                                  win=bool(self.chunk), name="pack"))
         x = enc_in
         if cfg.is_u2:
             for i in range(4):
@@ -881,18 +884,16 @@ class GagLowering(Lowering):
             self.mark("join", branches)
             nxt = Act(self.alloc(B * T * GAG_PRE_LD), 1, GAG_PRE_LD, raw=True)
             self.ops.append(GagCrmOp(pre=pre.ref, g=gain, r=lr, i=li, pre_out=nxt.ref, planar=Ref("out", gi * B * 2 * T * F),
-                                     B=B, T=T, F=F, act=act, name=f"gags.{gi}.crm"))
+                                     B=B, T=T, F=F, act=act, win=bool(self.chunk), name=f"gags.{gi}.crm"))
             pre = nxt
         return Program(cfg, B, T, F, self.ops, self.W.flat(), self.act_size, self.taps, self.flops,
-                       lanes=self.lane_of_ops(), sync=self.sync)
+                       lanes=self.lane_of_ops(), sync=self.sync, chunk=self.chunk)
 
 
 def lower(cfg, params: Dict[str, np.ndarray], B: int, T: int, F: int = 161,
           dump_bfw: bool = False, precision: str = "f32", chunk: int = 0) -> Program:
-    """chunk > 0 lowers the streaming form (EaBNet only): T is then the longest utterance the resident
-    activations can hold and every op advances `chunk` frames per replay."""
+    """chunk > 0 lowers the streaming form: T is then the longest utterance the resident activations can
+    hold and every op advances `chunk` frames per replay."""
     if isinstance(cfg, GagConfig):
-        if chunk:
-            raise NotImplementedError("streaming is implemented for the beam-former (EaBNet)")
-        return GagLowering(cfg, params, B, T, F, False, precision).build()
+        return GagLowering(cfg, params, B, T, F, False, precision, chunk).build()
     return Lowering(cfg, params, B, T, F, dump_bfw, precision, chunk).build()

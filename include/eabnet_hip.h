@@ -41,6 +41,18 @@ typedef void* eab_stream_t;
 int         eab_abi_version(void);
 const char* eab_error_string(int code);
 
+/* Time window for streaming inference (causal programs without data-dependent statistics, i.e.
+ * norm_type = "BN" in eval mode; SURVEY §8f N4 / BASELINE config 5).  The activations of the whole
+ * utterance [B][T][..] stay resident; when `pos` is non-NULL an op computes only the time rows
+ *     t in [*pos, min(*pos + count, T))
+ * of its output and leaves every other row as it is -- older rows are the "state" later chunks read.
+ * `pos` points to DEVICE memory, so ONE captured hipGraph is replayed for successive chunks after a
+ * 4-byte update of the position; the launch geometry depends on `count` only. */
+typedef struct eab_time_window {
+    const int32_t* pos;
+    int32_t count;
+} eab_time_window;
+
 /* --------------------------------------------------------------------------
  * K1+K2+K3  STFT front end, fused.
  * Replaces train_distributed.py:80,83,86,89,91 (noisy branch) and
@@ -96,13 +108,15 @@ int eab_istft_f32(const float* spec, const float* window, const float* twiddle, 
  *   pre [B][T][ld];  g, r, i [B][T][lin_ld] (first F entries used; biases already added)
  *   -> pre_out [B][T][ld] (next module's pre)  and  planar [B][2][T][F] (the stage output)
  * ------------------------------------------------------------------------ */
+/* (both take a streaming window like every other op: win.pos == NULL = the whole utterance) */
 #define EAB_ACT_SIGMOID 0
 #define EAB_ACT_TANH    1
 #define EAB_ACT_RELU    2
 int eab_gag_pack_f32(const float* inpt, const float* pre_x, float* enc_in, float* pre, int B, int T, int F,
-                     int ld, eab_stream_t stream);
+                     int ld, eab_time_window win, eab_stream_t stream);
 int eab_gag_crm_f32(const float* pre, const float* g, const float* r, const float* i, float* pre_out,
-                    float* planar, int B, int T, int F, int ld, int lin_ld, int act, eab_stream_t stream);
+                    float* planar, int B, int T, int F, int ld, int lin_ld, int act, eab_time_window win,
+                    eab_stream_t stream);
 
 /* --------------------------------------------------------------------------
  * K13  complex filter-and-sum, stand-alone.   Replaces EaBNet.py:114-117.
@@ -142,18 +156,6 @@ int eab_filter_sum_f32(const float* w, const float* x, float* y, int B, int T, i
                                * columns [0,Cout) see src0 through transform 0 (xf0/slope0), columns
                                * [Cout,2Cout) through transform 1 (xf1/slope1) of the SAME tensor;
                                * out[c] = acc[c] * sigmoid(acc[Cout + c]); rows interleaved as for GLU */
-
-/* Time window for streaming inference (causal programs without data-dependent statistics, i.e.
- * norm_type = "BN" in eval mode; SURVEY §8f N4 / BASELINE config 5).  The activations of the whole
- * utterance [B][T][..] stay resident; when `pos` is non-NULL an op computes only the time rows
- *     t in [*pos, min(*pos + count, T))
- * of its output and leaves every other row as it is -- older rows are the "state" later chunks read.
- * `pos` points to DEVICE memory, so ONE captured hipGraph is replayed for successive chunks after a
- * 4-byte update of the position; the launch geometry depends on `count` only. */
-typedef struct eab_time_window {
-    const int32_t* pos;
-    int32_t count;
-} eab_time_window;
 
 typedef struct eab_conv_desc {
     /* sources, channels-last [B][T][Fin][C*]; src1 == NULL when there is no concat */

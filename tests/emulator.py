@@ -293,6 +293,10 @@ class Emulator:
             return o + ([(op.bfw, (op.B, op.T, op.F * op.M * 2), 1)] if op.bfw is not None else [])
         if op.kind == prg.OP_MEMSET0:
             return [(op.ptr, (op.B, op.T, op.row), 1)]
+        if op.kind == prg.OP_GAG_PACK:
+            return [(op.enc_in, (op.B, op.T, op.F * 4), 1), (op.pre, (op.B, op.T, prg.GAG_PRE_LD), 1)]
+        if op.kind == prg.OP_GAG_CRM:
+            return [(op.pre_out, (op.B, op.T, prg.GAG_PRE_LD), 1), (op.planar, (op.B, 2, op.T, op.F), 2)]
         raise ValueError(op.kind)
 
     def run_stream(self):
@@ -317,6 +321,8 @@ class Emulator:
                     new = cur[tuple(idx)].copy()
                     cur[:] = old
                     cur[tuple(idx)] = new
+        if "in2" in self.arena:
+            return self.arena["out"].reshape(self.stages, p.B, 2, p.T, p.F)
         return self.arena["out"].reshape(p.B, 2, p.T, p.F)
 
     def run(self):

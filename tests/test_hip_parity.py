@@ -696,3 +696,50 @@ def test_streaming_variants_and_refusals(dev):
     net.precision = "f16x3"
     with pytest.raises(NotImplementedError):
         net.stream_begin(1, 8)
+
+
+def test_post_filter_and_two_stage_streaming_bit_exact(dev):
+    """GaGNet / EaBNetWithPostNet with BatchNorm norms: chunked streaming == offline, bit for bit."""
+    import eabnet_amd
+    args = _postnet_args(4, p=2, q=1, gagnet_p=1, gagnet_q=2, norm_type="BN", gagnet_norm_type="BN")
+    net = eabnet_amd.make_eabnet_with_postnet(args)
+    specs = {**{"eabnet." + k: s for k, s in net.eabnet._specs.items()}, **{"postnet." + k: s for k, s in net.postnet._specs.items()}}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in paramgen.make_params(specs, 560).items()}, strict=True)
+    net = net.to(dev).eval()
+    B, T, chunk = 2, 23, 4
+    x = torch.from_numpy(paramgen.make_spec_input(B, T, 161, 4, 561)).to(dev)
+    with torch.no_grad():
+        off = net(x)
+    st = net.stream_begin(B, T_max=24, chunk=chunk)
+    outs = [st.step(x[:, t:t + chunk]) for t in range(0, T, chunk)]
+    assert torch.equal(torch.cat([o["esti0_stft"] for o in outs], dim=2), off["esti0_stft"])
+    assert torch.equal(torch.cat([o["esti_stft"] for o in outs], dim=2), off["esti_stft"])
+    for j in range(2):
+        assert torch.equal(torch.cat([o["esti1_stft_list"][j] for o in outs], dim=3), off["esti1_stft_list"][j])
+    with pytest.raises(NotImplementedError):
+        eabnet_amd.GaGNet().to(dev).eval().stream_begin(1, 8)          # InstanceNorm post-filter
+
+
+@pytest.mark.parametrize("chunk", [1, 5])
+def test_wave_to_wave_streaming_enhancer_bit_exact(dev, chunk):
+    """enhance.py as a real-time loop: pushing `chunk` hops of samples at a time through STFT windows, the
+    streamed two-stage model and ISTFT windows returns exactly the offline enhanced wave."""
+    import eabnet_amd
+    M, L = 4, 160 * 30
+    args = _postnet_args(M, p=1, q=1, gagnet_p=1, gagnet_q=1, gagnet_dilas=[1, 2], norm_type="BN", gagnet_norm_type="BN")
+    net = eabnet_amd.make_eabnet_with_postnet(args)
+    specs = {**{"eabnet." + k: s for k, s in net.eabnet._specs.items()}, **{"postnet." + k: s for k, s in net.postnet._specs.items()}}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in paramgen.make_params(specs, 570).items()}, strict=True)
+    net = net.to(dev).eval()
+    wav = torch.from_numpy(paramgen.make_wave(2, M, L, 571)).to(dev)
+    win = torch.hann_window(320)
+    with torch.no_grad():
+        off = eabnet_amd.istft(net(eabnet_amd.stft_compress(wav, 320, 160, win))["esti_stft"], 320, 160, win)
+    enh = eabnet_amd.StreamingEnhancer(net, B=2, seconds=L / 16000, chunk=chunk)
+    step = chunk * 160
+    pieces = []
+    for a in range(0, L, step):
+        pieces.append(enh.push(wav[:, :, a:a + step], last=a + step >= L))
+    got = torch.cat(pieces, dim=1)
+    assert got.shape == off.shape == (2, L)
+    assert torch.equal(got, off)

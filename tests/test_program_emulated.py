@@ -194,3 +194,17 @@ def test_emulated_streaming_program_equals_offline(chunk):
             prg.lower(NetConfig(M=4, **bad), paramgen.make_params(param_specs(NetConfig(M=4, **bad)), 1), 1, 8, 161, chunk=2)
     with pytest.raises(NotImplementedError):
         prg.lower(cfg, P, 1, 8, 161, chunk=2, precision="f16x3")
+
+
+def test_emulated_post_filter_streaming_equals_offline():
+    """GaGNet with BatchNorm norms, windowed lowering (pack / convs / tail all restricted to the chunk)."""
+    from eabnet_amd.spec import GagConfig, gag_param_specs
+    cfg = GagConfig(norm_type="BN", p=1, q=2, dilas=(1, 2))
+    P = paramgen.make_params(gag_param_specs(cfg), 580)
+    mk = lambda seed: np.ascontiguousarray(paramgen.make_spec_input(1, 10, 161, 1, seed)[..., 0, :].transpose(0, 3, 1, 2))  # noqa: E731
+    a, b = mk(581), mk(582)
+    off = Emulator(prg.lower(cfg, P, 1, 10, 161), a, b).run()
+    prog = prg.lower(cfg, P, 1, 10, 161, chunk=3)
+    assert all(op.win for op in prog.ops) and prog.chunk == 3
+    y = Emulator(prog, a, b).run_stream()
+    assert np.array_equal(y, off)
