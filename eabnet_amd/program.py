@@ -378,14 +378,12 @@ class Lowering:
         self.dump_bfw = dump_bfw
         self.bn = cfg.norm_type == "BN"
         self.add = cfg.intra_connect == "add"
-        self.lane = 0                  # stream lane given to the ops emitted from now on
-        self._lane_marks: List[Tuple[int, int]] = [(0, 0)]      # (first op index, lane)
+        self._lane_marks: List[Tuple[int, int]] = [(0, 0)]      # (first op index, stream lane from there on)
         self.sync: Dict[int, list] = {}
 
-    def __setattr__(self, k, v):
-        if k == "lane" and "_lane_marks" in self.__dict__:
-            self._lane_marks.append((len(self.ops), v))
-        object.__setattr__(self, k, v)
+    def set_lane(self, lane: int) -> None:
+        """Ops emitted from now on belong to parallel branch `lane` (0 = the main stream)."""
+        self._lane_marks.append((len(self.ops), lane))
 
     def mark(self, what: str, lanes) -> None:
         self.sync.setdefault(len(self.ops), []).append((what, list(lanes)))
@@ -872,15 +870,15 @@ class GagLowering(Lowering):
             branches = [1] if cfg.is_squeezed else [1, 2]
             self.mark("fork", branches)
             gain = self.linear(f"{gl}.linear_g.0", self.chain(f"{gl}.tcn_g", xg0))
-            self.lane = 1
+            self.set_lane(1)
             if cfg.is_squeezed:
                 xr = self.chain(f"{gz}.tcm_ri", xz)
                 lr, li = self.linear(f"{gz}.linear_r", xr), self.linear(f"{gz}.linear_i", xr)
             else:
                 lr = self.linear(f"{gz}.linear_r", self.chain(f"{gz}.tcm_r", xz))
-                self.lane = 2
+                self.set_lane(2)
                 li = self.linear(f"{gz}.linear_i", self.chain(f"{gz}.tcm_i", xz))
-            self.lane = 0
+            self.set_lane(0)
             self.mark("join", branches)
             nxt = Act(self.alloc(B * T * GAG_PRE_LD), 1, GAG_PRE_LD, raw=True)
             self.ops.append(GagCrmOp(pre=pre.ref, g=gain, r=lr, i=li, pre_out=nxt.ref, planar=Ref("out", gi * B * 2 * T * F),
