@@ -637,6 +637,8 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
     const __amdgpu_buffer_rsrc_t r_acc = __builtin_amdgcn_make_buffer_rsrc(
         d.dst_acc ? d.dst_acc + out_b : d.dst + out_b, 0, d.dst_acc ? out_bytes : 0u, 0x00020000);
 
+    const unsigned row_bytes = (unsigned)(d.Fout * Cout) * 4u, step_bytes = (unsigned)(d.ostride * Cout) * 4u;
+    const unsigned phase_bytes = (unsigned)(d.ophase * Cout) * 4u;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         unsigned off[16];
@@ -645,14 +647,23 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
         for (int r4 = 0; r4 < 4; ++r4) {
             // rows r = 4*r4 + j, j = 0..3 are consecutive q: one division per group of four
             const int qg = q0 + (wm * MI + mi) * 32 + 8 * r4 + 4 * lh;
-            int t = cg_div(qg < Q ? qg : 0, d.No, inv_no);
+            const int t = cg_div(qg < Q ? qg : 0, d.No, inv_no);
             int o = (qg < Q ? qg : 0) - t * d.No;
+            // byte offset of (t, o) stepped incrementally: two integer multiplies per group of four rows
+            // instead of three per row (v_mul_lo_u32 is quarter rate and shares the pipe with the fp32 MFMA)
+            unsigned row_start = (unsigned)t * row_bytes + phase_bytes;
+            unsigned cur = row_start + (unsigned)o * step_bytes;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = 4 * r4 + j;
                 rowok[r] = qg + j < Q;
-                off[r] = rowok[r] ? (unsigned)((t * d.Fout + o * d.ostride + d.ophase) * Cout) * 4u : CG_OOB;
-                if (++o == d.No) { o = 0; ++t; }
+                off[r] = rowok[r] ? cur : CG_OOB;
+                cur += step_bytes;
+                if (++o == d.No) {
+                    o = 0;
+                    row_start += row_bytes;
+                    cur = row_start;
+                }
             }
         }
         float auxv[16][NC], accv[16][NC];
