@@ -743,3 +743,59 @@ def test_wave_to_wave_streaming_enhancer_bit_exact(dev, chunk):
     got = torch.cat(pieces, dim=1)
     assert got.shape == off.shape == (2, L)
     assert torch.equal(got, off)
+
+
+# ------------------------------------------------------------------ structural properties
+def test_causality_with_batchnorm_norms(dev):
+    """norm_type='BN' (eval) + is_causal: frames before t0 do not depend on the input from t0 on -- bit for bit
+    (the property streaming rests on); with InstanceNorm they do, through the utterance statistics."""
+    B, T, t0 = 2, 70, 41
+    x = torch.from_numpy(paramgen.make_spec_input(B, T, 161, 4, 700)).to(dev)
+    x2 = x.clone()
+    x2[:, t0:] = torch.from_numpy(paramgen.make_spec_input(B, T - t0, 161, 4, 701)).to(dev)
+    net = _model(4, 702, dev, norm_type="BN")
+    with torch.no_grad():
+        y, y2 = net(x), net(x2)
+    assert torch.equal(y[:, :, :t0], y2[:, :, :t0]) and not torch.equal(y[:, :, t0:], y2[:, :, t0:])
+    net_in = _model(4, 702, dev)
+    with torch.no_grad():
+        z, z2 = net_in(x), net_in(x2)
+    assert not torch.equal(z[:, :, :t0], z2[:, :, :t0])
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_batch_permutation_equivariance(dev, precision):
+    """Utterances never interact: permuting the batch permutes the outputs bit for bit (tiles never
+    straddle utterances, statistics are per utterance, the LSTM state is per sequence)."""
+    net = _model(4, 710, dev, p=2, q=2)
+    net.precision = precision
+    x = torch.from_numpy(paramgen.make_spec_input(5, 37, 161, 4, 711)).to(dev)
+    perm = torch.tensor([3, 0, 4, 2, 1], device=dev)
+    with torch.no_grad():
+        assert torch.equal(net(x[perm]), net(x)[perm])
+        assert torch.equal(net(x[1:2]), net(x)[1:2])         # and a batch of one is the same utterance alone
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_random_configurations_vs_oracle(dev, seed):
+    """A seeded sweep over the constructor space (M, p, q, kd1, norm, skips, head, encoder) and over (B, T)."""
+    from oracle import eabnet_oracle as orc
+    rng = np.random.default_rng(4200 + seed)
+    kw = dict(M=int(rng.integers(1, 7)), p=int(rng.integers(1, 4)), q=int(rng.integers(1, 3)), kd1=int(rng.choice([3, 5])),
+              norm_type=str(rng.choice(["IN", "BN"])), intra_connect=str(rng.choice(["cat", "add"])),
+              bf_type=str(rng.choice(["lstm", "cnn"])), is_u2=bool(rng.integers(0, 2)), is_causal=bool(rng.integers(0, 2)))
+    B, T = int(rng.integers(1, 4)), int(rng.integers(3, 90))
+    M = kw.pop("M")
+    net = _model(M, 4300 + seed, dev, **kw)
+    x = torch.from_numpy(paramgen.make_spec_input(B, T, 161, M, 4400 + seed))
+    okw = {k: v for k, v in kw.items() if k not in ("p", "q", "kd1")}
+    with torch.no_grad():
+        P = torch_params(M, 4300 + seed, **kw)
+        ref = orc.eabnet_forward(P, x, p=kw["p"], q=kw["q"], kd=kw["kd1"], fast_lstm=True, **okw)
+        ref64 = orc.eabnet_forward({k: v.double() if v.dtype == torch.float32 else v for k, v in P.items()}, x.double(),
+                                   p=kw["p"], q=kw["q"], kd=kw["kd1"], **okw)
+        floor = rel_errs(ref.numpy(), ref64.numpy())[0]
+        for precision in ("f32", "f16x3"):
+            net.precision = precision
+            y = net(x.to(dev))
+            assert_close(y.cpu().numpy(), ref.numpy(), max(TOL_HIP, 3 * floor), f"{kw} B={B} T={T} {precision}")
