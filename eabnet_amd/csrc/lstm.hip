@@ -24,6 +24,7 @@
 //     channels-last tensor per workgroup); h_t leaves as one coalesced 4 KB store.
 // Bound: fp32 matrix pipe.
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 #define LS_H 64
@@ -246,6 +247,180 @@ __global__ __launch_bounds__(256) void lstm64_kernel(const float* __restrict__ x
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Small-batch variant: 4*G sequences per workgroup on v_mfma_f32_4x4x1_16b_f32.
+// The 16x16x4 kernel above needs 16 sequences per workgroup, so B*F <= 2048 sequences leave most CUs
+// idle (one 4-s utterance: 11 workgroups) while its step time stays 128 x 32 MFMA cycles.  The 4x4x1
+// form (16 independent 4x4 blocks: 4 sequences x 64 gate columns per instruction, measured 10 cycles
+// each with >= 6 independent accumulation chains, tools/probe_mfma_4x4.hip) cuts the granule to 4
+// sequences: a step is 128*G MFMAs of 10 cycles, and four times as many workgroups share the work
+// (G = 1 is what the dispatcher uses: whole-network step at B = 1 / 4 / 8 / 12: 3.85 / 4.82 / 6.42 / 7.52 ms
+// against 4.65 / 5.69 / 6.79 / 7.83 ms with the 16-sequence kernel; at B = 16 the latter wins, 9.10 vs 9.73).
+//   lane l of wave w: hidden unit u = 16w + l/4, gate j = l%4 (i, f, g, o); B operand = that gate
+//   column of [W_x | W_h] (128 VGPRs, stationary); A operand = the 4 sequences of a group, identical
+//   in all 16 blocks (read from LDS as a broadcast); result VGPR s = sequence s of the group.
+//   The four gates of a unit sit in one quad: quad_perm DPP broadcasts hand every lane i, f, g, o and
+//   the quad updates the cell redundantly (lanes are free; lane j stores sequence j).
+// Same x prefetch, LayerNorm, streaming window and state hand-off as lstm64_kernel.
+template <bool LN, int G>
+__global__ __launch_bounds__(256) void lstm64_q_kernel(const float* __restrict__ x, const float* __restrict__ ln_g,
+                                                       const float* __restrict__ ln_b, float ln_eps,
+                                                       const float* __restrict__ wcat, const float* __restrict__ bias,
+                                                       float* __restrict__ h_out, int T, int F, int S,
+                                                       const int* __restrict__ t_pos, int t_count,
+                                                       float* __restrict__ c_state) {
+    constexpr int NSEQ = 4 * G;
+    constexpr int NCH = G == 1 ? 8 : (G == 2 ? 4 : 2);       // accumulation chains per group (>= 6 in flight overall)
+    __shared__ __attribute__((aligned(16))) float xs[2][NSEQ * LS_LD];
+    __shared__ __attribute__((aligned(16))) float hs[2][NSEQ * LS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gate = lane & 3, u = wave * 16 + (lane >> 2);
+    const int s0 = blockIdx.x * NSEQ;
+    const int t_lo = t_pos ? *t_pos : 0;
+    const int t_hi = t_pos ? (t_lo + t_count < T ? t_lo + t_count : T) : T;
+
+    // stationary weights: this lane's gate column of [W_x | W_h]
+    float wx[64], wh[64];
+    const int wrow = gate * LS_H + u;
+    const float bia = bias[wrow];
+#pragma unroll
+    for (int k4 = 0; k4 < 16; ++k4) {
+        const f32x4 vx = *reinterpret_cast<const f32x4*>(&wcat[(size_t)wrow * 128 + 4 * k4]);
+        const f32x4 vh = *reinterpret_cast<const f32x4*>(&wcat[(size_t)wrow * 128 + 64 + 4 * k4]);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            wx[4 * k4 + kk] = vx[kk];
+            wh[4 * k4 + kk] = vh[kk];
+        }
+    }
+    // activation of this lane's gate: sigmoid(v) = 1/(1+exp(-v)), tanh(v) = 2/(1+exp(-2v)) - 1
+    const float act_k = gate == 2 ? -2.0f : -1.0f, act_a = gate == 2 ? 2.0f : 1.0f, act_b = gate == 2 ? -1.0f : 0.0f;
+
+    // loader role: thread -> (sequence ls, channels lc..lc+3); only the first NSEQ rows are live
+    const int ls = tid >> 4, lc = (tid & 15) * 4;
+    const int sg = s0 + ls;
+    const bool sv = ls < NSEQ && sg < S;
+    const int sb = sv ? sg / F : 0, sf = sv ? sg - sb * F : 0;
+    const unsigned total_bytes = (unsigned)S * (unsigned)T * (LS_H * 4u);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, total_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(h_out, 0, total_bytes, 0x00020000);
+    const unsigned seq_off = (unsigned)((((size_t)sb * T * F + sf) * LS_H + lc) * 4);
+    const unsigned t_stride = (unsigned)F * LS_H * 4u;
+    f32x4 g4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f};
+    if (LN) {
+        g4 = *reinterpret_cast<const f32x4*>(ln_g + lc);
+        b4 = *reinterpret_cast<const f32x4*>(ln_b + lc);
+    }
+    auto load_x = [&](int t) -> f32x4 {
+        const unsigned off = (sv && t < t_hi) ? seq_off + (unsigned)t * t_stride : LS_OOB;
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+    };
+    auto norm_store = [&](f32x4 v, int buf) {
+        if (LN) {
+            const float mean = ls_row_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 64.0f);
+            f32x4 dlt = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
+            const float q = ls_row_sum((dlt[0] * dlt[0] + dlt[1] * dlt[1]) + (dlt[2] * dlt[2] + dlt[3] * dlt[3]));
+            const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + ln_eps);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = dlt[j] * rstd * g4[j] + b4[j];
+        }
+        if (ls < NSEQ) *reinterpret_cast<f32x4*>(&xs[buf][ls * LS_LD + lc]) = v;
+    };
+    auto quad = [](float v, auto ctrl) {   // quad_perm broadcast of one lane of the quad
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+
+    // prologue: h_{t_lo-1}, c_{t_lo-1}, x_{t_lo} normalised in LDS; x_{t_lo+1}, x_{t_lo+2} raw in registers
+    if (ls < NSEQ)
+        *reinterpret_cast<f32x4*>(&hs[0][ls * LS_LD + lc]) = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rh, (sv && t_lo > 0) ? seq_off + (unsigned)(t_lo - 1) * t_stride : LS_OOB, 0, 0));
+    norm_store(load_x(t_lo), 0);
+    float cst[G][4];
+#pragma unroll
+    for (int q = 0; q < G; ++q)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int sq = s0 + 4 * q + s;
+            cst[q][s] = (c_state && t_lo > 0 && sq < S) ? c_state[(size_t)sq * LS_H + u] : 0.0f;
+        }
+    f32x4 xq = load_x(t_lo + 1), xr = load_x(t_lo + 2);
+    __syncthreads();
+
+    for (int t = t_lo; t < t_hi; ++t) {
+        const int cur = (t - t_lo) & 1, nxt = cur ^ 1;
+        const f32x4 xn = load_x(t + 3);
+        // ---- gates: pre[q][s] = b + W_x x_t + W_h h_{t-1} for the 4 sequences of every group
+        f32x4 acc[G][NCH];
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) acc[q][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const float* src = part == 0 ? xs[cur] : hs[cur];
+#pragma unroll
+            for (int k4 = 0; k4 < 16; ++k4) {
+#pragma unroll
+                for (int q = 0; q < G; ++q) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(&src[(4 * q + gate) * LS_LD + 4 * k4]);
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int c = (part * 16 + k4) % NCH;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        acc[q][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[kk], part == 0 ? wx[4 * k4 + kk] : wh[4 * k4 + kk],
+                                                                       acc[q][c], 0, 0, 0);
+                }
+            }
+        }
+        norm_store(xq, nxt);                            // x_{t+1}: its buffer was last read one step ago
+        // ---- activations, cell update (redundant in the quad), h_t -> LDS
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            f32x4 pre = acc[q][0];
+#pragma unroll
+            for (int c = 1; c < NCH; ++c) pre += acc[q][c];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float sgm = __builtin_amdgcn_rcpf(1.0f + __expf(act_k * (pre[s] + bia)));
+                const float a = fmaf(act_a, sgm, act_b);
+                const float gi = quad(a, std::integral_constant<int, 0x00>{}), gf = quad(a, std::integral_constant<int, 0x55>{});
+                const float gg = quad(a, std::integral_constant<int, 0xAA>{}), go = quad(a, std::integral_constant<int, 0xFF>{});
+                cst[q][s] = fmaf(gf, cst[q][s], gi * gg);
+                const float hv = go * ls_tanh(cst[q][s]);
+                if (s == gate) hs[nxt][(4 * q + s) * LS_LD + u] = hv;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (ls < NSEQ) {
+            const f32x4 hv4 = *reinterpret_cast<const f32x4*>(&hs[nxt][ls * LS_LD + lc]);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv4), rh,
+                                                   sv ? seq_off + (unsigned)t * t_stride : LS_OOB, 0, 0);
+        }
+        xq = xr;
+        xr = xn;
+    }
+    if (c_state && (lane & 3) == 0) {
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (s0 + 4 * q + s < S) c_state[(size_t)(s0 + 4 * q + s) * LS_H + u] = cst[q][s];
+    }
+}
+
+template <int G>
+static void lstm64_q_launch(bool ln, int grid, hipStream_t st, const float* x, const float* ln_g, const float* ln_b,
+                            float ln_eps, const float* wcat, const float* bias, float* h_out, int T, int F, int S,
+                            const int* t_pos, int t_count, float* cs) {
+    if (ln)
+        hipLaunchKernelGGL((lstm64_q_kernel<true, G>), dim3(grid), dim3(256), 0, st, x, ln_g, ln_b, ln_eps, wcat, bias,
+                           h_out, T, F, S, t_pos, t_count, cs);
+    else
+        hipLaunchKernelGGL((lstm64_q_kernel<false, G>), dim3(grid), dim3(256), 0, st, x, ln_g, ln_b, ln_eps, wcat, bias,
+                           h_out, T, F, S, t_pos, t_count, cs);
+}
+
 int eab_lstm64_h3_launch(const float* x, const float* ln_g, const float* ln_b, float ln_eps, const float* wcat,
                          const float* bias, float* h_out, int T, int F, int S, hipStream_t stream);   // lstm_h3.hip
 
@@ -273,8 +448,16 @@ extern "C" int eab_lstm64_stream_f32(const float* x, const float* ln_g, const fl
     EAB_CHECK_ARG(S * T * LS_H * 4 < (1ll << 31));          // 31-bit byte offsets in the buffer descriptors
     if (precision == EAB_PREC_F16X3)
         return eab_lstm64_h3_launch(x, ln_g, ln_b, ln_eps, wcat, bias, h_out, T, F, (int)S, eab_stream(stream));
-    const int grid = (int)((S + LS_SEQ - 1) / LS_SEQ);
     float* cs = win.pos ? c_state : nullptr;
+    // up to 2048 sequences (12 four-second utterances): 4-sequence workgroups on the 4x4x1 MFMA (measured faster
+    // than the 16-sequence kernel up to there, even at two workgroups per CU; larger groups never won)
+    static const int g_env = getenv("EAB_LSTM_G") ? atoi(getenv("EAB_LSTM_G")) : 0;      // 1 / 4 force a kernel
+    if (g_env == 1 || (g_env != 4 && S <= 2048)) {
+        lstm64_q_launch<1>(ln_g != nullptr, (int)((S + 3) / 4), eab_stream(stream), x, ln_g, ln_b, ln_eps, wcat, bias, h_out,
+                           T, F, (int)S, win.pos, win.count, cs);
+        EAB_RETURN_LAUNCH_STATUS();
+    }
+    const int grid = (int)((S + LS_SEQ - 1) / LS_SEQ);
     if (ln_g)
         hipLaunchKernelGGL(lstm64_kernel<true>, dim3(grid), dim3(256), 0, eab_stream(stream), x, ln_g, ln_b, ln_eps,
                            wcat, bias, h_out, T, F, (int)S, win.pos, win.count, cs);
