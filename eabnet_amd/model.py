@@ -265,7 +265,14 @@ class _HipModule(nn.Module):
         self.precision = "f32"
 
     def _param_fingerprint(self) -> tuple:
-        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        """Cheap change detector for the packed weights (runs on every forward): in-place updates bump a
+        tensor's version counter, a device move or re-assignment changes storage addresses.  The tensor list
+        is cached -- walking the ~800-node module tree costs more than the rest of the host side of a step."""
+        ts = self.__dict__.get("_tensor_list")
+        if ts is None or len(ts) != len(self._specs):
+            ts = list(self.parameters()) + list(self.buffers())
+            self.__dict__["_tensor_list"] = ts
+        return (ts[0].data_ptr(), ts[-1].data_ptr(), sum(t._version for t in ts))
 
     def _numpy_params(self) -> Dict[str, np.ndarray]:
         sd = self.state_dict()
@@ -633,6 +640,23 @@ def make_eabnet_with_postnet(args) -> EaBNetWithPostNet:
 # front end and helpers
 # ----------------------------------------------------------------------------
 _TWIDDLE: Dict[Tuple[int, str], torch.Tensor] = {}
+_WINDOW: Dict[tuple, torch.Tensor] = {}
+
+
+def _device_window(window: torch.Tensor, device: torch.device) -> torch.Tensor:
+    """The analysis/synthesis window on the device.  prepare_data builds it on the CPU on every call, as the
+    reference does (train_distributed.py:83), and a pageable host-to-device copy blocks the host until the
+    stream has drained -- one full pipeline bubble per step.  CPU windows are therefore cached by content."""
+    if window.is_cuda:
+        return window.to(device=device, dtype=torch.float32).contiguous()
+    w = window.detach().to(torch.float32).contiguous()
+    key = (str(device), w.numpy().tobytes())
+    hit = _WINDOW.get(key)
+    if hit is None:
+        if len(_WINDOW) > 16:
+            _WINDOW.clear()
+        hit = _WINDOW[key] = w.to(device)
+    return hit
 
 
 def _twiddle(n_fft: int, device: torch.device) -> torch.Tensor:
@@ -652,7 +676,7 @@ def stft_compress(wav: torch.Tensor, n_fft: int, hop: int, window: torch.Tensor,
     B, M, L = wav.shape
     T, F = 1 + L // hop, n_fft // 2 + 1
     wav = wav.to(torch.float32).contiguous()
-    window = window.to(device=wav.device, dtype=torch.float32).contiguous()
+    window = _device_window(window, wav.device)
     out = torch.empty((B, T, F, M, 2) if layout == 0 else (B, 2, T, F), dtype=torch.float32, device=wav.device)
     with torch.cuda.device(wav.device):
         tw = _twiddle(n_fft, wav.device)
@@ -696,7 +720,7 @@ def istft(esti_stft: torch.Tensor, fft_num: int, win_shift: int, window: torch.T
     lib = _lib.load()
     B, _, T, _ = esti_stft.shape
     x = esti_stft.detach().to(torch.float32).contiguous()
-    window = window.to(device=x.device, dtype=torch.float32).contiguous()
+    window = _device_window(window, x.device)
     wav = torch.empty((B, win_shift * (T - 1)), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(lib.eab_istft_f32(x.data_ptr(), window.data_ptr(), _twiddle(fft_num, x.device).data_ptr(),
