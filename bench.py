@@ -338,6 +338,28 @@ def main():
         out["single_utterance_c1"] = c1
 
     if rank == 0 and not a.no_next:
+        # the boundary as the reference drives it: the wave arrives in HOST memory and prepare_data moves it
+        # (train_distributed.py:76-77) -- the PCIe-inclusive rate, never the headline
+        pd_args = argparse.Namespace(mics=MICS, sr=SR, wav_len=SECONDS, win_size=0.020, win_shift=0.010, fft_num=N_FFT)
+        net.precision = a.precision
+        host = {"pageable": wav.cpu(), "pinned": wav.cpu().pin_memory()}
+        pc = {}
+        for kind, hw in host.items():
+            with torch.no_grad():
+                for _ in range(3):
+                    net(eabnet_amd.prepare_data(hw, hw[:, :1], dev, pd_args)[0])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    net(eabnet_amd.prepare_data(hw, hw[:, :1], dev, pd_args)[0])
+                torch.cuda.synchronize()
+            dth = (time.perf_counter() - t0) / 10
+            pc[kind] = {"ms_per_step": 1e3 * dth, "frames_per_s": B_PER_GPU * T / dth}
+        pc["note"] = (f"host wave ({wav.numel() * 4 / 1e6:.1f} MB per step) -> prepare_data (noisy + target STFT) -> EaBNet; "
+                      "blocking copies, no overlap with the previous step")
+        out.setdefault("next_rows", {})["pcie_inclusive"] = pc
+
+    if rank == 0 and not a.no_next:
         # SURVEY §8f rows built after the hot path: what enhance.py actually runs -- wave -> STFT ->
         # EaBNetWithPostNet (beam-former + GaGNet post-filter) -> ISTFT -> wave, same batch, same protocol
         net = None
@@ -421,7 +443,7 @@ def main():
                                          "ms_per_push": 1e3 * dtp, "rtf": dtp / 0.010,
                                          "latency_ms": 20.0 + 1e3 * dtp}
         tw = enh = None
-        out["next_rows"] = nxt
+        out.setdefault("next_rows", {}).update(nxt)
         two = None
         torch.cuda.empty_cache()
 
