@@ -54,7 +54,6 @@ struct CgSmem {
     float xsl[2][CG_XFC];        // PReLU slopes
     int dt[EAB_MAX_TAPS];
     int ioff[EAB_MAX_TAPS];
-    unsigned toff[2][EAB_MAX_TAPS];   // gather mode: byte offset of a tap inside source 0 / 1, (dt*Fin + ioff) * C * 4
 };
 
 template <int XF>
@@ -140,8 +139,6 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
         if (tid == j) {
             sm.dt[j] = d.dt[j];
             sm.ioff[j] = d.ioff[j];
-            sm.toff[0][j] = (unsigned)((d.dt[j] * d.Fin + d.ioff[j]) * d.C0) * 4u;
-            sm.toff[1][j] = (unsigned)((d.dt[j] * d.Fin + d.ioff[j]) * d.C1) * 4u;
         }
 
     if (XF != EAB_XF_NONE) {
@@ -231,28 +228,6 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
     auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
     __syncthreads();   // tap tables (and transform tables) visible
-
-    // Gather mode: everything about (row, tap) that does not depend on the channel chunk is worked out
-    // once -- a validity bit per tap and the row's base byte offset in either source -- so a K unit
-    // costs two adds, a bit test and a select per row instead of the full index arithmetic (integer
-    // multiplies and compares share the issue port with the fp32 MFMAs).
-    unsigned a_vmask[MI], a_b0[MI], a_b1[MI];
-#pragma unroll
-    for (int p = 0; p < MI; ++p) {
-        a_vmask[p] = 0u;
-        a_b0[p] = (unsigned)(a_tf[p] * d.C0) * 4u;
-        a_b1[p] = (unsigned)(a_tf[p] * d.C1) * 4u;
-    }
-    if constexpr (!PATCH) {
-        for (int j = 0; j < d.ntaps; ++j) {
-            const int dtj = sm.dt[j], ioj = sm.ioff[j];
-#pragma unroll
-            for (int p = 0; p < MI; ++p) {
-                const int tt = a_t[p] + dtj, fi = a_f0[p] + ioj;
-                if (a_ok[p] && tt >= 0 && tt < d.T && fi >= 0 && fi < d.Fin) a_vmask[p] |= 1u << j;
-            }
-        }
-    }
 
     if constexpr (PATCH) {
         // ------------------------------------------------------------------------------
@@ -457,16 +432,17 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
             const int uu = live ? u : 0;
             const int tap = uu / UPT;
             const int c0 = (uu - tap * UPT) << 4;
+            const int dt = sm.dt[tap], io = sm.ioff[tap];
             const bool second = (d.C1 > 0) && (c0 >= d.C0);     // wave-uniform
             const int Cs = second ? d.C1 : d.C0;
             const int c = (second ? c0 - d.C0 : c0) + skq * 4;
             const bool cok = live && (c < Cs);
-            const unsigned tap_c = sm.toff[second ? 1 : 0][tap] + (unsigned)c * 4u;
 #pragma unroll
             for (int p = 0; p < MI; ++p) {
-                const bool ok = cok && ((a_vmask[p] >> tap) & 1u);
+                const int tt = a_t[p] + dt, fi = a_f0[p] + io;
+                const bool ok = a_ok[p] && cok && tt >= 0 && tt < d.T && fi >= 0 && fi < d.Fin;
                 rg.st_ok[ku][p] = ok;
-                const unsigned off = ok ? (second ? a_b1[p] : a_b0[p]) + tap_c : CG_OOB;
+                const unsigned off = ok ? (unsigned)(((a_tf[p] + dt * d.Fin + io) * Cs + c) * 4) : CG_OOB;
                 if (VEC) {
                     const u32x4 v = second ? __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0)
                                            : __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0);
