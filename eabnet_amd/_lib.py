@@ -68,6 +68,8 @@ _SIGS = {
     "eab_bfw_filter_sum_win_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [TimeWindow, C.c_void_p]),
     "eab_mlp_bfw_filter_sum_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 4 + [TimeWindow, C.c_void_p]),
     "eab_zero_rows_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [TimeWindow, C.c_void_p]),
+    "eab_com_mag_mse_loss_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_void_p]),
     "eab_gag_pack_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [TimeWindow, C.c_void_p]),
     "eab_gag_crm_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 6 + [TimeWindow, C.c_void_p]),
     "eab_conv_tiles": (C.c_int, [C.c_int] * 3),

@@ -749,8 +749,48 @@ def numParams(net: nn.Module) -> int:
     return sum(int(np.prod(p.size())) for p in net.parameters() if p.requires_grad)
 
 
+class _ComMagMseLoss(torch.autograd.Function):
+    """Loss value and d loss / d esti from one fused HIP pass (csrc/loss.hip); the backward is a scale."""
+
+    @staticmethod
+    def forward(ctx, esti: torch.Tensor, label: torch.Tensor, frames: tuple) -> torch.Tensor:
+        lib = _lib.load()
+        B, _, T, F = esti.shape
+        e = esti.detach().to(torch.float32).contiguous()
+        lab = label.detach().to(torch.float32).contiguous()
+        grad = torch.empty_like(e) if ctx.needs_input_grad[0] else None
+        nblocks = 1024
+        partial = torch.empty(2 * nblocks, dtype=torch.float32, device=e.device)
+        loss = torch.empty((), dtype=torch.float32, device=e.device)
+        fr = (C.c_int32 * B)(*[int(n) for n in frames])
+        with torch.cuda.device(e.device):
+            _lib.check(lib.eab_com_mag_mse_loss_f32(e.data_ptr(), lab.data_ptr(), fr, B, T, F, partial.data_ptr(), nblocks,
+                                                    loss.data_ptr(), grad.data_ptr() if grad is not None else None,
+                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       "eab_com_mag_mse_loss_f32")
+        ctx.save_for_backward(grad)
+        ctx.in_dtype = esti.dtype
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (g * grad).to(ctx.in_dtype), None, None
+
+
+def _loss_on_device(esti: torch.Tensor, label: torch.Tensor, frame_list) -> bool:
+    return (esti.is_cuda and label.is_cuda and esti.ndim == 4 and esti.shape == label.shape and esti.shape[1] == 2
+            and esti.shape[0] <= 64 and len(frame_list) == esti.shape[0] and not label.requires_grad
+            and all(0 <= int(n) <= esti.shape[2] for n in frame_list) and sum(int(n) for n in frame_list) > 0)
+
+
 def com_mag_mse_loss(esti: torch.Tensor, label: torch.Tensor, frame_list) -> torch.Tensor:
-    """Reference EaBNet.py:627-640: 0.5*(masked magnitude MSE + masked complex MSE)."""
+    """Reference EaBNet.py:627-640: 0.5*(masked magnitude MSE + masked complex MSE), esti/label (B,2,T,F).
+    CUDA tensors: one fused HIP pass produces the value and the gradient w.r.t. ``esti``
+    (eab_com_mag_mse_loss_f32); anything else (CPU tensors, > 64 utterances, a label that needs a gradient)
+    is evaluated with the reference's tensor expressions."""
+    if _loss_on_device(esti, label, frame_list):
+        return _ComMagMseLoss.apply(esti, label, tuple(int(n) for n in frame_list))
     B, _, T, F = esti.shape
     mask = torch.zeros((B, T, F), dtype=esti.dtype, device=esti.device)
     for i, n in enumerate(frame_list):
@@ -765,6 +805,15 @@ def com_mag_mse_loss(esti: torch.Tensor, label: torch.Tensor, frame_list) -> tor
 def stagewise_com_mag_mse_loss(esti_list, label: torch.Tensor, frame_list) -> torch.Tensor:
     """Reference GaGNet.py:601-619: the complex + magnitude MSE of every stage, weight 0.1 (1 for the
     last stage).  esti (B,2,F,T) each, label (B,2,F,T)."""
+    lab_t = label.permute(0, 1, 3, 2)
+    if all(_loss_on_device(e.permute(0, 1, 3, 2), lab_t, frame_list) for e in esti_list):
+        # every stage is the same masked loss on (B,2,T,F) views; the stage outputs of eabnet_amd.GaGNet are
+        # already laid out that way, so nothing is copied
+        total = 0.0
+        for i, e in enumerate(esti_list):
+            alpha = 1.0 if i == len(esti_list) - 1 else 0.1
+            total = total + alpha * com_mag_mse_loss(e.permute(0, 1, 3, 2), lab_t, frame_list)
+        return total
     B, _, Fq, T = label.shape
     mask = torch.zeros((B, Fq, T), dtype=label.dtype, device=label.device)
     for i, n in enumerate(frame_list):

@@ -119,6 +119,18 @@ int eab_gag_crm_f32(const float* pre, const float* g, const float* r, const floa
                     eab_stream_t stream);
 
 /* --------------------------------------------------------------------------
+ * Training loss, value and gradient in one pass (first piece).  Replaces com_mag_mse_loss
+ * (EaBNet.py:627-640) and each stage of stagewise_com_mag_mse_loss (GaGNet.py:601-619):
+ *     mask[b,t,f] = t < frames[b],  n = sum(mask)
+ *     loss = 0.5 * ( sum mask (|e|-|l|)^2 / n + sum mask |e-l|^2 / (2n) )
+ *   esti, label [B][2][T][F];  frames: HOST array of B frame counts (B <= 64; passed by value to the kernel)
+ *   partial: device scratch of 2*partial_blocks floats;  loss: device scalar
+ *   grad: NULL or [B][2][T][F] receiving d loss / d esti (zero outside the masks)
+ * ------------------------------------------------------------------------ */
+int eab_com_mag_mse_loss_f32(const float* esti, const float* label, const int32_t* frames, int B, int T, int F,
+                             float* partial, int partial_blocks, float* loss, float* grad, eab_stream_t stream);
+
+/* --------------------------------------------------------------------------
  * K13  complex filter-and-sum, stand-alone.   Replaces EaBNet.py:114-117.
  *   w, x [B][T][F][M][2] -> y [B][2][T][F];  Y = sum_m W_m * X_m (no conjugate)
  * ------------------------------------------------------------------------ */

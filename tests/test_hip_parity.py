@@ -799,3 +799,43 @@ def test_random_configurations_vs_oracle(dev, seed):
             net.precision = precision
             y = net(x.to(dev))
             assert_close(y.cpu().numpy(), ref.numpy(), max(TOL_HIP, 3 * floor), f"{kw} B={B} T={T} {precision}")
+
+
+# ------------------------------------------------------------------ fused losses (first piece)
+def test_fused_loss_value_vs_reference_fixtures(dev):
+    """com_mag_mse_loss on the device (one fused pass) against the values the reference's own function
+    returned (full and ragged frame lists), and the stage-wise loss against GaGNet.py's."""
+    import eabnet_amd
+    g = load("e2e_M8_B2_T20.npz")
+    esti = torch.from_numpy(g["out"]).to(dev)
+    label = torch.from_numpy(paramgen.make_spec_input(2, 20, 161, 1, int(g["label_seed"]))[..., 0, :]).permute(0, 3, 1, 2).to(dev)
+    for frames, key in (([20, 20], "loss_full"), ([20, 13], "loss_ragged")):
+        v = float(eabnet_amd.com_mag_mse_loss(esti, label, frames))
+        assert abs(v - float(g[key])) <= 1e-5 * abs(float(g[key])), (v, float(g[key]))
+    gg = load("gag_default.npz")
+    outs = [torch.from_numpy(gg[f"out{j}"]).to(dev) for j in range(3)]
+    lab = torch.from_numpy(paramgen.make_spec_input(2, 14, 161, 1, 800)[..., 0, :]).permute(0, 3, 2, 1).contiguous().to(dev)
+    v = float(eabnet_amd.stagewise_com_mag_mse_loss(outs, lab, [14, 9]))
+    assert abs(v - float(gg["stage_loss"])) <= 1e-5 * float(gg["stage_loss"])
+
+
+def test_fused_loss_gradient_vs_autograd(dev):
+    """d loss / d esti from the fused kernel == autograd through the reference's tensor expressions
+    (ragged masks, bf16-rounded inputs, an exactly-zero bin), and it composes with upstream autograd."""
+    import eabnet_amd
+    from oracle import eabnet_oracle as orc
+    torch.manual_seed(5)
+    e0 = torch.randn(3, 2, 17, 161, device=dev)
+    e0[1, :, 4, 7] = 0.0
+    lab = torch.randn(3, 2, 17, 161, device=dev)
+    frames = [17, 9, 12]
+    w = torch.randn(3, 2, 17, 161, device=dev, requires_grad=True)
+    loss = eabnet_amd.com_mag_mse_loss(e0 * w, lab, frames)            # upstream op: grads flow through
+    loss.backward()
+    e_ref = (e0 * w.detach()).cpu().double().requires_grad_(True)
+    ref = orc.com_mag_mse_loss(e_ref, lab.cpu().double(), frames)
+    ref.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-5 * float(ref.detach())
+    gref = (e_ref.grad * e0.cpu().double())
+    gref[torch.isnan(gref)] = 0.0                                      # |e| = 0: the kernel's subgradient is 0
+    assert_close(w.grad.cpu().numpy(), gref.numpy(), 1e-5, "d loss / d w")
