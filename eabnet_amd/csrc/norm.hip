@@ -77,44 +77,45 @@ extern "C" int eab_in_finalize_f32(const float* stats, int B, int C, int nsets, 
     EAB_RETURN_LAUNCH_STATUS();
 }
 
-// out = prelu(a*sa + ha) [+ prelu(b*sb + hb)], float4 per thread, grid-stride.
+// out = prelu(a*sa + ha) [+ prelu(b*sb + hb)], float4 per thread.  blockIdx.y = batch element, grid-stride over
+// its float4s in 32-bit arithmetic (the flat 64-bit index needed two emulated 64-bit divisions per float4).
 __global__ __launch_bounds__(256) void norm_act_kernel(const float* __restrict__ a, const float* __restrict__ xfa,
                                                        const float* __restrict__ sla, const float* __restrict__ bb,
                                                        const float* __restrict__ xfb, const float* __restrict__ slb,
-                                                       float* __restrict__ out, int P, int C, long long total4,
+                                                       float* __restrict__ out, int P, int C,
                                                        const int* __restrict__ t_pos, int rows_per_t, int Pw) {
-    // total4 counts float4 of the rows computed: all P rows per batch element, or the Pw rows of the
-    // streaming window starting at row *t_pos * rows_per_t
-    const int C4 = C >> 2;
-    const int p_lo = t_pos ? *t_pos * rows_per_t : 0;
-    const long long per_b = (long long)(t_pos ? Pw : P) * C4;
-    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < total4;
-         j += (long long)gridDim.x * blockDim.x) {
-        const int b = (int)(j / per_b);
-        const long long rem = j - (long long)b * per_b;
-        if (p_lo + rem / C4 >= P) continue;                      // last chunk shorter than the window
-        const long long i = ((long long)b * P + p_lo) * C4 + rem;
-        const int c = (int)(rem % C4) * 4;
+    // rows computed per batch element: all P, or the Pw rows of the streaming window starting at row
+    // *t_pos * rows_per_t (clipped at P: the last chunk may be shorter than the window)
+    const unsigned C4 = (unsigned)C >> 2;
+    const unsigned p_lo = t_pos ? (unsigned)*t_pos * (unsigned)rows_per_t : 0u;
+    const unsigned rows = t_pos ? ((unsigned)Pw < (unsigned)P - p_lo ? (unsigned)Pw : (unsigned)P - p_lo) : (unsigned)P;
+    const unsigned n4 = p_lo < (unsigned)P ? rows * C4 : 0u;
+    const unsigned b = blockIdx.y;
+    const size_t base = ((size_t)b * P + p_lo) * C4;
+    const bool pow2 = (C4 & (C4 - 1)) == 0;
+    for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < n4; r += gridDim.x * blockDim.x) {
+        const size_t i = base + r;
+        const int c = (int)(pow2 ? (r & (C4 - 1)) : (r % C4)) * 4;
         const f32x4 va = reinterpret_cast<const f32x4*>(a)[i];
         const float* xp = xfa + ((size_t)b * C + c) * 2;
         const f32x4 s01 = *reinterpret_cast<const f32x4*>(xp), s23 = *reinterpret_cast<const f32x4*>(xp + 4);
         const f32x4 sl = *reinterpret_cast<const f32x4*>(sla + c);
-        f32x4 r;
-        r[0] = eab_prelu(fmaf(va[0], s01[0], s01[1]), sl[0]);
-        r[1] = eab_prelu(fmaf(va[1], s01[2], s01[3]), sl[1]);
-        r[2] = eab_prelu(fmaf(va[2], s23[0], s23[1]), sl[2]);
-        r[3] = eab_prelu(fmaf(va[3], s23[2], s23[3]), sl[3]);
+        f32x4 r4;
+        r4[0] = eab_prelu(fmaf(va[0], s01[0], s01[1]), sl[0]);
+        r4[1] = eab_prelu(fmaf(va[1], s01[2], s01[3]), sl[1]);
+        r4[2] = eab_prelu(fmaf(va[2], s23[0], s23[1]), sl[2]);
+        r4[3] = eab_prelu(fmaf(va[3], s23[2], s23[3]), sl[3]);
         if (bb) {
             const f32x4 vb = reinterpret_cast<const f32x4*>(bb)[i];
             const float* yp = xfb + ((size_t)b * C + c) * 2;
             const f32x4 t01 = *reinterpret_cast<const f32x4*>(yp), t23 = *reinterpret_cast<const f32x4*>(yp + 4);
             const f32x4 tl = *reinterpret_cast<const f32x4*>(slb + c);
-            r[0] += eab_prelu(fmaf(vb[0], t01[0], t01[1]), tl[0]);
-            r[1] += eab_prelu(fmaf(vb[1], t01[2], t01[3]), tl[1]);
-            r[2] += eab_prelu(fmaf(vb[2], t23[0], t23[1]), tl[2]);
-            r[3] += eab_prelu(fmaf(vb[3], t23[2], t23[3]), tl[3]);
+            r4[0] += eab_prelu(fmaf(vb[0], t01[0], t01[1]), tl[0]);
+            r4[1] += eab_prelu(fmaf(vb[1], t01[2], t01[3]), tl[1]);
+            r4[2] += eab_prelu(fmaf(vb[2], t23[0], t23[1]), tl[2]);
+            r4[3] += eab_prelu(fmaf(vb[3], t23[2], t23[3]), tl[3]);
         }
-        reinterpret_cast<f32x4*>(out)[i] = r;
+        reinterpret_cast<f32x4*>(out)[i] = r4;
     }
 }
 
@@ -125,12 +126,13 @@ extern "C" int eab_norm_act_win_f32(const float* a, const float* xfa, const floa
     EAB_CHECK_ARG(b == nullptr || (xfb && slopeb));
     EAB_CHECK_ARG(win.pos == nullptr || win.count > 0);
     const long long P = (long long)T * rows_per_t, Pw = (long long)(win.pos ? win.count : T) * rows_per_t;
-    EAB_CHECK_ARG(P < (1ll << 31));
-    const long long total4 = (long long)B * Pw * (C / 4);
-    long long g = (total4 + 255) / 256;
-    if (g > 256 * 8) g = 256 * 8;   // <= 8 blocks per CU, grid-stride the rest
-    hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)g), dim3(256), 0, eab_stream(stream), a, xfa, slopea, b, xfb,
-                       slopeb, out, (int)P, C, total4, win.pos, rows_per_t, (int)Pw);
+    EAB_CHECK_ARG(P * (C / 4) < (1ll << 31) && B <= 65535);
+    long long gx = (Pw * (C / 4) + 255) / 256;
+    const long long cap = (256 * 8 + B - 1) / B;       // <= 8 blocks per CU over the whole grid, grid-stride the rest
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)gx, (unsigned)B), dim3(256), 0, eab_stream(stream), a, xfa, slopea,
+                       b, xfb, slopeb, out, (int)P, C, win.pos, rows_per_t, (int)Pw);
     EAB_RETURN_LAUNCH_STATUS();
 }
 
