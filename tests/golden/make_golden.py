@@ -242,9 +242,58 @@ def main_gagnet():
          input_seed=522, ref_mic=ref_mic, **{f"stage{j}": o.numpy() for j, o in enumerate(lst)})
 
 
+def _fill(module, seed, recipe):
+    """deterministic, non-default values for every parameter of a stand-alone reference block; `recipe`
+    receives (key, shape, kind, fan_in, seed) so that the test can regenerate them without the reference"""
+    sd = {}
+    for k, v in module.state_dict().items():
+        kind = ("prelu" if v.ndim == 1 and k.endswith(("0.weight", "2.weight")) and "norm" not in k and "conv" not in k.split(".")[-2:]
+                else "norm_w" if "norm.weight" in k else "norm_b" if "norm.bias" in k
+                else "bias" if k.endswith("bias") or "bias_" in k else "conv_w")
+        fan = int(np.prod(v.shape[1:])) if v.ndim > 1 else int(v.shape[0])
+        sd[k] = torch.from_numpy(paramgen.make_param("block/" + k, tuple(v.shape), kind, fan, seed))
+        recipe.append([k, list(v.shape), kind, fan, seed])
+    module.load_state_dict(sd, strict=True)
+
+
+def main_blocks():
+    """Per-block input/output pairs of the reference's own classes: each block alone, with
+    its parameters stored next to the result (they are small), T = 10, B = 1."""
+    import EaBNet as R
+    rng = np.random.default_rng(77)
+    out, recipes = {}, {}
+
+    def run(name, module, x, seed):
+        module.eval()
+        recipes[name] = []
+        _fill(module, seed, recipes[name])
+        y = module(torch.from_numpy(x))
+        out[f"{name}/x"] = x
+        out[f"{name}/y"] = (y[0] if isinstance(y, tuple) else y).numpy()
+
+    g = lambda *shape: (0.5 * rng.standard_normal(shape)).astype(np.float32)  # noqa: E731
+    run("gateconv_2x5", R.GateConv2d(16, 64, (2, 5), (1, 2)), g(1, 16, 10, 161), 1)
+    run("gateconv_2x3", R.GateConv2d(64, 64, (2, 3), (1, 2)), g(1, 64, 10, 39), 2)
+    run("gatedeconv_2x3", R.GateConvTranspose2d(128, 64, (2, 3), (1, 2)), g(1, 128, 10, 19), 3)
+    run("gatedeconv_2x5", R.GateConvTranspose2d(128, 64, (2, 5), (1, 2)), g(1, 128, 10, 79), 4)
+    run("conv2dunit", R.Conv2dunit((1, 3), 64, "IN"), g(1, 64, 10, 39), 5)
+    run("deconv2dunit_add", R.Deconv2dunit((1, 3), 64, "add", "IN"), g(1, 64, 10, 9), 6)
+    run("deconv2dunit_cat", R.Deconv2dunit((1, 3), 64, "cat", "IN"), g(1, 128, 10, 9), 7)
+    run("unet_module_enc_s3", R.En_unet_module(64, 64, (2, 3), (1, 3), "cat", "IN", 3, False), g(1, 64, 10, 79), 8)
+    run("unet_module_dec_s2", R.En_unet_module(128, 64, (2, 3), (1, 3), "cat", "IN", 2, True), g(1, 128, 10, 9), 9)
+    run("stcm_d1", R.SqueezedTCM(5, 64, 1, 256, True, "IN"), g(1, 256, 40), 10)
+    run("stcm_d32", R.SqueezedTCM(5, 64, 32, 256, True, "IN"), g(1, 256, 40), 11)
+    run("lstm_bf", R.LSTM_BF(64, 8), g(1, 64, 10, 21), 12)
+    save("blocks.npz", **out)
+    with open(os.path.join(HERE, "blocks_params.json"), "w") as f:
+        json.dump(recipes, f)
+
+
 if __name__ == "__main__":
     with torch.no_grad():
-        if sys.argv[1:] == ["gagnet"]:
+        if sys.argv[1:] == ["blocks"]:
+            main_blocks()
+        elif sys.argv[1:] == ["gagnet"]:
             main_gagnet()
         elif sys.argv[1:] == ["variants"]:
             main_variants()
@@ -255,3 +304,4 @@ if __name__ == "__main__":
             main_variants()
             main_istft()
             main_gagnet()
+            main_blocks()

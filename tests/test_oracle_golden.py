@@ -249,3 +249,47 @@ def test_two_stage_oracle_matches_reference_composition():
     assert_close(o["esti0_stft"].numpy(), g["esti0"], TOL_ORACLE, "esti0")
     assert o["esti_stft"].shape == (1, 2, 12, 161)
     assert_close(o["esti_stft"].numpy(), g["esti"], 2e-4, "esti")
+
+
+def _block(name):
+    """inputs, reference output and regenerated parameters of one stand-alone reference block
+    (tests/golden/blocks.npz + blocks_params.json, make_golden.py main_blocks)"""
+    import json
+    import os
+    g = load("blocks.npz")
+    with open(os.path.join(GOLDEN, "blocks_params.json")) as f:
+        recipe = json.load(f)[name]
+    P = {k: torch.from_numpy(paramgen.make_param("block/" + k, tuple(shape), kind, fan, seed)) for k, shape, kind, fan, seed in recipe}
+    return torch.from_numpy(g[f"{name}/x"]), g[f"{name}/y"], P
+
+
+def test_oracle_blocks_match_the_reference_classes():
+    """Every block function of the oracle against the reference's own class run alone:
+    GateConv2d, GateConvTranspose2d (+Chomp_T), Conv2dunit, Deconv2dunit (add / cat), En_unet_module in both
+    directions, SqueezedTCM at dilation 1 and 32 (longer than the 40-frame input), LSTM_BF."""
+    with torch.no_grad():
+        for name in ("gateconv_2x5", "gateconv_2x3"):
+            x, y, P = _block(name)
+            assert_close(orc.gate_conv2d(x, P["conv.1.weight"], P["conv.1.bias"]).numpy(), y, TOL_ORACLE, name)
+        for name in ("gatedeconv_2x3", "gatedeconv_2x5"):
+            x, y, P = _block(name)
+            assert_close(orc.gate_deconv2d(x, P["conv.0.weight"], P["conv.0.bias"]).numpy(), y, TOL_ORACLE, name)
+        x, y, P = _block("conv2dunit")
+        Pq = {f"u.{k}": v for k, v in P.items()}
+        out = orc._in_prelu(torch.nn.functional.conv2d(x, P["conv.0.weight"], P["conv.0.bias"], stride=(1, 2)), Pq, "u.conv.1", "u.conv.2")
+        assert_close(out.numpy(), y, TOL_ORACLE, "conv2dunit")
+        for name in ("deconv2dunit_add", "deconv2dunit_cat"):
+            x, y, P = _block(name)
+            Pq = {f"u.{k}": v for k, v in P.items()}
+            out = orc._in_prelu(torch.nn.functional.conv_transpose2d(x, P["deconv.0.weight"], P["deconv.0.bias"], stride=(1, 2)),
+                                Pq, "u.deconv.1", "u.deconv.2")
+            assert_close(out.numpy(), y, TOL_ORACLE, name)
+        x, y, P = _block("unet_module_enc_s3")
+        assert_close(orc.unet_module(x, {f"m.{k}": v for k, v in P.items()}, "m", 3, False).numpy(), y, TOL_ORACLE, "enc module")
+        x, y, P = _block("unet_module_dec_s2")
+        assert_close(orc.unet_module(x, {f"m.{k}": v for k, v in P.items()}, "m", 2, True).numpy(), y, TOL_ORACLE, "dec module")
+        for name, d in (("stcm_d1", 1), ("stcm_d32", 32)):
+            x, y, P = _block(name)
+            assert_close(orc.squeezed_tcm(x, {f"t.{k}": v for k, v in P.items()}, "t", d, 5).numpy(), y, TOL_ORACLE, name)
+        x, y, P = _block("lstm_bf")
+        assert_close(orc.lstm_bf(x, {f"bf_map.{k}": v for k, v in P.items()}, 8).numpy(), y, TOL_ORACLE, "lstm_bf")
