@@ -213,243 +213,248 @@ def main():
             y, ns = step()                      # rebind the f32 program for the instrumented replay
         torch.cuda.synchronize()
 
-    if rank == 0 and not a.no_roofline:
-        with torch.no_grad():
-            ops, ms = instrumented_replay(net, ns, reps=3)
+    # Everything below is secondary reporting by rank 0 (the other ranks wait at the final barrier): a failure
+    # there must not cost the headline line, so it is recorded instead of raised.
+    try:
+        if rank == 0 and not a.no_roofline:
+            with torch.no_grad():
+                ops, ms = instrumented_replay(net, ns, reps=3)
 
-        def valid_flop(o):
-            """exact MACs*2 of a conv launch: taps that fall on zero padding are not counted"""
-            tot = 0
-            oo = np.arange(o.No)
-            for dt, io in zip(o.dt, o.ioff):
-                fi = oo * o.istride + io
-                tot += max(o.T + dt, 0) * int(((fi >= 0) & (fi < o.Fin)).sum())
-            return 2.0 * o.B * tot * o.N * (o.C0 + o.C1)
+            def valid_flop(o):
+                """exact MACs*2 of a conv launch: taps that fall on zero padding are not counted"""
+                tot = 0
+                oo = np.arange(o.No)
+                for dt, io in zip(o.dt, o.ioff):
+                    fi = oo * o.istride + io
+                    tot += max(o.T + dt, 0) * int(((fi >= 0) & (fi < o.Fin)).sum())
+                return 2.0 * o.B * tot * o.N * (o.C0 + o.C1)
 
-        if a.per_op:
-            with open(a.per_op, "w") as f:
-                f.write("idx kind ms gflop tflops name geometry\n")
-                for k, o in enumerate(ops):
-                    gf, geo = 0.0, ""
-                    if o.kind == prg.OP_CONV:
-                        gf = valid_flop(o) * 1e-9
-                        geo = (f"N={o.N} C={o.C0}+{o.C1} taps={len(o.dt)} Fin={o.Fin} No={o.No} bm={o.bm} xf={o.xf_mode} "
-                               f"epi={o.epi} sets={o.nsets} prec={o.precision} korder={o.korder}")
-                    f.write(f"{k} {o.kind} {ms[k]:.4f} {gf:.3f} {gf / max(ms[k], 1e-9):.2f} {o.name} {geo}\n")
-        conv = [k for k, o in enumerate(ops) if o.kind == prg.OP_CONV]
-        # dominant kernel = the 128x128-tile gated instantiation (GateConv2d / GateConvTranspose2d)
-        dom = [k for k in conv if ops[k].epi == prg.EPI_GLU and ops[k].bm == 128 and ops[k].C0 % 4 == 0
-               and ops[k].precision == (prg.PREC_F32 if a.precision == "f32" else prg.PREC_F16X3)]
-        dom_ms = float(ms[dom].sum())
-        dom_flop = float(sum(valid_flop(ops[k]) for k in dom))
-        achieved = dom_flop / (dom_ms * 1e-3) / 1e12
-        conv_ms = float(ms[conv].sum())
-        by_kind = {}
-        for k, o in enumerate(ops):
-            nm = {prg.OP_CONV: "conv_gemm", prg.OP_IN_FINALIZE: "in_finalize", prg.OP_NORM_ACT: "norm_act",
-                  prg.OP_LSTM64: "lstm64", prg.OP_BFW_FS: "bfw_filter_sum", prg.OP_MEMSET0: "memset"}[o.kind]
-            by_kind[nm] = by_kind.get(nm, 0.0) + float(ms[k])
-        peak = PEAK_FP32_MFMA_TFLOPS
-        # HBM traffic of the dominant kernel from the committed PMC summary of the same command
-        # (tools/prof.sh + tools/summarize_profiles.py; PMC passes are separate runs by necessity).
-        # MI355X_MICROARCH.md §HBM: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE reads
-        # half of a wide coalesced read stream on gfx950.
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_final", "pmc_summary.json")))
-            tag = "conv_gemm_kernel<2, 2, 1, 1, 0, true, %d, true>" % (0 if a.precision == "f32" else 1)
-            ent = next(v for k, v in pmc.items() if tag in k)
-            c = ent["counters"]
-            nd = ent.get("dispatches_of", {})
-            traffic = (2.0 * c["FETCH_SIZE"] / nd.get("FETCH_SIZE", ent["dispatches"])
-                       + c["WRITE_SIZE"] / nd.get("WRITE_SIZE", ent["dispatches"])) * 1024.0
-        except Exception:                                   # noqa: BLE001 - no committed profile: leave null
+            if a.per_op:
+                with open(a.per_op, "w") as f:
+                    f.write("idx kind ms gflop tflops name geometry\n")
+                    for k, o in enumerate(ops):
+                        gf, geo = 0.0, ""
+                        if o.kind == prg.OP_CONV:
+                            gf = valid_flop(o) * 1e-9
+                            geo = (f"N={o.N} C={o.C0}+{o.C1} taps={len(o.dt)} Fin={o.Fin} No={o.No} bm={o.bm} xf={o.xf_mode} "
+                                   f"epi={o.epi} sets={o.nsets} prec={o.precision} korder={o.korder}")
+                        f.write(f"{k} {o.kind} {ms[k]:.4f} {gf:.3f} {gf / max(ms[k], 1e-9):.2f} {o.name} {geo}\n")
+            conv = [k for k, o in enumerate(ops) if o.kind == prg.OP_CONV]
+            # dominant kernel = the 128x128-tile gated instantiation (GateConv2d / GateConvTranspose2d)
+            dom = [k for k in conv if ops[k].epi == prg.EPI_GLU and ops[k].bm == 128 and ops[k].C0 % 4 == 0
+                   and ops[k].precision == (prg.PREC_F32 if a.precision == "f32" else prg.PREC_F16X3)]
+            dom_ms = float(ms[dom].sum())
+            dom_flop = float(sum(valid_flop(ops[k]) for k in dom))
+            achieved = dom_flop / (dom_ms * 1e-3) / 1e12
+            conv_ms = float(ms[conv].sum())
+            by_kind = {}
+            for k, o in enumerate(ops):
+                nm = {prg.OP_CONV: "conv_gemm", prg.OP_IN_FINALIZE: "in_finalize", prg.OP_NORM_ACT: "norm_act",
+                      prg.OP_LSTM64: "lstm64", prg.OP_BFW_FS: "bfw_filter_sum", prg.OP_MEMSET0: "memset"}[o.kind]
+                by_kind[nm] = by_kind.get(nm, 0.0) + float(ms[k])
+            peak = PEAK_FP32_MFMA_TFLOPS
+            # HBM traffic of the dominant kernel from the committed PMC summary of the same command
+            # (tools/prof.sh + tools/summarize_profiles.py; PMC passes are separate runs by necessity).
+            # MI355X_MICROARCH.md §HBM: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE reads
+            # half of a wide coalesced read stream on gfx950.
             traffic = None
-        out["roofline"] = {
-            "kernel": "conv_gemm_kernel<MI=2,NI=2,KU=1,GLU,XF=0,VEC," + ("f32" if a.precision == "f32" else "f16x3")
-                      + "> (128x128-tile gated gather-GEMM convolution)",
-            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r01_final)",
-            "launches_per_step": len(dom), "avg_launch_ms": dom_ms / max(len(dom), 1),
-            "algorithmic_gflop_per_launch": dom_flop / max(len(dom), 1) / 1e9,
-            "share_of_program_time": dom_ms / float(ms.sum()),
-            "all_conv_launches": {"launches_per_step": len(conv), "ms": conv_ms,
-                                  "achieved_tflops": 2.0 * conv_kernel_mac_per_frame(MICS) * B_PER_GPU * T / (conv_ms * 1e-3) / 1e12},
-            "program_ms_by_kernel": {k: round(v, 4) for k, v in sorted(by_kind.items(), key=lambda kv: -kv[1])},
-            "program_ms_total": float(ms.sum()),
-            "note": "achieved = exact valid-tap FLOPs of the dominant instantiation's launches / their summed "
-                    "duration (HIP events per op on the launch stream, instrumented replay after the timed region); "
-                    "peak = fp32 MFMA dense (MI355X_MICROARCH.md); traffic: see profiles/ (PMC passes are separate runs)",
-        }
-    if rank == 0 and not a.no_roofline:
-        # HBM-side kernels of the path (SURVEY §8d asks for both fractions): algorithmic bytes / time
-        def timed(fn, reps=10):
-            for _ in range(3):
-                fn()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / reps * 1e-3
-        with torch.no_grad():
-            t_stft = timed(lambda: eabnet_amd.stft_compress(wav, N_FFT, HOP, window))
-            wts = torch.randn_like(ns)
-            t_fs = timed(lambda: eabnet_amd.filter_and_sum(wts, ns))
-            est = torch.randn(B_PER_GPU, 2, T, 161, device=dev)
-            t_is = timed(lambda: eabnet_amd.istft(est, N_FFT, HOP, window))
-        fr = B_PER_GPU * T
-        by_stft = fr * (160 * MICS * 4 + 161 * MICS * 2 * 4)
-        by_fs = fr * 161 * (4 * MICS + 2) * 4
-        by_is = fr * (2 * 161 + 160) * 4
-        by_na = fr * 3 * 64 * 4 * sum(o.P for o in ops if o.kind == prg.OP_NORM_ACT and o.b is not None) / T \
-            + fr * 2 * 64 * 4 * sum(o.P for o in ops if o.kind == prg.OP_NORM_ACT and o.b is None) / T
-        t_na = 1e-3 * sum(float(ms[k]) for k, o in enumerate(ops) if o.kind == prg.OP_NORM_ACT)
-        out["hbm_kernels"] = {
-            "peak_GBs": PEAK_HBM_GBS,
-            "stft_compress": {"us": 1e6 * t_stft, "achieved_GBs": by_stft / t_stft / 1e9, "frac": by_stft / t_stft / 1e9 / PEAK_HBM_GBS,
-                              "bytes_per_frame": 160 * MICS * 4 + 161 * MICS * 2 * 4},
-            "filter_sum": {"us": 1e6 * t_fs, "achieved_GBs": by_fs / t_fs / 1e9, "frac": by_fs / t_fs / 1e9 / PEAK_HBM_GBS,
-                           "bytes_per_frame": 161 * (4 * MICS + 2) * 4},
-            "istft(back end, next row N2)": {"us": 1e6 * t_is, "achieved_GBs": by_is / t_is / 1e9,
-                                             "frac": by_is / t_is / 1e9 / PEAK_HBM_GBS, "bytes_per_frame": (2 * 161 + 160) * 4},
-            "norm_act(all 10 launches)": {"us": 1e6 * t_na, "achieved_GBs": by_na / t_na / 1e9, "frac": by_na / t_na / 1e9 / PEAK_HBM_GBS},
-        }
-
-    if rank == 0 and not a.no_c1:
-        # BASELINE configs[0] shape on the GPU: ONE 4-s 8-mic utterance, wave -> output, latency and RTF
-        wav1 = wav[:1].contiguous()
-        c1 = {}
-        for prec in (("f32", "f16x3") if (a.precision == "f32" and not a.no_alt) else (a.precision,)):
-            net.precision = prec
-            with torch.no_grad():
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_final", "pmc_summary.json")))
+                tag = "conv_gemm_kernel<2, 2, 1, 1, 0, true, %d, true>" % (0 if a.precision == "f32" else 1)
+                ent = next(v for k, v in pmc.items() if tag in k)
+                c = ent["counters"]
+                nd = ent.get("dispatches_of", {})
+                traffic = (2.0 * c["FETCH_SIZE"] / nd.get("FETCH_SIZE", ent["dispatches"])
+                           + c["WRITE_SIZE"] / nd.get("WRITE_SIZE", ent["dispatches"])) * 1024.0
+            except Exception:                                   # noqa: BLE001 - no committed profile: leave null
+                traffic = None
+            out["roofline"] = {
+                "kernel": "conv_gemm_kernel<MI=2,NI=2,KU=1,GLU,XF=0,VEC," + ("f32" if a.precision == "f32" else "f16x3")
+                          + "> (128x128-tile gated gather-GEMM convolution)",
+                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r01_final)",
+                "launches_per_step": len(dom), "avg_launch_ms": dom_ms / max(len(dom), 1),
+                "algorithmic_gflop_per_launch": dom_flop / max(len(dom), 1) / 1e9,
+                "share_of_program_time": dom_ms / float(ms.sum()),
+                "all_conv_launches": {"launches_per_step": len(conv), "ms": conv_ms,
+                                      "achieved_tflops": 2.0 * conv_kernel_mac_per_frame(MICS) * B_PER_GPU * T / (conv_ms * 1e-3) / 1e12},
+                "program_ms_by_kernel": {k: round(v, 4) for k, v in sorted(by_kind.items(), key=lambda kv: -kv[1])},
+                "program_ms_total": float(ms.sum()),
+                "note": "achieved = exact valid-tap FLOPs of the dominant instantiation's launches / their summed "
+                        "duration (HIP events per op on the launch stream, instrumented replay after the timed region); "
+                        "peak = fp32 MFMA dense (MI355X_MICROARCH.md); traffic: see profiles/ (PMC passes are separate runs)",
+            }
+        if rank == 0 and not a.no_roofline:
+            # HBM-side kernels of the path (SURVEY §8d asks for both fractions): algorithmic bytes / time
+            def timed(fn, reps=10):
                 for _ in range(3):
-                    y1 = net(eabnet_amd.stft_compress(wav1, N_FFT, HOP, window))
+                    fn()
                 torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(20):
-                    y1 = net(eabnet_amd.stft_compress(wav1, N_FFT, HOP, window))
-                torch.cuda.synchronize()
-                dt1 = (time.perf_counter() - t0) / 20
-            c1[prec] = {"ms_per_utterance": 1e3 * dt1, "rtf": dt1 / SECONDS, "frames_per_s": T / dt1}
-        net.precision = a.precision
-        out["single_utterance_c1"] = c1
-
-    if rank == 0 and not a.no_next:
-        # the boundary as the reference drives it: the wave arrives in HOST memory and prepare_data moves it
-        # (train_distributed.py:76-77) -- the PCIe-inclusive rate, never the headline
-        pd_args = argparse.Namespace(mics=MICS, sr=SR, wav_len=SECONDS, win_size=0.020, win_shift=0.010, fft_num=N_FFT)
-        net.precision = a.precision
-        host = {"pageable": wav.cpu(), "pinned": wav.cpu().pin_memory()}
-        pc = {}
-        for kind, hw in host.items():
-            with torch.no_grad():
-                for _ in range(3):
-                    net(eabnet_amd.prepare_data(hw, hw[:, :1], dev, pd_args)[0])
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(10):
-                    net(eabnet_amd.prepare_data(hw, hw[:, :1], dev, pd_args)[0])
-                torch.cuda.synchronize()
-            dth = (time.perf_counter() - t0) / 10
-            pc[kind] = {"ms_per_step": 1e3 * dth, "frames_per_s": B_PER_GPU * T / dth}
-        pc["note"] = (f"host wave ({wav.numel() * 4 / 1e6:.1f} MB per step) -> prepare_data (noisy + target STFT) -> EaBNet; "
-                      "blocking copies, no overlap with the previous step")
-        out.setdefault("next_rows", {})["pcie_inclusive"] = pc
-
-    if rank == 0 and not a.no_next:
-        # SURVEY §8f rows built after the hot path: what enhance.py actually runs -- wave -> STFT ->
-        # EaBNetWithPostNet (beam-former + GaGNet post-filter) -> ISTFT -> wave, same batch, same protocol
-        net = None
-        torch.cuda.empty_cache()
-        pa = argparse.Namespace(
-            k1=(2, 3), k2=(1, 3), c=64, M=MICS, embed_dim=64, kd1=5, cd1=64, d_feat=256, p=6, q=3, is_causal=True,
-            is_u2=True, bf_type="lstm", topo_type="mimo", intra_connect="cat", norm_type="IN", ref_mic=0,
-            freeze_eabnet=False, gagnet_k1=(2, 3), gagnet_k2=(1, 3), gagnet_c=64, gagnet_kd1=3, gagnet_cd1=64,
-            gagnet_d_feat=256, gagnet_p=2, gagnet_q=3, gagnet_dilas=[1, 2, 5, 9], gagnet_fft_num=320, gagnet_is_u2=True,
-            gagnet_is_causal=True, gagnet_is_squeezed=False, gagnet_acti_type="sigmoid", gagnet_intra_connect="cat",
-            gagnet_norm_type="IN")
-        torch.manual_seed(1)
-        two = eabnet_amd.make_eabnet_with_postnet(pa).to(dev).eval()
-        two.eabnet.load_state_dict(state, strict=True)
-        nxt = {"pipeline": "wave -> stft_compress -> EaBNetWithPostNet -> istft -> wave (enhance.py:45-62)",
-               "params": eabnet_amd.numParams(two)}
-        for prec in (("f32", "f16x3") if not a.no_alt else ("f32",)):
-            two.eabnet.precision = two.postnet.precision = prec
-
-            def step():
-                o = two(eabnet_amd.stft_compress(wav, N_FFT, HOP, window))
-                return eabnet_amd.istft(o["esti_stft"], N_FFT, HOP, window)
-            with torch.no_grad():
-                for _ in range(3):
-                    step()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(10):
-                    w_out = step()
-                torch.cuda.synchronize()
-                dtw = (time.perf_counter() - t0) / 10
-                inp = two.postnet._last[1:]
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for _ in range(10):
-                    two.postnet(*inp)
+                for _ in range(reps):
+                    fn()
                 e1.record()
                 torch.cuda.synchronize()
-            assert bool(torch.isfinite(w_out).all())
-            nxt[prec] = {"ms_per_step": 1e3 * dtw, "frames_per_s": B_PER_GPU * T / dtw,
-                         "postfilter_ms_per_step": e0.elapsed_time(e1) / 10}
-        # BASELINE config 5 shape: 16 microphones, 8-s utterance, frame-synchronous (BatchNorm norms, causal):
-        # latency of one step of `chunk` 10-ms frames = one hipGraph replay of the windowed program
-        torch.manual_seed(2)
-        sn = eabnet_amd.EaBNet(M=16, norm_type="BN").to(dev).eval()
-        stream_rows = {"config": "B=1, M=16, T_max=801 (8 s), norm_type=BN, fp32", "hop_ms": 10.0}
-        for chunk in (1, 16):
-            st = sn.stream_begin(1, T_max=801, chunk=chunk)
-            xs = 0.3 * torch.randn(1, chunk, 161, 16, 2, device=dev)
-            for _ in range(3):
-                st.step(xs)
-            torch.cuda.synchronize()
-            nstep = min(40, (801 - 3 * chunk) // chunk)
-            t0 = time.perf_counter()
-            for _ in range(nstep):
-                ys = st.step(xs)
-            torch.cuda.synchronize()
-            dts = (time.perf_counter() - t0) / nstep
-            assert bool(torch.isfinite(ys).all())
-            stream_rows[f"chunk{chunk}"] = {"ms_per_step": 1e3 * dts, "rtf": dts / (chunk * 0.010),
-                                            "algorithmic_latency_ms": 10.0 * chunk + 10.0}
-            st = None
-        nxt["streaming"] = stream_rows
-        sn = None
-        # the same, wave in -> wave out through the two-stage model (StreamingEnhancer: STFT windows, streamed
-        # beam-former + post-filter, ISTFT windows), one 10-ms hop of 16-microphone samples per push
-        pb = argparse.Namespace(**{**vars(pa), "M": 16, "norm_type": "BN", "gagnet_norm_type": "BN"})
-        tw = eabnet_amd.make_eabnet_with_postnet(pb).to(dev).eval()
-        enh = eabnet_amd.StreamingEnhancer(tw, B=1, seconds=8.0, chunk=1)
-        hop_samples = 0.05 * torch.randn(1, 16, 160, device=dev)
-        for _ in range(5):
-            enh.push(hop_samples)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(40):
-            wv = enh.push(hop_samples)
-        torch.cuda.synchronize()
-        dtp = (time.perf_counter() - t0) / 40
-        assert wv.shape == (1, 160) and bool(torch.isfinite(wv).all())
-        nxt["streaming_wave_to_wave"] = {"config": "B=1, M=16, two-stage model with BN norms, one hop (160 samples) per push",
-                                         "ms_per_push": 1e3 * dtp, "rtf": dtp / 0.010,
-                                         "latency_ms": 20.0 + 1e3 * dtp}
-        tw = enh = None
-        out.setdefault("next_rows", {}).update(nxt)
-        two = None
-        torch.cuda.empty_cache()
+                return e0.elapsed_time(e1) / reps * 1e-3
+            with torch.no_grad():
+                t_stft = timed(lambda: eabnet_amd.stft_compress(wav, N_FFT, HOP, window))
+                wts = torch.randn_like(ns)
+                t_fs = timed(lambda: eabnet_amd.filter_and_sum(wts, ns))
+                est = torch.randn(B_PER_GPU, 2, T, 161, device=dev)
+                t_is = timed(lambda: eabnet_amd.istft(est, N_FFT, HOP, window))
+            fr = B_PER_GPU * T
+            by_stft = fr * (160 * MICS * 4 + 161 * MICS * 2 * 4)
+            by_fs = fr * 161 * (4 * MICS + 2) * 4
+            by_is = fr * (2 * 161 + 160) * 4
+            by_na = fr * 3 * 64 * 4 * sum(o.P for o in ops if o.kind == prg.OP_NORM_ACT and o.b is not None) / T \
+                + fr * 2 * 64 * 4 * sum(o.P for o in ops if o.kind == prg.OP_NORM_ACT and o.b is None) / T
+            t_na = 1e-3 * sum(float(ms[k]) for k, o in enumerate(ops) if o.kind == prg.OP_NORM_ACT)
+            out["hbm_kernels"] = {
+                "peak_GBs": PEAK_HBM_GBS,
+                "stft_compress": {"us": 1e6 * t_stft, "achieved_GBs": by_stft / t_stft / 1e9, "frac": by_stft / t_stft / 1e9 / PEAK_HBM_GBS,
+                                  "bytes_per_frame": 160 * MICS * 4 + 161 * MICS * 2 * 4},
+                "filter_sum": {"us": 1e6 * t_fs, "achieved_GBs": by_fs / t_fs / 1e9, "frac": by_fs / t_fs / 1e9 / PEAK_HBM_GBS,
+                               "bytes_per_frame": 161 * (4 * MICS + 2) * 4},
+                "istft(back end, next row N2)": {"us": 1e6 * t_is, "achieved_GBs": by_is / t_is / 1e9,
+                                                 "frac": by_is / t_is / 1e9 / PEAK_HBM_GBS, "bytes_per_frame": (2 * 161 + 160) * 4},
+                "norm_act(all 10 launches)": {"us": 1e6 * t_na, "achieved_GBs": by_na / t_na / 1e9, "frac": by_na / t_na / 1e9 / PEAK_HBM_GBS},
+            }
 
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(state, MICS, L)
-        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        if rank == 0 and not a.no_c1:
+            # BASELINE configs[0] shape on the GPU: ONE 4-s 8-mic utterance, wave -> output, latency and RTF
+            wav1 = wav[:1].contiguous()
+            c1 = {}
+            for prec in (("f32", "f16x3") if (a.precision == "f32" and not a.no_alt) else (a.precision,)):
+                net.precision = prec
+                with torch.no_grad():
+                    for _ in range(3):
+                        y1 = net(eabnet_amd.stft_compress(wav1, N_FFT, HOP, window))
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(20):
+                        y1 = net(eabnet_amd.stft_compress(wav1, N_FFT, HOP, window))
+                    torch.cuda.synchronize()
+                    dt1 = (time.perf_counter() - t0) / 20
+                c1[prec] = {"ms_per_utterance": 1e3 * dt1, "rtf": dt1 / SECONDS, "frames_per_s": T / dt1}
+            net.precision = a.precision
+            out["single_utterance_c1"] = c1
+
+        if rank == 0 and not a.no_next:
+            # the boundary as the reference drives it: the wave arrives in HOST memory and prepare_data moves it
+            # (train_distributed.py:76-77) -- the PCIe-inclusive rate, never the headline
+            pd_args = argparse.Namespace(mics=MICS, sr=SR, wav_len=SECONDS, win_size=0.020, win_shift=0.010, fft_num=N_FFT)
+            net.precision = a.precision
+            host = {"pageable": wav.cpu(), "pinned": wav.cpu().pin_memory()}
+            pc = {}
+            for kind, hw in host.items():
+                with torch.no_grad():
+                    for _ in range(3):
+                        net(eabnet_amd.prepare_data(hw, hw[:, :1], dev, pd_args)[0])
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(10):
+                        net(eabnet_amd.prepare_data(hw, hw[:, :1], dev, pd_args)[0])
+                    torch.cuda.synchronize()
+                dth = (time.perf_counter() - t0) / 10
+                pc[kind] = {"ms_per_step": 1e3 * dth, "frames_per_s": B_PER_GPU * T / dth}
+            pc["note"] = (f"host wave ({wav.numel() * 4 / 1e6:.1f} MB per step) -> prepare_data (noisy + target STFT) -> EaBNet; "
+                          "blocking copies, no overlap with the previous step")
+            out.setdefault("next_rows", {})["pcie_inclusive"] = pc
+
+        if rank == 0 and not a.no_next:
+            # SURVEY §8f rows built after the hot path: what enhance.py actually runs -- wave -> STFT ->
+            # EaBNetWithPostNet (beam-former + GaGNet post-filter) -> ISTFT -> wave, same batch, same protocol
+            net = None
+            torch.cuda.empty_cache()
+            pa = argparse.Namespace(
+                k1=(2, 3), k2=(1, 3), c=64, M=MICS, embed_dim=64, kd1=5, cd1=64, d_feat=256, p=6, q=3, is_causal=True,
+                is_u2=True, bf_type="lstm", topo_type="mimo", intra_connect="cat", norm_type="IN", ref_mic=0,
+                freeze_eabnet=False, gagnet_k1=(2, 3), gagnet_k2=(1, 3), gagnet_c=64, gagnet_kd1=3, gagnet_cd1=64,
+                gagnet_d_feat=256, gagnet_p=2, gagnet_q=3, gagnet_dilas=[1, 2, 5, 9], gagnet_fft_num=320, gagnet_is_u2=True,
+                gagnet_is_causal=True, gagnet_is_squeezed=False, gagnet_acti_type="sigmoid", gagnet_intra_connect="cat",
+                gagnet_norm_type="IN")
+            torch.manual_seed(1)
+            two = eabnet_amd.make_eabnet_with_postnet(pa).to(dev).eval()
+            two.eabnet.load_state_dict(state, strict=True)
+            nxt = {"pipeline": "wave -> stft_compress -> EaBNetWithPostNet -> istft -> wave (enhance.py:45-62)",
+                   "params": eabnet_amd.numParams(two)}
+            for prec in (("f32", "f16x3") if not a.no_alt else ("f32",)):
+                two.eabnet.precision = two.postnet.precision = prec
+
+                def step():
+                    o = two(eabnet_amd.stft_compress(wav, N_FFT, HOP, window))
+                    return eabnet_amd.istft(o["esti_stft"], N_FFT, HOP, window)
+                with torch.no_grad():
+                    for _ in range(3):
+                        step()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(10):
+                        w_out = step()
+                    torch.cuda.synchronize()
+                    dtw = (time.perf_counter() - t0) / 10
+                    inp = two.postnet._last[1:]
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(10):
+                        two.postnet(*inp)
+                    e1.record()
+                    torch.cuda.synchronize()
+                assert bool(torch.isfinite(w_out).all())
+                nxt[prec] = {"ms_per_step": 1e3 * dtw, "frames_per_s": B_PER_GPU * T / dtw,
+                             "postfilter_ms_per_step": e0.elapsed_time(e1) / 10}
+            # BASELINE config 5 shape: 16 microphones, 8-s utterance, frame-synchronous (BatchNorm norms, causal):
+            # latency of one step of `chunk` 10-ms frames = one hipGraph replay of the windowed program
+            torch.manual_seed(2)
+            sn = eabnet_amd.EaBNet(M=16, norm_type="BN").to(dev).eval()
+            stream_rows = {"config": "B=1, M=16, T_max=801 (8 s), norm_type=BN, fp32", "hop_ms": 10.0}
+            for chunk in (1, 16):
+                st = sn.stream_begin(1, T_max=801, chunk=chunk)
+                xs = 0.3 * torch.randn(1, chunk, 161, 16, 2, device=dev)
+                for _ in range(3):
+                    st.step(xs)
+                torch.cuda.synchronize()
+                nstep = min(40, (801 - 3 * chunk) // chunk)
+                t0 = time.perf_counter()
+                for _ in range(nstep):
+                    ys = st.step(xs)
+                torch.cuda.synchronize()
+                dts = (time.perf_counter() - t0) / nstep
+                assert bool(torch.isfinite(ys).all())
+                stream_rows[f"chunk{chunk}"] = {"ms_per_step": 1e3 * dts, "rtf": dts / (chunk * 0.010),
+                                                "algorithmic_latency_ms": 10.0 * chunk + 10.0}
+                st = None
+            nxt["streaming"] = stream_rows
+            sn = None
+            # the same, wave in -> wave out through the two-stage model (StreamingEnhancer: STFT windows, streamed
+            # beam-former + post-filter, ISTFT windows), one 10-ms hop of 16-microphone samples per push
+            pb = argparse.Namespace(**{**vars(pa), "M": 16, "norm_type": "BN", "gagnet_norm_type": "BN"})
+            tw = eabnet_amd.make_eabnet_with_postnet(pb).to(dev).eval()
+            enh = eabnet_amd.StreamingEnhancer(tw, B=1, seconds=8.0, chunk=1)
+            hop_samples = 0.05 * torch.randn(1, 16, 160, device=dev)
+            for _ in range(5):
+                enh.push(hop_samples)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(40):
+                wv = enh.push(hop_samples)
+            torch.cuda.synchronize()
+            dtp = (time.perf_counter() - t0) / 40
+            assert wv.shape == (1, 160) and bool(torch.isfinite(wv).all())
+            nxt["streaming_wave_to_wave"] = {"config": "B=1, M=16, two-stage model with BN norms, one hop (160 samples) per push",
+                                             "ms_per_push": 1e3 * dtp, "rtf": dtp / 0.010,
+                                             "latency_ms": 20.0 + 1e3 * dtp}
+            tw = enh = None
+            out.setdefault("next_rows", {}).update(nxt)
+            two = None
+            torch.cuda.empty_cache()
+
+        if rank == 0 and world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(state, MICS, L)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    except Exception as e:  # noqa: BLE001
+        out["secondary_sections_error"] = repr(e)
     if rank == 0:
         print(json.dumps(out))
     if is_dist:
