@@ -9,9 +9,9 @@ error, never a fallback.
 """
 from .spec import GagConfig, NetConfig, gag_param_specs, param_specs  # noqa: F401
 from .model import (EaBNet, GaGNet, EaBNetWithPostNet, make_gag_net, make_eabnet_with_postnet,  # noqa: F401
-                    StreamingEnhancer, prepare_data, stft_compress, istft, filter_and_sum, numParams, com_mag_mse_loss,
+                    StreamingEnhancer, Pipeline, prepare_data, stft_compress, istft, filter_and_sum, numParams, com_mag_mse_loss,
                     stagewise_com_mag_mse_loss)
 
-__all__ = ["EaBNet", "GaGNet", "EaBNetWithPostNet", "make_gag_net", "make_eabnet_with_postnet", "StreamingEnhancer", "prepare_data",
+__all__ = ["EaBNet", "GaGNet", "EaBNetWithPostNet", "make_gag_net", "make_eabnet_with_postnet", "StreamingEnhancer", "Pipeline", "prepare_data",
            "stft_compress", "istft", "filter_and_sum", "numParams", "com_mag_mse_loss", "stagewise_com_mag_mse_loss",
            "NetConfig", "GagConfig", "param_specs", "gag_param_specs"]

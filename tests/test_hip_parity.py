@@ -839,3 +839,32 @@ def test_fused_loss_gradient_vs_autograd(dev):
     gref = (e_ref.grad * e0.cpu().double())
     gref[torch.isnan(gref)] = 0.0                                      # |e| = 0: the kernel's subgradient is 0
     assert_close(w.grad.cpu().numpy(), gref.numpy(), 1e-5, "d loss / d w")
+
+
+@pytest.mark.parametrize("depth,front", [(2, False), (3, True)])
+def test_pipeline_executor_is_bit_identical_and_ordered(dev, depth, front):
+    """eabnet_amd.Pipeline: several batches in flight on separate streams / captured programs return, in
+    submission order, exactly what net(x) returns for each batch (different inputs per batch; also after a
+    weight update and for the wave front end)."""
+    import eabnet_amd
+    net = _model(4, 230, dev, p=2, q=1)
+    win = torch.hann_window(320)
+    if front:
+        batches = [torch.from_numpy(paramgen.make_wave(2, 4, 4000, 240 + i)).to(dev) for i in range(5)]
+        ref_in = [eabnet_amd.stft_compress(w, 320, 160, win) for w in batches]
+    else:
+        batches = [torch.from_numpy(paramgen.make_spec_input(2, 19, 161, 4, 240 + i)).to(dev) for i in range(5)]
+        ref_in = batches
+    with torch.no_grad():
+        want = [net(x).clone() for x in ref_in]
+    pipe = eabnet_amd.Pipeline(net, depth=depth, front_end=(320, 160, win) if front else None)
+    got = list(pipe.map(batches))
+    assert len(got) == len(want) and all(torch.equal(g, w) for g, w in zip(got, want))
+    with pytest.raises(RuntimeError):
+        pipe.collect()
+    with torch.no_grad():                                   # parameters change -> every slot re-packs
+        net.get_parameter("bf_map.w_dnn.2.bias").add_(0.5)
+        want2 = net(ref_in[0]).clone()
+    assert not torch.equal(want2, want[0])
+    pipe.submit(batches[0])
+    assert torch.equal(pipe.collect(), want2)
