@@ -415,8 +415,25 @@ def main():
                         two.postnet(*inp)
                     e1.record()
                     torch.cuda.synchronize()
+                    # the same with two batches in flight (eabnet_amd.Pipeline over the two-stage model)
+                    pipe2 = eabnet_amd.Pipeline(two, depth=2, front_end=(N_FFT, HOP, window))
+                    for _ in range(3):
+                        pipe2.submit(wav)
+                        eabnet_amd.istft(pipe2.collect()["esti_stft"], N_FFT, HOP, window)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(12):
+                        if pipe2.outstanding == 2:
+                            w_out = eabnet_amd.istft(pipe2.collect()["esti_stft"], N_FFT, HOP, window)
+                        pipe2.submit(wav)
+                    while pipe2.outstanding:
+                        w_out = eabnet_amd.istft(pipe2.collect()["esti_stft"], N_FFT, HOP, window)
+                    torch.cuda.synchronize()
+                    dtp2 = (time.perf_counter() - t0) / 12
+                    pipe2 = None
                 assert bool(torch.isfinite(w_out).all())
                 nxt[prec] = {"ms_per_step": 1e3 * dtw, "frames_per_s": B_PER_GPU * T / dtw,
+                             "two_in_flight_ms_per_step": 1e3 * dtp2, "two_in_flight_frames_per_s": B_PER_GPU * T / dtp2,
                              "postfilter_ms_per_step": e0.elapsed_time(e1) / 10}
             # BASELINE config 5 shape: 16 microphones, 8-s utterance, frame-synchronous (BatchNorm norms, causal):
             # latency of one step of `chunk` 10-ms frames = one hipGraph replay of the windowed program

@@ -280,18 +280,19 @@ class _HipModule(nn.Module):
                 if s.kind != "bn_count"}
 
     def _program(self, B: int, T: int, F: int, device: torch.device) -> _Bound:
-        key = (B, T, F, str(device), self.precision)
+        chains = bool(self.__dict__.get("parallel_chains", True))
+        key = (B, T, F, str(device), self.precision, chains)
         fp = self._param_fingerprint()
         bound = self._bound.get(key)
         if bound is None or ("bf_w" in bound.prog.taps) != self.dump_bfw:
             prog = prg.lower(self.cfg, self._numpy_params(), B, T, F, dump_bfw=self.dump_bfw,
-                             precision=self.precision)
+                             precision=self.precision, parallel_chains=chains)
             bound = _Bound(prog, device)
             self._bound = {key: bound}                # keep one shape resident (activations can be GBs)
             self._packed_version = {key: fp}
         elif self._packed_version.get(key) != fp:
             prog = prg.lower(self.cfg, self._numpy_params(), B, T, F, dump_bfw=self.dump_bfw,
-                             precision=self.precision)
+                             precision=self.precision, parallel_chains=chains)
             bound.update_weights(prog.weights)
             self._packed_version[key] = fp
         return bound
@@ -456,28 +457,61 @@ class EaBNetStream:
         return out.to(x.dtype)
 
 
+def _replica(module: nn.Module) -> nn.Module:
+    """A second handle on the same parameters with its own lowered-program cache (own activation arena, boundary
+    buffers and hipGraph): shallow copies down the module tree, ``nn.Parameter`` objects shared."""
+    import copy
+    rep = copy.copy(module)
+    rep._modules = {k: (_replica(v) if v is not None else None) for k, v in module._modules.items()}
+    if isinstance(rep, _HipModule):
+        rep._bound, rep._packed_version = {}, {}
+        rep.__dict__.pop("_tensor_list", None)
+    return rep
+
+
+_PIPE_STREAMS: Dict[tuple, list] = {}
+
+
+def _sync_knobs(src: nn.Module, rep: nn.Module) -> None:
+    for k in ("precision", "use_graph", "training"):
+        if k in src.__dict__:
+            rep.__dict__[k] = src.__dict__[k]
+    for name, child in src._modules.items():
+        if child is not None:
+            _sync_knobs(child, rep._modules[name])
+
+
 class Pipeline:
-    """Throughput executor: keeps ``depth`` batches of the beam-former in flight on ``depth`` HIP streams, each
-    with its own captured program (own activations and boundary buffers; utterances of different batches never
-    interact).  One program alone leaves capacity idle -- the LSTM occupies 161 of 256 CUs for a fifth of the
-    step, the S-TCM launches 112, every kernel ends in a partial round of workgroups -- and a second, independent
-    program fills it: 9.06 -> 7.48 ms per 16-utterance step in exact fp32, 5.74 -> 4.49 ms in f16x3 (deeper
-    pipelines add nothing).  Results come back in submission order and are bit-identical to ``net(x)``.
+    """Throughput executor: keeps ``depth`` batches in flight on ``depth`` HIP streams, each through its own
+    replica of the model (own captured program, activations and boundary buffers; shared parameters).  One
+    program alone leaves capacity idle -- the LSTM occupies 161 of 256 CUs for a fifth of the step, the S-TCM
+    launches 112, every kernel ends in a partial round of workgroups -- and a second, independent batch fills
+    it: 9.06 -> 7.48 ms per 16-utterance step in exact fp32, 5.74 -> 4.49 ms in f16x3 (deeper pipelines add
+    nothing).  Results come back in submission order and are bit-identical to calling the model directly.
+    Works for ``EaBNet``, ``GaGNet`` (two inputs) and ``EaBNetWithPostNet``; inference only.
 
         pipe = Pipeline(net, depth=2, front_end=(320, 160, torch.hann_window(320)))
-        for wav in batches:            # (B, M, L) waves; without front_end: (B, T, F, M, 2) spectra
-            pipe.submit(wav)
+        for wav in batches:            # (B, M, L) waves; without front_end: whatever the model takes
             if pipe.outstanding == pipe.depth:
-                y = pipe.collect()     # (B, 2, T, F), ordered on the current stream
+                y = pipe.collect()     # what model(x) returns, ordered on the current stream
+            pipe.submit(wav)
         while pipe.outstanding: y = pipe.collect()
     """
 
-    def __init__(self, net: "EaBNet", depth: int = 2, front_end: Optional[tuple] = None):
+    def __init__(self, model: nn.Module, depth: int = 2, front_end: Optional[tuple] = None):
         if depth < 1:
             raise ValueError("depth must be >= 1")
-        self.net, self.depth, self.front_end = net, depth, front_end
+        self.model, self.depth, self.front_end = model, depth, front_end
+        self._replicas = [_replica(model) for _ in range(depth)] if depth > 1 else [model]
+        if depth > 1:
+            # with several batches in flight the post-filter's three S-TCM chains run back to back: the
+            # parallelism comes from the other batch, and hipGraphs with internal branches do not overlap
+            # each other (two-stage step 13.99 -> 12.13 ms; with branches kept: no gain at all)
+            for rep in self._replicas:
+                for m in rep.modules():
+                    if isinstance(m, GaGNet):
+                        m.parallel_chains = False
         self._streams: list = []
-        self._slots: list = [None] * depth            # (key, fingerprint, _Bound)
         self._pending: list = []
         self._n = 0
 
@@ -485,69 +519,62 @@ class Pipeline:
     def outstanding(self) -> int:
         return len(self._pending)
 
-    def _bound(self, slot: int, B: int, T: int, F: int, device: torch.device) -> _Bound:
-        net = self.net
-        key = (B, T, F, str(device), net.precision)
-        fp = net._param_fingerprint()
-        cur = self._slots[slot]
-        if cur is None or cur[0] != key:
-            prog = prg.lower(net.cfg, net._numpy_params(), B, T, F, precision=net.precision)
-            cur = (key, fp, _Bound(prog, device))
-        elif cur[1] != fp:
-            cur[2].update_weights(prg.lower(net.cfg, net._numpy_params(), B, T, F, precision=net.precision).weights)
-            cur = (key, fp, cur[2])
-        self._slots[slot] = cur
-        return cur[2]
+    @staticmethod
+    def _tensors(obj):
+        if torch.is_tensor(obj):
+            yield obj
+        elif isinstance(obj, dict):
+            for v in obj.values():
+                yield from Pipeline._tensors(v)
+        elif isinstance(obj, (list, tuple)):
+            for v in obj:
+                yield from Pipeline._tensors(v)
 
-    def submit(self, x: torch.Tensor) -> None:
-        """Enqueue one batch; returns immediately.  At most ``depth`` batches may be outstanding."""
+    def submit(self, *inputs: torch.Tensor) -> None:
+        """Enqueue one batch (the model's positional inputs); returns immediately.  At most ``depth`` batches
+        may be outstanding."""
         if self.outstanding >= self.depth:
             raise RuntimeError("collect() a result before submitting more than `depth` batches")
-        if not x.is_cuda:
-            raise _lib.EabError("Pipeline.submit needs a CUDA (ROCm) tensor; there is no CPU fallback by design.")
-        net = self.net
-        _lib.load()
-        with torch.cuda.device(x.device):
+        if not inputs or not all(x.is_cuda for x in inputs):
+            raise _lib.EabError("Pipeline.submit needs CUDA (ROCm) tensors; there is no CPU fallback by design.")
+        device = inputs[0].device
+        with torch.cuda.device(device):
             if not self._streams:
-                self._streams = [torch.cuda.Stream(device=x.device) for _ in range(self.depth)]
+                # one set of streams per (device, depth) for the whole process: HIP maps streams onto a few
+                # hardware queues in creation order, and two streams that land on the same queue do not overlap
+                # (observed: a later Pipeline with freshly created streams gained nothing)
+                key = (str(device), self.depth)
+                if key not in _PIPE_STREAMS:
+                    _PIPE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(self.depth)]
+                self._streams = _PIPE_STREAMS[key]
             slot = self._n % self.depth
             self._n += 1
             st = self._streams[slot]
-            st.wait_stream(torch.cuda.current_stream())            # the input was produced on the caller's stream
+            st.wait_stream(torch.cuda.current_stream())            # the inputs were produced on the caller's stream
             with torch.cuda.stream(st), torch.no_grad():
-                x.record_stream(st)
+                for x in inputs:
+                    x.record_stream(st)
                 if self.front_end is not None:
                     fft_num, hop, window = self.front_end
-                    x = stft_compress(x, fft_num, hop, window)
-                if x.ndim == 4:
-                    x = x.unsqueeze(-2)
-                if x.ndim != 5 or x.shape[-1] != 2 or x.shape[-2] != net.M:
-                    raise ValueError(f"expected (B,T,F,{net.M},2), got {tuple(x.shape)}")
-                B, T, F, M, _ = x.shape
-                xin = x.detach().to(torch.float32).contiguous()
-                bound = self._bound(slot, B, T, F, x.device)
-                if net.use_graph and bound.capture((B, T, F, M, 2), (B, 2, T, F)):
-                    bound.static_in.copy_(xin, non_blocking=True)
-                    bound.graph.replay()
-                    out = bound.static_out.clone()
-                else:
-                    out = torch.empty((B, 2, T, F), dtype=torch.float32, device=x.device)
-                    bound.bind(xin.data_ptr(), out.data_ptr())
-                    bound.run(st.cuda_stream)
-                if net.topo_type == "miso":
-                    out = out.sum(dim=-1)
+                    inputs = (stft_compress(inputs[0], fft_num, hop, window),) + tuple(inputs[1:])
+                rep = self._replicas[slot]
+                if rep is not self.model:
+                    _sync_knobs(self.model, rep)                   # precision / use_graph / train-eval follow the model
+                out = rep(*inputs)
                 ev = torch.cuda.Event()
                 ev.record(st)
-            self._pending.append((out, ev, xin))
+            self._pending.append((out, ev, inputs))
 
-    def collect(self) -> torch.Tensor:
+    def collect(self):
         """The oldest outstanding result; the caller's current stream is ordered behind its computation."""
         if not self._pending:
             raise RuntimeError("nothing outstanding")
         out, ev, _ = self._pending.pop(0)
-        cur = torch.cuda.current_stream(out.device)
+        first = next(self._tensors(out))
+        cur = torch.cuda.current_stream(first.device)
         cur.wait_event(ev)
-        out.record_stream(cur)
+        for t in self._tensors(out):
+            t.record_stream(cur)
         return out
 
     def map(self, batches):
@@ -555,7 +582,7 @@ class Pipeline:
         for x in batches:
             if self.outstanding == self.depth:
                 yield self.collect()
-            self.submit(x)
+            self.submit(*(x if isinstance(x, (tuple, list)) else (x,)))
         while self._pending:
             yield self.collect()
 

@@ -769,6 +769,7 @@ class GagLowering(Lowering):
     'in2' = pre_x, both planar (B,2,T,F); 'out' = the q stage outputs [q][B][2][T][F] (the reference's
     (B,2,F,T) tensors are permuted views of it).  Every 1-D tensor is [B][T][1][C]."""
     spec_fn = staticmethod(gag_param_specs)
+    parallel_chains = True        # False: the three S-TCM chains of a stage back to back (no graph branches)
 
     def tcm1(self, pre: str, x: Act, dilation: int) -> Act:
         """GaGNet's single-branch SqueezedTCM (GaGNet.py:303-327): in_conv -> PReLU/norm/dilated conv ->
@@ -867,19 +868,23 @@ class GagLowering(Lowering):
             # branches (each S-TCM launch fills less than half of the chip on its own)
             xg0 = self.gated_in(gl, feat, pre, feat_perm)
             xz = self.gated_in(gz, feat, pre, feat_perm)
-            branches = [1] if cfg.is_squeezed else [1, 2]
-            self.mark("fork", branches)
+            branches = ([1] if cfg.is_squeezed else [1, 2]) if self.parallel_chains else []
+            if branches:
+                self.mark("fork", branches)
             gain = self.linear(f"{gl}.linear_g.0", self.chain(f"{gl}.tcn_g", xg0))
-            self.set_lane(1)
+            if branches:
+                self.set_lane(1)
             if cfg.is_squeezed:
                 xr = self.chain(f"{gz}.tcm_ri", xz)
                 lr, li = self.linear(f"{gz}.linear_r", xr), self.linear(f"{gz}.linear_i", xr)
             else:
                 lr = self.linear(f"{gz}.linear_r", self.chain(f"{gz}.tcm_r", xz))
-                self.set_lane(2)
+                if branches:
+                    self.set_lane(2)
                 li = self.linear(f"{gz}.linear_i", self.chain(f"{gz}.tcm_i", xz))
-            self.set_lane(0)
-            self.mark("join", branches)
+            if branches:
+                self.set_lane(0)
+                self.mark("join", branches)
             nxt = Act(self.alloc(B * T * GAG_PRE_LD), 1, GAG_PRE_LD, raw=True)
             self.ops.append(GagCrmOp(pre=pre.ref, g=gain, r=lr, i=li, pre_out=nxt.ref, planar=Ref("out", gi * B * 2 * T * F),
                                      B=B, T=T, F=F, act=act, win=bool(self.chunk), name=f"gags.{gi}.crm"))
@@ -889,9 +894,13 @@ class GagLowering(Lowering):
 
 
 def lower(cfg, params: Dict[str, np.ndarray], B: int, T: int, F: int = 161,
-          dump_bfw: bool = False, precision: str = "f32", chunk: int = 0) -> Program:
+          dump_bfw: bool = False, precision: str = "f32", chunk: int = 0, parallel_chains: bool = True) -> Program:
     """chunk > 0 lowers the streaming form: T is then the longest utterance the resident activations can
-    hold and every op advances `chunk` frames per replay."""
+    hold and every op advances `chunk` frames per replay.  parallel_chains (GaGNet): the glance / gaze S-TCM
+    chains of a stage as parallel graph branches (best latency of one batch) or back to back (best when
+    several batches are in flight anyway, eabnet_amd.Pipeline)."""
     if isinstance(cfg, GagConfig):
-        return GagLowering(cfg, params, B, T, F, False, precision, chunk).build()
+        low = GagLowering(cfg, params, B, T, F, False, precision, chunk)
+        low.parallel_chains = parallel_chains
+        return low.build()
     return Lowering(cfg, params, B, T, F, dump_bfw, precision, chunk).build()

@@ -868,3 +868,27 @@ def test_pipeline_executor_is_bit_identical_and_ordered(dev, depth, front):
     assert not torch.equal(want2, want[0])
     pipe.submit(batches[0])
     assert torch.equal(pipe.collect(), want2)
+
+
+def test_pipeline_executor_two_stage_model(dev):
+    """The same executor over EaBNetWithPostNet (dictionary outputs, two programs per replica) and over GaGNet
+    (two inputs), f16x3 knob set after construction."""
+    import eabnet_amd
+    net = eabnet_amd.make_eabnet_with_postnet(_postnet_args(4, p=1, q=1, gagnet_p=1, gagnet_q=2, gagnet_dilas=[1, 2]))
+    specs = {**{"eabnet." + k: s for k, s in net.eabnet._specs.items()}, **{"postnet." + k: s for k, s in net.postnet._specs.items()}}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in paramgen.make_params(specs, 250).items()}, strict=True)
+    net = net.to(dev).eval()
+    pipe = eabnet_amd.Pipeline(net, depth=2)
+    net.eabnet.precision = net.postnet.precision = "f16x3"
+    xs = [torch.from_numpy(paramgen.make_spec_input(1, 15, 161, 4, 260 + i)).to(dev) for i in range(4)]
+    with torch.no_grad():
+        want = [{k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in net(x).items()} for x in xs]
+    for got, w in zip(pipe.map(xs), want):
+        assert torch.equal(got["esti_stft"], w["esti_stft"]) and torch.equal(got["esti0_stft"], w["esti0_stft"])
+        assert all(torch.equal(a, b) for a, b in zip(got["esti1_stft_list"], w["esti1_stft_list"]))
+    gp = eabnet_amd.Pipeline(net.postnet, depth=2)
+    pairs = [(_planar(1, 15, 270 + i).to(dev), _planar(1, 15, 280 + i).to(dev)) for i in range(3)]
+    with torch.no_grad():
+        wg = [[t.clone() for t in net.postnet(a, b)] for a, b in pairs]
+    for got, w in zip(gp.map(pairs), wg):
+        assert all(torch.equal(a, b) for a, b in zip(got, w))
