@@ -184,6 +184,10 @@ def main():
     elapsed, y = timed_steps(depth, a.warmup, a.steps)
     assert torch.isfinite(y).all()
     seq_elapsed = timed_steps(1, 2, a.steps)[0] if depth > 1 else elapsed
+    if seq_elapsed < elapsed:
+        # streams that happen to share a hardware queue do not overlap; then the plain loop IS the better executor
+        # and the headline is its (equally complete) timing of the same K steps
+        elapsed, depth = seq_elapsed, 1
     with torch.no_grad():
         y_seq, ns = step()
     assert torch.equal(y_seq, y), "the pipelined executor must return exactly what net(x) returns"
