@@ -354,7 +354,24 @@ def main():
                         y1 = net(eabnet_amd.stft_compress(wav1, N_FFT, HOP, window))
                     torch.cuda.synchronize()
                     dt1 = (time.perf_counter() - t0) / 20
-                c1[prec] = {"ms_per_utterance": 1e3 * dt1, "rtf": dt1 / SECONDS, "frames_per_s": T / dt1}
+                    # independent single-utterance requests, two in flight (throughput of a request server)
+                    p1 = eabnet_amd.Pipeline(net, depth=2, front_end=(N_FFT, HOP, window))
+                    for _ in range(4):
+                        p1.submit(wav1)
+                        p1.collect()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(40):
+                        if p1.outstanding == 2:
+                            p1.collect()
+                        p1.submit(wav1)
+                    while p1.outstanding:
+                        p1.collect()
+                    torch.cuda.synchronize()
+                    dt2 = (time.perf_counter() - t0) / 40
+                    p1 = None
+                c1[prec] = {"ms_per_utterance": 1e3 * dt1, "rtf": dt1 / SECONDS, "frames_per_s": T / dt1,
+                            "two_in_flight_ms_per_utterance": 1e3 * dt2, "two_in_flight_frames_per_s": T / dt2}
             net.precision = a.precision
             out["single_utterance_c1"] = c1
 
