@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 echo "[prof] kernel trace" | tee $OUT/log.txt
 timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- \
-    python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline $BENCH_ARGS >> $OUT/log.txt 2>&1
+    python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --pipeline 1 --no-cpu-baseline --no-roofline $BENCH_ARGS >> $OUT/log.txt 2>&1
 echo "[prof] trace rc=$?" | tee -a $OUT/log.txt
 ls -R $OUT/trace | head -20 >> $OUT/log.txt
 if [ -n "$2" ]; then
@@ -17,7 +17,7 @@ if [ -n "$2" ]; then
   for grp in $2; do
     i=$((i+1))
     timeout -k 10 420 rocprofv3 --kernel-trace --pmc ${grp//,/ } --output-format csv -d $OUT/pmc$i -o pmc -- \
-      python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline $BENCH_ARGS >> $OUT/log.txt 2>&1
+      python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --pipeline 1 --no-cpu-baseline --no-roofline $BENCH_ARGS >> $OUT/log.txt 2>&1
     echo "[prof] pmc$i ($grp) rc=$?" | tee -a $OUT/log.txt
   done
 fi
