@@ -140,8 +140,12 @@ def main():
 
     rank, world, local = dist.env_rank()
     if world == 1 and a.gpus > 1:
-        sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                 "--master-addr 127.0.0.1 bench.py --gpus N")
+        # no launcher around us: start the ranks ourselves, as the reference's mp.spawn does
+        # (train_distributed.py:363-366) -- fresh processes, one GPU each, before this one makes any GPU call;
+        # rank 0's JSON line is the job's.  (Under torch.distributed.run WORLD_SIZE is set and this is skipped.)
+        sys.exit(dist.launch_local(a.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+    if world != a.gpus:
+        sys.exit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     is_dist = dist.init("nccl", dev)                        # RCCL; only barriers and one scalar MAX
@@ -184,16 +188,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
+        per_rank.clear()
+        per_rank.extend(dist.gather_over_ranks(el, dev))
         return dist.max_over_ranks(el, dev), yy
 
+    per_rank: list = []                   # elapsed seconds of every rank in the most recent timed region
     depth = max(1, a.pipeline)
     elapsed, y = timed_steps(depth, a.warmup, a.steps)
+    rank_elapsed = list(per_rank)
     assert torch.isfinite(y).all()
     seq_elapsed = timed_steps(1, 2, a.steps)[0] if depth > 1 else elapsed
     if seq_elapsed < elapsed:
         # streams that happen to share a hardware queue do not overlap; then the plain loop IS the better executor
         # and the headline is its (equally complete) timing of the same K steps
-        elapsed, depth = seq_elapsed, 1
+        elapsed, depth, rank_elapsed = seq_elapsed, 1, list(per_rank)
     with torch.no_grad():
         y_seq, ns = step()
     assert torch.equal(y_seq, y), "the pipelined executor must return exactly what net(x) returns"
@@ -214,6 +222,10 @@ def main():
                                        "a step; the headline keeps `pipeline_depth` batches in flight on separate HIP "
                                        "streams (eabnet_amd.Pipeline), results bit-identical"},
         "rtf_per_utterance": elapsed / a.steps / (B_PER_GPU * SECONDS),
+        "ranks": {"world_size_seen_by_torch_distributed": torch.distributed.get_world_size() if is_dist else 1,
+                  "backend": "nccl (RCCL)" if is_dist else "none (single process)",
+                  "frames_per_s_per_rank": [B_PER_GPU * T * a.steps / e for e in rank_elapsed],
+                  "min": B_PER_GPU * T * a.steps / max(rank_elapsed), "max": B_PER_GPU * T * a.steps / min(rank_elapsed)},
         "gflop_per_step_algorithmic": 2e-9 * mac_per_frame(MICS) * B_PER_GPU * T,
     }
 
@@ -224,14 +236,22 @@ def main():
         net.precision = "f16x3"
         el2, y = timed_steps(depth, max(2, a.warmup), a.steps)
         el2_seq = timed_steps(1, 2, a.steps)[0] if depth > 1 else el2
+        with torch.no_grad():
+            y_seq2, _ = step()                  # the same batch through a direct (unpipelined) call
+        same = bool(torch.equal(y_seq2, y))
         dev_rel = float((y - y32).abs().max() / y32.abs().max())
-        out["alt_precision"] = {
-            "dtype": "f32 storage/accumulate, products as 3 x f16 MFMA on fp16 hi+lo splits (f16x3)",
-            "value": frames / el2, "unit": "frames/s", "ms_per_step": 1e3 * el2 / a.steps,
-            "one_step_at_a_time_ms_per_step": 1e3 * el2_seq / a.steps,
-            "max_rel_deviation_from_f32_mode": dev_rel,
-            "note": "same 1e-4 parity tests as the f32 mode (tests/test_hip_parity.py); end-to-end error vs an "
-                    "fp64 reference 3e-6 (f32 mode: 2e-6)"}
+        if same and dev_rel < 1e-4:
+            out["alt_precision"] = {
+                "dtype": "f32 storage/accumulate, products as 3 x f16 MFMA on fp16 hi+lo splits (f16x3)",
+                "value": frames / el2, "unit": "frames/s", "ms_per_step": 1e3 * el2 / a.steps,
+                "one_step_at_a_time_ms_per_step": 1e3 * el2_seq / a.steps,
+                "max_rel_deviation_from_f32_mode": dev_rel, "pipelined_equals_direct": same,
+                "note": "checked in this run: pipelined output == direct output bit for bit and within 1e-4 of the "
+                        "f32 mode's output on the same batch; parity tests: tests/test_hip_parity.py"}
+        else:
+            # an unverified number is not reported (round-1 shipped one: a cross-wave LDS race in lstm64_h3_kernel)
+            out["alt_precision_failed"] = {"pipelined_equals_direct": same, "max_rel_deviation_from_f32_mode": dev_rel,
+                                           "note": "f16x3 output failed its in-bench check; no throughput reported"}
         net.precision = "f32"
         with torch.no_grad():
             y, ns = step()                      # rebind the f32 program for the instrumented replay

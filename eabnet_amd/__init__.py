@@ -10,8 +10,9 @@ error, never a fallback.
 from .spec import GagConfig, NetConfig, gag_param_specs, param_specs  # noqa: F401
 from .model import (EaBNet, GaGNet, EaBNetWithPostNet, make_gag_net, make_eabnet_with_postnet,  # noqa: F401
                     StreamingEnhancer, Pipeline, prepare_data, stft_compress, istft, filter_and_sum, numParams, com_mag_mse_loss,
-                    stagewise_com_mag_mse_loss)
+                    stagewise_com_mag_mse_loss, eabnet_with_postnet_loss)
 
 __all__ = ["EaBNet", "GaGNet", "EaBNetWithPostNet", "make_gag_net", "make_eabnet_with_postnet", "StreamingEnhancer", "Pipeline", "prepare_data",
            "stft_compress", "istft", "filter_and_sum", "numParams", "com_mag_mse_loss", "stagewise_com_mag_mse_loss",
+           "eabnet_with_postnet_loss",
            "NetConfig", "GagConfig", "param_specs", "gag_param_specs"]

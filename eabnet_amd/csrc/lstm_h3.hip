@@ -163,7 +163,11 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = accx[g];
         mma(hh, hl, whh, whl, acc);
-        norm_store(xq, cur);                            // x_{t+2} replaces x_t; VALU work beside the MFMAs
+        // x_{t+1} fragments are taken BEFORE this step's barrier (as csrc/lstm.hip does): xs[nxt] is overwritten
+        // with x_{t+3} by the next step's norm_store, which a wave that runs ahead reaches without passing
+        // another barrier -- reading it behind the barrier was a cross-wave write-after-read race
+        frags(xs[nxt], xh, xl);
+        norm_store(xq, cur);                            // x_{t+2} replaces x_t (its fragments were read one barrier ago)
         __builtin_amdgcn_sched_barrier(0);
         char* hrow = &hs[nxt][hcol];
 #pragma unroll
@@ -187,7 +191,6 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- input half of the next step: independent of the recurrence, covers the LDS round trip
-        frags(xs[nxt], xh, xl);
 #pragma unroll
         for (int g = 0; g < 4; ++g) accx[g] = f32x4{bia[g], bia[g], bia[g], bia[g]};
         mma(xh, xl, wxh, wxl, accx);

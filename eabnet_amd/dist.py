@@ -10,7 +10,10 @@ process per GPU; backend "nccl" is RCCL on ROCm, "gloo" is used by the CPU tests
 from __future__ import annotations
 
 import os
-from typing import Tuple
+import socket
+import subprocess
+import sys
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as td
@@ -60,3 +63,55 @@ def mean_over_ranks(x: torch.Tensor) -> torch.Tensor:
 def barrier() -> None:
     if td.is_available() and td.is_initialized():
         td.barrier()
+
+
+def gather_over_ranks(value: float, device="cpu") -> List[float]:
+    """The value of every rank, in rank order (a list of one without a process group)."""
+    if not (td.is_available() and td.is_initialized()):
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(td.get_world_size())]
+    td.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_local(n: int, argv: Sequence[str], env: Optional[dict] = None, timeout: Optional[float] = None) -> int:
+    """Start ``n`` fresh copies of ``python argv...`` on this node, one per GPU, as the reference's
+    ``torch.multiprocessing.spawn(main, nprocs=world_size)`` does (train_distributed.py:363-366): RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in the environment (what
+    ``torch.distributed.run`` would set).  The caller must not have touched the GPU: the children are new
+    processes, nothing is forked or exec'd from an initialised one.  Rank 0 inherits stdout (its one JSON
+    line is the job's); every rank inherits stderr.  Returns the worst exit code; a failing rank ends the rest."""
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, *argv], env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    import time
+    t0, rc = time.monotonic(), 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0:
+                rc = rc or code
+                for q in alive:                      # one rank failed: the others would wait at a barrier forever
+                    q.terminate()
+        if timeout is not None and time.monotonic() - t0 > timeout:
+            for q in alive:
+                q.kill()
+            return rc or 124
+        time.sleep(0.05)
+    return rc

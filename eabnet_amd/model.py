@@ -94,6 +94,16 @@ class _Bound:
         self.static_out = None
         self.graph_failed = False
 
+    def __del__(self):
+        # The arenas may have been used on streams other than the one they were allocated under (Pipeline slot
+        # streams, hipGraph replays): the caching allocator would hand the blocks out again while such work is
+        # still queued.  Dropping a bound program is rare (shape / precision change), so drain the device first.
+        try:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize(self.device)
+        except Exception:                                 # noqa: BLE001 - interpreter shutdown
+            pass
+
     def capture(self, in_shape, out_shape, in2_shape=None) -> bool:
         """Capture the whole op program into a hipGraph bound to static in/out buffers.  Replaying it
         costs one graph launch instead of ~250 kernel launches enqueued by the host.  Returns False
@@ -265,14 +275,22 @@ class _HipModule(nn.Module):
         self.precision = "f32"
 
     def _param_fingerprint(self) -> tuple:
-        """Cheap change detector for the packed weights (runs on every forward): in-place updates bump a
-        tensor's version counter, a device move or re-assignment changes storage addresses.  The tensor list
-        is cached -- walking the ~800-node module tree costs more than the rest of the host side of a step."""
-        ts = self.__dict__.get("_tensor_list")
-        if ts is None or len(ts) != len(self._specs):
-            ts = list(self.parameters()) + list(self.buffers())
-            self.__dict__["_tensor_list"] = ts
-        return (ts[0].data_ptr(), ts[-1].data_ptr(), sum(t._version for t in ts))
+        """Change detector for the packed weights (runs on every forward).  Every parameter / buffer slot
+        contributes (storage address, version counter): in-place updates bump the version, ``.data =``
+        re-assignment, a device move or ``load_state_dict(assign=True)`` change the address or the object in the
+        slot.  The slot list (owning module, name) is cached -- walking the ~800-node module tree costs more
+        than the rest of the host side of a step; looking the ~500 slots up does not."""
+        slots = self.__dict__.get("_slot_list")
+        if slots is None:
+            slots = []
+            for mod in self.modules():
+                slots += [(mod._parameters, n) for n in mod._parameters] + [(mod._buffers, n) for n in mod._buffers]
+            self.__dict__["_slot_list"] = slots
+        fp = []
+        for d, n in slots:
+            t = d[n]
+            fp.append((t.data_ptr(), t._version))
+        return tuple(fp)
 
     def _numpy_params(self) -> Dict[str, np.ndarray]:
         sd = self.state_dict()
@@ -465,7 +483,7 @@ def _replica(module: nn.Module) -> nn.Module:
     rep._modules = {k: (_replica(v) if v is not None else None) for k, v in module._modules.items()}
     if isinstance(rep, _HipModule):
         rep._bound, rep._packed_version = {}, {}
-        rep.__dict__.pop("_tensor_list", None)
+        rep.__dict__.pop("_slot_list", None)
     return rep
 
 
@@ -578,6 +596,7 @@ class Pipeline:
         for attempt in range(tries):
             if attempt > 0 or not self._streams:
                 with torch.cuda.device(device):
+                    torch.cuda.synchronize(device)
                     self._streams = [torch.cuda.Stream(device=device) for _ in range(self.depth)]
             for _ in range(self.depth + 1):                  # programs lowered / captured, caches warm
                 self.submit(*inputs)
@@ -993,3 +1012,11 @@ def stagewise_com_mag_mse_loss(esti_list, label: torch.Tensor, frame_list) -> to
         loss1 = loss1 + alpha * (((e - label) ** 2.0) * com_mask).sum() / com_mask.sum()
         loss2 = loss2 + alpha * (((torch.norm(e, dim=1) - mag_label) ** 2.0) * mask).sum() / mask.sum()
     return 0.5 * (loss1 + loss2)
+
+
+def eabnet_with_postnet_loss(output: dict, label: torch.Tensor, frame_list) -> dict:
+    """Reference EaBNet.py:642-650 (called at train_distributed.py:225): the beam-former's loss on
+    ``esti0_stft`` plus the stage-wise loss of the post-filter estimates; label (B,2,T,F)."""
+    loss0 = com_mag_mse_loss(output["esti0_stft"], label, frame_list)
+    loss1 = stagewise_com_mag_mse_loss(output["esti1_stft_list"], label.permute(0, 1, 3, 2), frame_list)
+    return {"eabnet": loss0, "postnet": loss1, "final": loss0 + loss1}

@@ -289,9 +289,27 @@ def main_blocks():
         json.dump(recipes, f)
 
 
+def main_losses():
+    """eabnet_with_postnet_loss (EaBNet.py:642-650, called at train_distributed.py:225) on the two-stage
+    fixture's reference outputs."""
+    from EaBNet import eabnet_with_postnet_loss as ref_two_stage_loss
+    g = np.load(os.path.join(HERE, "postnet_M4_T12.npz"))
+    output = {"esti0_stft": torch.from_numpy(g["esti0"]),
+              "esti1_stft_list": [torch.from_numpy(g[f"stage{j}"]) for j in range(3)]}
+    label = torch.from_numpy(paramgen.make_spec_input(1, 12, 161, 1, 810)[..., 0, :]).permute(0, 3, 1, 2).contiguous()
+    arrs = {"label_seed": 810}
+    for tag, frames in (("full", [12]),):        # (the reference's pad_sequence masks need one full-length utterance per batch)
+        l = ref_two_stage_loss(output, label, frames)
+        for k, v in l.items():
+            arrs[f"{tag}/{k}"] = v.numpy()
+    save("loss_postnet.npz", **arrs)
+
+
 if __name__ == "__main__":
     with torch.no_grad():
-        if sys.argv[1:] == ["blocks"]:
+        if sys.argv[1:] == ["losses"]:
+            main_losses()
+        elif sys.argv[1:] == ["blocks"]:
             main_blocks()
         elif sys.argv[1:] == ["gagnet"]:
             main_gagnet()
@@ -305,3 +323,4 @@ if __name__ == "__main__":
             main_istft()
             main_gagnet()
             main_blocks()
+            main_losses()

@@ -216,3 +216,54 @@ def test_two_stage_wrapper_keys_and_output_dictionary(monkeypatch):
     assert not any(p.requires_grad for p in net.eabnet.parameters())
     with pytest.raises(eabnet_amd._lib.EabError):      # frozen beam-former = inference = HIP program: no CPU fallback
         net(torch.randn(1, 6, 161, 3, 2))
+
+
+def test_param_fingerprint_sees_every_kind_of_weight_change():
+    """The packed-weight cache key (model._param_fingerprint) must change for an in-place update, a ``.data =``
+    re-assignment of a MIDDLE tensor, ``load_state_dict(assign=True)`` and a dtype round trip of one
+    submodule -- and replicas (eabnet_amd.Pipeline) must see the same changes."""
+    import torch
+    import eabnet_amd
+    from eabnet_amd.model import _replica
+    net = eabnet_amd.EaBNet(M=2, p=1, q=1)
+    rep = _replica(net)
+    names = [n for n, _ in net.named_parameters()]
+    mid = names[len(names) // 2]
+    seen = {net._param_fingerprint()}
+
+    def changed():
+        fp, fr = net._param_fingerprint(), rep._param_fingerprint()
+        assert fp == fr, "replica and model disagree"
+        new = fp not in seen
+        seen.add(fp)
+        return new
+
+    assert not changed()
+    with torch.no_grad():
+        net.get_parameter(mid).mul_(1.5)                              # in place
+    assert changed()
+    p = net.get_parameter(mid)
+    p.data = p.data.clone()                                           # re-assignment, version counter untouched
+    assert changed()
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net.load_state_dict(sd, strict=True, assign=True)                 # new Parameter objects in every slot
+    assert changed()
+    net.stcns.double().float()                                        # dtype round trip of one submodule
+    assert changed()
+    assert not changed()
+
+
+def test_two_stage_loss_matches_reference_value():
+    """eabnet_with_postnet_loss (reference EaBNet.py:642-650) on CPU tensors against the reference's own value."""
+    import numpy as np
+    import torch
+    import eabnet_amd
+    import paramgen
+    gd = os.path.join(ROOT, "tests", "golden")
+    g, gl = np.load(os.path.join(gd, "postnet_M4_T12.npz")), np.load(os.path.join(gd, "loss_postnet.npz"))
+    output = {"esti0_stft": torch.from_numpy(g["esti0"]), "esti1_stft_list": [torch.from_numpy(g[f"stage{j}"]) for j in range(3)]}
+    label = torch.from_numpy(paramgen.make_spec_input(1, 12, 161, 1, int(gl["label_seed"]))[..., 0, :]).permute(0, 3, 1, 2).contiguous()
+    l = eabnet_amd.eabnet_with_postnet_loss(output, label, [12])
+    assert set(l) == {"eabnet", "postnet", "final"}
+    for k in l:
+        assert abs(float(l[k]) - float(gl[f"full/{k}"])) <= 1e-5 * abs(float(gl[f"full/{k}"])), k

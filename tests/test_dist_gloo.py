@@ -121,3 +121,24 @@ def test_two_rank_ddp_training_step():
     assert l0 == l1 and all(np.isfinite(l0))          # the averaged loss is the same number on both ranks
     assert abs(g0 - g1) <= 1e-9 * max(g0, 1.0)        # all-reduced gradients are identical
     assert abs(w0 - w1) <= 1e-9 * max(abs(w0), 1.0)   # so are the updated parameters
+
+
+@pytest.mark.timeout(300)
+def test_self_launcher_two_ranks():
+    """bench.py --gpus N without torchrun: dist.launch_local starts N fresh processes with the
+    torch.distributed.run environment; only rank 0's line reaches stdout; a failing rank fails the job."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path.insert(0, %r); from eabnet_amd import dist; "
+            "sys.exit(dist.launch_local(2, [%r] + sys.argv[1:], timeout=240))") % (os.path.dirname(here), os.path.join(here, "_launch_worker.py"))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip() and not l.startswith("[Gloo]")]   # gloo's own banner
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out == {"world": 2, "local": 0, "per_rank": [10.0, 11.0], "max": 11.0, "master": "127.0.0.1"}
+    r = subprocess.run([sys.executable, "-c", code, "fail"], capture_output=True, text=True, env=env, timeout=280)
+    assert r.returncode == 3 and not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -179,6 +179,12 @@ def test_e2e_taps_fixture(dev):
     for ref_name, mine in names.items():
         got = bound.view(bound.prog.taps[mine]).permute(0, 3, 1, 2).cpu().numpy()
         assert_close(got, g["tap/" + ref_name], TOL_HIP, ref_name)
+    # S-TCM output: reference layout (B, 256, T) with channel c*4+f; here [B][T][f*64+c]
+    t0 = bound.view(bound.prog.taps["stcns.0.0"]).reshape(1, 12, 4, 64).permute(0, 3, 2, 1).reshape(1, 256, 12)
+    assert_close(t0.cpu().numpy(), g["tap/stcns.0.0"], TOL_HIP, "stcns.0.0")
+    for nm in ("rnn1", "rnn2"):
+        h = bound.view(bound.prog.taps[f"bf_map.{nm}"]).permute(0, 2, 1, 3).reshape(161, 12, 64)
+        assert_close(h.cpu().numpy(), g["tap/" + nm], TOL_HIP, nm)
     assert_close(bound.view(bound.prog.taps["bf_w"]).reshape(1, 12, 161, 8, 2).cpu().numpy(), g["tap/bf_w"], TOL_HIP, "bf_w")
     assert_close(y.cpu().numpy(), g["out"], TOL_HIP, "out")
 
@@ -219,7 +225,8 @@ def test_c1_full_size_wave_to_output(dev):
     print(f"C1 parity: max-rel {m:.2e}, l2-rel {l2:.2e}")
 
 
-def test_c2_batch16_properties(dev):
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_c2_batch16_properties(dev, precision):
     """BASELINE config C2/C3 size (16 x 4 s x 8 mics).  The oracle needs minutes at
     this size, so use what the path guarantees: utterances are independent (IN /
     LN / LSTM are per sample), so (a) slot 0 carries the C1 fixture input and must
@@ -228,6 +235,7 @@ def test_c2_batch16_properties(dev):
     import eabnet_amd
     g = load("c1_M8_T401.npz")
     net = _model(8, int(g["param_seed"]), dev)
+    net.precision = precision
     wav = torch.from_numpy(paramgen.make_wave(16, 8, 64000, 77))
     wav[0] = torch.from_numpy(paramgen.make_wave(1, 8, 64000, int(g["wave_seed"])))[0]
     wav[5] = wav[0]
@@ -899,3 +907,112 @@ def test_pipeline_executor_two_stage_model(dev):
         wg = [[t.clone() for t in net.postnet(a, b)] for a, b in pairs]
     for got, w in zip(gp.map(pairs), wg):
         assert all(torch.equal(a, b) for a, b in zip(got, w))
+
+
+
+# ------------------------------------------------------------------ C2 size: nothing stale is ever read
+def _c2_batch(dev):
+    g = load("c1_M8_T401.npz")
+    wav = torch.from_numpy(paramgen.make_wave(16, 8, 64000, 78))
+    wav[0] = torch.from_numpy(paramgen.make_wave(1, 8, 64000, int(g["wave_seed"])))[0]
+    wav[9] = wav[0]
+    return g, wav.to(dev)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_c2_size_nan_poisoned_workspace(dev, precision):
+    """B = 16, T = 401 (the bench's shape): with the activation arena, the static boundary buffers and the output
+    NaN-filled before a run, the result is finite and bit-identical -- every kernel (tile tails, halo cells,
+    statistics partials, LSTM windows) reads only what this run wrote.  Graph replay and direct launches."""
+    import eabnet_amd
+    g, wav = _c2_batch(dev)
+    net = _model(8, int(g["param_seed"]), dev)
+    net.precision = precision
+    with torch.no_grad():
+        ns = eabnet_amd.stft_compress(wav, 320, 160, torch.hann_window(320))
+        ref = net(ns).clone()
+        bound = net._last[0]
+        assert bound.graph is not None
+        for _ in range(2):
+            bound.acts.fill_(float("nan"))
+            bound.static_out.fill_(float("nan"))
+            bound.static_in.fill_(float("nan"))
+            y = net(ns)
+            assert torch.isfinite(y).all() and torch.equal(y, ref)
+        net.use_graph = False
+        y0 = net(ns).clone()
+        b2 = net._last[0]
+        b2.acts.fill_(float("nan"))
+        y1 = net(ns)
+        assert torch.isfinite(y1).all() and torch.equal(y1, y0) and torch.equal(y0, ref)
+    assert_close(ref[0:1].cpu().numpy(), g["out"], TOL_HIP, "slot 0 vs reference fixture")
+    assert torch.equal(ref[0], ref[9])
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_c2_size_pipelined_equals_direct_after_other_precision(dev, precision):
+    """The round-1 failure mode: a Pipeline of the OTHER precision ran first and was dropped (its arenas went back
+    to the allocator, the process-wide slot streams stay), then this precision runs pipelined with two batches in
+    flight for many steps -- every collected result must equal the direct call bit for bit."""
+    import eabnet_amd
+    g, wav = _c2_batch(dev)
+    win = torch.hann_window(320)
+    net = _model(8, int(g["param_seed"]), dev)
+    other = "f16x3" if precision == "f32" else "f32"
+    with torch.no_grad():
+        net.precision = other
+        p0 = eabnet_amd.Pipeline(net, depth=2, front_end=(320, 160, win))
+        p0.calibrate(wav, tries=2, steps=3)
+        for _ in range(3):
+            p0.submit(wav)
+            p0.collect()
+        p0 = None
+        net.precision = precision
+        want = net(eabnet_amd.stft_compress(wav, 320, 160, win)).clone()
+        pipe = eabnet_amd.Pipeline(net, depth=2, front_end=(320, 160, win))
+        got = []
+        for _ in range(12):
+            if pipe.outstanding == 2:
+                got.append(pipe.collect())
+            pipe.submit(wav)
+        while pipe.outstanding:
+            got.append(pipe.collect())
+        torch.cuda.synchronize()
+    bad = [i for i, y in enumerate(got) if not torch.equal(y, want)]
+    assert not bad, f"pipelined results {bad} of {len(got)} differ from the direct call"
+    assert_close(want[0:1].cpu().numpy(), g["out"], TOL_HIP, "slot 0 vs reference fixture")
+
+
+# ------------------------------------------------------------------ BASELINE configs[4] as stated: streaming at M = 16, T = 801
+@pytest.mark.parametrize("chunk", [1, 16])
+def test_streaming_config5_size_equals_offline_and_oracle(dev, chunk):
+    """16 microphones, 8-s utterance (T = 801), BatchNorm norms: the streamed frames equal one offline call bit
+    for bit (chunk 1 = 801 replays; chunk 16 ends in a short chunk), and the offline call matches the oracle."""
+    from oracle import eabnet_oracle as orc
+    kw = dict(norm_type="BN")
+    M, T = 16, 801
+    net = _model(M, 1230, dev, **kw)
+    x = torch.from_numpy(paramgen.make_spec_input(1, T, 161, M, 1231))
+    xd = x.to(dev)
+    with torch.no_grad():
+        off = net(xd)
+    st = net.stream_begin(1, T_max=T, chunk=chunk)
+    y = torch.cat([st.step(xd[:, t:t + chunk]) for t in range(0, T, chunk)], dim=2)
+    assert torch.equal(y, off)
+    if chunk == 16:
+        with torch.no_grad():
+            ref = orc.eabnet_forward(torch_params(M, 1230, **kw), x, fast_lstm=True, **kw)
+        assert_close(off.cpu().numpy(), ref.numpy(), TOL_HIP, "offline BN vs oracle")
+
+
+def test_two_stage_loss_vs_reference_fixture(dev):
+    """eabnet_with_postnet_loss (EaBNet.py:642-650) on the device against the value the reference's own
+    function returned on the two-stage fixture's outputs."""
+    import eabnet_amd
+    g, gl = load("postnet_M4_T12.npz"), load("loss_postnet.npz")
+    output = {"esti0_stft": torch.from_numpy(g["esti0"]).to(dev),
+              "esti1_stft_list": [torch.from_numpy(g[f"stage{j}"]).to(dev) for j in range(3)]}
+    label = torch.from_numpy(paramgen.make_spec_input(1, 12, 161, 1, int(gl["label_seed"]))[..., 0, :]).permute(0, 3, 1, 2).contiguous().to(dev)
+    l = eabnet_amd.eabnet_with_postnet_loss(output, label, [12])
+    for k in ("eabnet", "postnet", "final"):
+        assert abs(float(l[k]) - float(gl[f"full/{k}"])) <= 1e-5 * abs(float(gl[f"full/{k}"])), k
