@@ -206,6 +206,18 @@ def main():
         y_seq, ns = step()
     assert torch.equal(y_seq, y), "the pipelined executor must return exactly what net(x) returns"
 
+    def pipelined_results_all_equal(want, n=8) -> bool:
+        """untimed: every one of n pipelined results (not only the last, which runs while the pipeline drains)
+        equals the direct call's output"""
+        pipe = eabnet_amd.Pipeline(net, depth=max(2, depth), front_end=(N_FFT, HOP, window))
+        ok = True
+        with torch.no_grad():
+            for yy in pipe.map([(wav,)] * n):
+                ok = ok and bool(torch.equal(yy, want))
+        torch.cuda.synchronize()
+        return ok
+    assert pipelined_results_all_equal(y_seq), "a pipelined result differs from the direct call (f32)"
+
     frames = world * B_PER_GPU * T * a.steps
     out = {
         "metric": "enhanced frames/sec (16 kHz, 8-mic) at 1/2/4/8 MI355X; RTF per utterance",
@@ -238,7 +250,7 @@ def main():
         el2_seq = timed_steps(1, 2, a.steps)[0] if depth > 1 else el2
         with torch.no_grad():
             y_seq2, _ = step()                  # the same batch through a direct (unpipelined) call
-        same = bool(torch.equal(y_seq2, y))
+        same = bool(torch.equal(y_seq2, y)) and pipelined_results_all_equal(y_seq2)
         dev_rel = float((y - y32).abs().max() / y32.abs().max())
         if same and dev_rel < 1e-4:
             out["alt_precision"] = {

@@ -160,6 +160,8 @@ __global__ __launch_bounds__(256) void lstm64_kernel(const float* __restrict__ x
     frags(xs[0], xf);
     mma(xf, wx, accx, I0{}, I4{});
     frags(hs[0], hf);
+    // every wave has taken its x_{t_lo} fragments before any wave's first step overwrites xs[0] with x_{t_lo+2}
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     f32x4 xq = load_x(t_lo + 2), xr = load_x(t_lo + 3); // x_{t+2}, x_{t+3}: raw, in registers
 
     for (int t = t_lo; t < t_hi; ++t) {

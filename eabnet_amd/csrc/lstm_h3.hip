@@ -150,6 +150,10 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
     frags(xs[0], xh, xl);
     mma(xh, xl, wxh, wxl, accx);
     frags(hs[0], hh, hl);
+    // every wave has taken its x_0 fragments before any wave's first step overwrites xs[0] with x_2
+    // (a wave that leads by the 24 recurrent MFMAs of step 0 would otherwise clobber rows a slower wave
+    // has not read yet: a cross-wave write-after-read race that shows when other kernels share the CU)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     f32x4 xq = load_x(2), xr = load_x(3);
 
     const int u = wave * 16 + ln;

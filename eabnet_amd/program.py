@@ -745,7 +745,7 @@ class Lowering:
                                    ln_b=self.vec("bf_map.norm.bias") if li == 0 else None, ln_eps=EPS_LN,
                                    wcat=self.W.add(f"{p}#wcat", wcat), bias=self.W.add(f"{p}#bias", bias),
                                    h_out=out, B=B, T=T, F=F, name=p,
-                                   precision=PREC_F16X3 if self.precision == "f16x3" else PREC_F32,
+                                   precision=PREC_F16X3 if os.environ.get("EAB_LSTM_PREC", self.precision) == "f16x3" else PREC_F32,
                                    c_state=self.alloc(B * F * 64) if self.chunk else None, win=bool(self.chunk)))
             self.flops += 2 * B * T * F * 256 * 128
             h = Act(out, F, 64)

@@ -953,34 +953,94 @@ def test_c2_size_nan_poisoned_workspace(dev, precision):
 def test_c2_size_pipelined_equals_direct_after_other_precision(dev, precision):
     """The round-1 failure mode: a Pipeline of the OTHER precision ran first and was dropped (its arenas went back
     to the allocator, the process-wide slot streams stay), then this precision runs pipelined with two batches in
-    flight for many steps -- every collected result must equal the direct call bit for bit."""
+    flight for many steps, a DIFFERENT batch each step (with one repeated batch a stale read returns the right
+    values) -- every collected result must equal the direct call bit for bit.  Root causes found with this test:
+    two cross-wave LDS races in lstm64_h3_kernel, and packed-fp32 VALU results going wrong next to another wave's
+    f16 MFMAs (csrc/Makefile: -packed-fp32-ops; tools/diag_corun.py isolates kernel pairs)."""
     import eabnet_amd
-    g, wav = _c2_batch(dev)
+    g, wav0 = _c2_batch(dev)
+    wavs = [wav0] + [torch.from_numpy(paramgen.make_wave(16, 8, 64000, 79 + i)).to(dev) for i in range(2)]
     win = torch.hann_window(320)
     net = _model(8, int(g["param_seed"]), dev)
     other = "f16x3" if precision == "f32" else "f32"
     with torch.no_grad():
         net.precision = other
         p0 = eabnet_amd.Pipeline(net, depth=2, front_end=(320, 160, win))
-        p0.calibrate(wav, tries=2, steps=3)
+        p0.calibrate(wav0, tries=2, steps=3)
         for _ in range(3):
-            p0.submit(wav)
+            p0.submit(wav0)
             p0.collect()
         p0 = None
         net.precision = precision
-        want = net(eabnet_amd.stft_compress(wav, 320, 160, win)).clone()
-        pipe = eabnet_amd.Pipeline(net, depth=2, front_end=(320, 160, win))
-        got = []
-        for _ in range(12):
-            if pipe.outstanding == 2:
+        wants = [net(eabnet_amd.stft_compress(w, 320, 160, win)).clone() for w in wavs]
+        for use_graph in (True, False):
+            net.use_graph = use_graph
+            pipe = eabnet_amd.Pipeline(net, depth=2, front_end=(320, 160, win))
+            got = []
+            for k in range(14):
+                if pipe.outstanding == 2:
+                    got.append(pipe.collect())
+                pipe.submit(wavs[k % 3])
+            while pipe.outstanding:
                 got.append(pipe.collect())
-            pipe.submit(wav)
-        while pipe.outstanding:
-            got.append(pipe.collect())
+            torch.cuda.synchronize()
+            bad = [(k, int((y != wants[k % 3]).sum())) for k, y in enumerate(got) if not torch.equal(y, wants[k % 3])]
+            assert not bad, f"graph={use_graph}: pipelined results (index, wrong values) {bad} of {len(got)} differ from the direct call"
+    assert_close(wants[0][0:1].cpu().numpy(), g["out"], TOL_HIP, "slot 0 vs reference fixture")
+
+
+def test_kernels_are_unaffected_by_co_running_kernels(dev):
+    """Kernel pairs on two streams (own programs, own arenas): the victim's output must be bit-identical to its
+    solo run while the aggressor loops beside it.  Pairs = every kernel class against the two f16-MFMA-dense
+    kernels that exposed the packed-fp32 fault (lstm64_h3_kernel, the f16x3 patch convolution)."""
+    from eabnet_amd import program as prg
+    from eabnet_amd.model import _Bound
+    from eabnet_amd.spec import NetConfig, param_specs
+    B, T, M = 16, 401, 8
+    cfg = NetConfig(M=M)
+    P = paramgen.make_params(param_specs(cfg), 5)
+
+    def make(seed):
+        prog = prg.lower(cfg, P, B, T, 161, precision="f16x3")
+        bound = _Bound(prog, dev)
+        x = torch.from_numpy(paramgen.make_spec_input(B, T, 161, M, seed)).to(dev)
+        out = torch.empty(B, 2, T, 161, device=dev)
+        bound.bind(x.data_ptr(), out.data_ptr())
+        bound.run(torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
-    bad = [i for i, y in enumerate(got) if not torch.equal(y, want)]
-    assert not bad, f"pipelined results {bad} of {len(got)} differ from the direct call"
-    assert_close(want[0:1].cpu().numpy(), g["out"], TOL_HIP, "slot 0 vs reference fixture")
+        return bound, x, out
+
+    def region(bound, out, op):
+        if op.kind == prg.OP_CONV:
+            return bound.acts[op.dst.off:op.dst.off + op.B * op.T * op.Fout * op.Cout]
+        if op.kind == prg.OP_LSTM64:
+            return bound.acts[op.h_out.off:op.h_out.off + op.B * op.T * op.F * 64]
+        if op.kind == prg.OP_NORM_ACT:
+            return bound.acts[op.out.off:op.out.off + op.B * op.P * op.C]
+        return out.view(-1)
+
+    (ba, _, oa), (bb, _, _) = make(11), make(12)
+    idx = {op.name: k for k, op in enumerate(ba.prog.ops)}
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    reps = 6
+    for v in ("bf_map.w_dnn+fs", "bf_map.rnn2", "de.last_conv.ph0", "en.meta_unet_list.1.enco.0.conv", "de.last_conv",
+              "stcns.0.tcm_list.0.lr_conv"):
+        for a in ("bf_map.rnn2", "de.last_conv.ph0"):
+            reg = region(ba, oa, ba.prog.ops[idx[v]])
+            n = min(reg.numel(), 1 << 23)
+            ref = reg[:n].clone()
+            snaps = torch.empty(reps, n, device=dev)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(s2):
+                for _ in range(reps * 6):
+                    bb.run(s2.cuda_stream, idx[a], 1)
+            with torch.cuda.stream(s1):
+                for r in range(reps):
+                    ba.run(s1.cuda_stream, idx[v], 1)
+                    snaps[r].copy_(reg[:n])
+            torch.cuda.synchronize()
+            bad = [(r, int((snaps[r] != ref).sum())) for r in range(reps) if not torch.equal(snaps[r], ref)]
+            assert not bad, f"{v} next to {a}: runs (index, wrong values) {bad}"
 
 
 # ------------------------------------------------------------------ BASELINE configs[4] as stated: streaming at M = 16, T = 801
