@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libeabnet_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_TAPS = 16
 _fp = C.POINTER(C.c_float)
 
@@ -43,12 +43,24 @@ class ConvDesc(C.Structure):
         ("fin_tiles", C.c_int32), ("fin_nsets", C.c_int32), ("fin_count", C.c_int32), ("fin_eps", C.c_float),
         ("precision", C.c_int32), ("korder", C.c_int32),
         ("win", TimeWindow),
+        ("glu_dump", C.c_void_p),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("dz", C.c_void_p), ("src0", C.c_void_p), ("src1", C.c_void_p), ("dw", C.c_void_p),
+        ("N", C.c_int32), ("C0", C.c_int32), ("C1", C.c_int32), ("Kpad", C.c_int32),
+        ("B", C.c_int32), ("T", C.c_int32), ("Fin", C.c_int32), ("Fz", C.c_int32), ("No", C.c_int32),
+        ("ostride", C.c_int32), ("ophase", C.c_int32), ("istride", C.c_int32),
+        ("ntaps", C.c_int32), ("dt", C.c_int32 * MAX_TAPS), ("ioff", C.c_int32 * MAX_TAPS),
+        ("rows_per_wg", C.c_int32),
     ]
 
 
 class Op(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("i", C.c_int32 * 8), ("f", C.c_float * 2), ("p", C.c_void_p * 10),
-                ("win", TimeWindow), ("conv", ConvDesc)]
+    _fields_ = [("kind", C.c_int32), ("i", C.c_int32 * 8), ("f", C.c_float * 2), ("p", C.c_void_p * 12),
+                ("win", TimeWindow), ("conv", ConvDesc), ("wgrad", WgradDesc)]
 
 
 class EabError(RuntimeError):
@@ -82,6 +94,26 @@ _SIGS = {
     "eab_run_program": (C.c_int, [C.POINTER(Op), C.c_int, C.c_void_p]),
     "eab_sizeof_conv_desc": (C.c_int, []),
     "eab_sizeof_op": (C.c_int, []),
+    "eab_sizeof_wgrad_desc": (C.c_int, []),
+    # training (include/eabnet_hip.h, "Training")
+    "eab_gather_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong, C.c_void_p]),
+    "eab_train_in_stats_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_float] + [C.c_void_p] * 4 + [C.c_void_p]),
+    "eab_in_finalize_mr_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_float] + [C.c_void_p] * 8 + [C.c_void_p]),
+    "eab_train_norm_act_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
+    "eab_train_norm_bwd_f32": (C.c_int, [C.c_void_p] * 12 + [C.c_int] * 4 + [C.c_void_p]),
+    "eab_glu_bwd_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_longlong, C.c_int, C.c_void_p]),
+    "eab_gate_fwd_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_longlong, C.c_void_p]),
+    "eab_gate_bwd_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong, C.c_void_p]),
+    "eab_add_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_longlong, C.c_void_p]),
+    "eab_relu_bwd_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_longlong, C.c_void_p]),
+    "eab_colsum_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_longlong, C.c_int, C.c_void_p]),
+    "eab_filter_sum_bwd_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p]),
+    "eab_filter_sum_ld_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p]),
+    "eab_layernorm64_fwd_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_float] + [C.c_void_p] * 2 + [C.c_longlong, C.c_void_p]),
+    "eab_layernorm64_bwd_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_longlong, C.c_void_p]),
+    "eab_lstm64_train_fwd_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p]),
+    "eab_lstm64_bwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
+    "eab_wgrad_f32": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -106,7 +138,8 @@ def load() -> C.CDLL:
         fn.restype, fn.argtypes = res, args
     if lib.eab_abi_version() != ABI_VERSION:
         raise EabError(f"ABI mismatch: library {lib.eab_abi_version()} != binding {ABI_VERSION}")
-    if lib.eab_sizeof_conv_desc() != C.sizeof(ConvDesc) or lib.eab_sizeof_op() != C.sizeof(Op):
+    if lib.eab_sizeof_conv_desc() != C.sizeof(ConvDesc) or lib.eab_sizeof_op() != C.sizeof(Op) \
+            or lib.eab_sizeof_wgrad_desc() != C.sizeof(WgradDesc):
         raise EabError("struct layout mismatch between include/eabnet_hip.h and eabnet_amd/_lib.py")
     _lib = lib
     return lib

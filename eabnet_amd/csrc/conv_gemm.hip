@@ -689,7 +689,14 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
             for (int c = 0; c < NC; ++c) {
                 float v;
                 if (GLU) {
-                    v = (acc[mi][0][r] + bias_v[0]) * cg_sigmoid(acc[mi][1][r] + bias_v[1]);
+                    const float av = acc[mi][0][r] + bias_v[0], sv = cg_sigmoid(acc[mi][1][r] + bias_v[1]);
+                    v = av * sv;
+                    if (d.glu_dump && rowok[r]) {
+                        // training: value and sigmoid(gate) in the packed column order (what eab_glu_bwd_f32 reads)
+                        float* dp = d.glu_dump + 2 * (out_b + (off[r] >> 2)) + n_blk + wn * 64 + li;
+                        dp[0] = av;
+                        dp[32] = sv;
+                    }
                 } else {
                     v = acc[mi][c][r] + bias_v[c];
                 }

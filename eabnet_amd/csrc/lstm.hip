@@ -52,13 +52,13 @@ __device__ __forceinline__ float ls_row_sum(float v) {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define LS_OOB 0x80000000u   // byte offset outside every legal tensor (host checks < 2^31): loads give 0, stores drop
 
-template <bool LN>
+template <bool LN, bool DUMP>
 __global__ __launch_bounds__(256) void lstm64_kernel(const float* __restrict__ x, const float* __restrict__ ln_g,
                                                      const float* __restrict__ ln_b, float ln_eps,
                                                      const float* __restrict__ wcat, const float* __restrict__ bias,
                                                      float* __restrict__ h_out, int T, int F, int S,
                                                      const int* __restrict__ t_pos, int t_count,
-                                                     float* __restrict__ c_state) {
+                                                     float* __restrict__ c_state, float* __restrict__ gates) {
     __shared__ __attribute__((aligned(16))) float xs[2][LS_SEQ * LS_LD];
     __shared__ __attribute__((aligned(16))) float hs[2][LS_SEQ * LS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -224,6 +224,20 @@ __global__ __launch_bounds__(256) void lstm64_kernel(const float* __restrict__ x
             __builtin_amdgcn_sched_barrier(0);
         }
 
+        if (DUMP) {
+            // training: the activated gates i, f, g, o and the cell state c_t of every (sequence, step), layout
+            // gates[seq][t][5][64] -- what the reverse-time kernel (csrc/lstm_bwd.hip) needs; 64 B per 16 lanes
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int sq = s0 + 4 * lk + r;
+                if (sq < S) {
+                    float* gp = gates + (((size_t)sq * T + t) * 5) * LS_H + u;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) gp[g * LS_H] = ev[4 * g + r];
+                    gp[4 * LS_H] = cst[r];
+                }
+            }
+        }
         // ---- EX: exchange h_t through LDS
 #pragma unroll
         for (int r = 0; r < 4; ++r) hs[nxt][(4 * lk + r) * LS_LD + u] = hval[r];
@@ -461,10 +475,23 @@ extern "C" int eab_lstm64_stream_f32(const float* x, const float* ln_g, const fl
     }
     const int grid = (int)((S + LS_SEQ - 1) / LS_SEQ);
     if (ln_g)
-        hipLaunchKernelGGL(lstm64_kernel<true>, dim3(grid), dim3(256), 0, eab_stream(stream), x, ln_g, ln_b, ln_eps,
-                           wcat, bias, h_out, T, F, (int)S, win.pos, win.count, cs);
+        hipLaunchKernelGGL((lstm64_kernel<true, false>), dim3(grid), dim3(256), 0, eab_stream(stream), x, ln_g, ln_b, ln_eps,
+                           wcat, bias, h_out, T, F, (int)S, win.pos, win.count, cs, nullptr);
     else
-        hipLaunchKernelGGL(lstm64_kernel<false>, dim3(grid), dim3(256), 0, eab_stream(stream), x, ln_g, ln_b, ln_eps,
-                           wcat, bias, h_out, T, F, (int)S, win.pos, win.count, cs);
+        hipLaunchKernelGGL((lstm64_kernel<false, false>), dim3(grid), dim3(256), 0, eab_stream(stream), x, ln_g, ln_b, ln_eps,
+                           wcat, bias, h_out, T, F, (int)S, win.pos, win.count, cs, nullptr);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
+// Training forward: the same layer (no LayerNorm inside: the training program materialises it, its output is an
+// operand of the weight gradient) that also stores the activated gates and cell states, gates [B*F][T][5][64].
+extern "C" int eab_lstm64_train_fwd_f32(const float* x, const float* wcat, const float* bias, float* h_out, float* gates, int B,
+                                        int T, int F, eab_stream_t stream) {
+    EAB_CHECK_ARG(x && wcat && bias && h_out && gates && B > 0 && T > 0 && F > 0);
+    const long long S = (long long)B * F;
+    EAB_CHECK_ARG(S * T * LS_H * 4 < (1ll << 31));
+    const int grid = (int)((S + LS_SEQ - 1) / LS_SEQ);
+    hipLaunchKernelGGL((lstm64_kernel<false, true>), dim3(grid), dim3(256), 0, eab_stream(stream), x, nullptr, nullptr, 0.0f, wcat,
+                       bias, h_out, T, F, (int)S, nullptr, 0, nullptr, gates);
     EAB_RETURN_LAUNCH_STATUS();
 }

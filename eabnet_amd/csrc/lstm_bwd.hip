@@ -1,0 +1,140 @@
+// Backward through time of one LSTM(64->64) layer (what autograd does for nn.LSTM in LSTM_BF, EaBNet.py:610-611,
+// under train_distributed.py:228), persistent over the reversed time axis.
+//
+// Same ownership as the forward kernel (csrc/lstm.hip): one workgroup = 16 sequences for all T steps, wave w =
+// hidden units 16w..16w+15; lane (ln = lane&15, lk = lane>>4) holds unit u = 16w+ln of sequences 4*lk + r.
+//   per step t = T-1 .. 0:
+//     dh  = dh_out[t] + dh_rec                         (upstream gradient + recurrence)
+//     do' = dh * tanh(c_t) * o(1-o)
+//     dc  = dc_carry + dh * o * (1 - tanh(c_t)^2)
+//     di' = dc * g * i(1-i),  dg' = dc * i * (1-g^2),  df' = dc * c_{t-1} * f(1-f),  dc_carry = dc * f
+//     dgates_t (16 x 256, gate-major) -> LDS -> HBM [B][T][F][256] (the operand of dx = dgates W_ih, dW = dgates^T [x | h_{t-1}])
+//     dh_rec  = dgates_t . W_hh  as 64 v_mfma_f32_16x16x4_f32 per wave (K = 256; W_hh^T stationary in 64 VGPRs)
+// The activated gates and cell states come from the training forward (eab_lstm64_train_fwd_f32, gates [S][T][5][64]).
+// Bound: fp32 matrix pipe (64 MFMAs x 32 cycles per step), half of the forward's.
+#include "common.h"
+
+#define LB_H 64
+#define LB_SEQ 16
+#define LB_LD (4 * LB_H + 4)      // dgates tile row: 256 floats + pad (odd 16-byte-slot stride)
+#define LB_OOB 0x80000000u
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float lb_tanh(float x) { return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)), -1.0f); }
+
+__global__ __launch_bounds__(256) void lstm64_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ dh_out,
+                                                         const float* __restrict__ wcat, float* __restrict__ dgates, int T, int F,
+                                                         int S) {
+    __shared__ __attribute__((aligned(16))) float dg[2][LB_SEQ * LB_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ln = lane & 15, lk = lane >> 4;
+    const int s0 = blockIdx.x * LB_SEQ;
+    const int u = wave * 16 + ln;
+
+    // stationary operand: whT[4j+s] = W_hh[k = 16j + 4lk + s][u] = wcat[k][64 + u]
+    float whT[64];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) whT[4 * j + s] = wcat[(size_t)(16 * j + 4 * lk + s) * 128 + 64 + u];
+
+    // element role: unit u of sequences sq[r] = s0 + 4*lk + r
+    size_t goff[4];       // float offset of gates[sq][0][0][u]
+    size_t hoff[4];       // float offset of dh_out[b][0][f][u]
+    bool ok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int sq = s0 + 4 * lk + r;
+        ok[r] = sq < S;
+        const int b = ok[r] ? sq / F : 0, f = ok[r] ? sq - b * F : 0;
+        goff[r] = ((size_t)(ok[r] ? sq : 0) * T * 5) * LB_H + u;
+        hoff[r] = (((size_t)b * T) * F + f) * LB_H + u;
+    }
+    const size_t g_t = (size_t)5 * LB_H, h_t = (size_t)F * LB_H;         // strides per time step
+
+    // writer role: thread -> sequence ws = tid>>4, 16 floats starting at column (tid&15)*16 of the 256-wide row
+    const int ws = tid >> 4, wc = (tid & 15) * 16;
+    const int wsq = s0 + ws;
+    const bool wok = wsq < S;
+    const int wb = wok ? wsq / F : 0, wf = wok ? wsq - wb * F : 0;
+    const size_t dg_base = (((size_t)wb * T) * F + wf) * (4 * LB_H) + wc;
+    const size_t dg_t = (size_t)F * 4 * LB_H;
+
+    float dhr[4] = {0.f, 0.f, 0.f, 0.f}, dcc[4] = {0.f, 0.f, 0.f, 0.f};
+    // values of step t in registers (loaded one step ahead)
+    float gi[4], gf[4], gg[4], go[4], ct[4], cp[4], du[4];
+    auto load = [&](int t, float (&i_)[4], float (&f_)[4], float (&g_)[4], float (&o_)[4], float (&c_)[4], float (&p_)[4],
+                    float (&d_)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool v = ok[r] && t >= 0;
+            const float* gp = gates + goff[r] + (size_t)(t >= 0 ? t : 0) * g_t;
+            i_[r] = v ? gp[0] : 0.f;
+            f_[r] = v ? gp[LB_H] : 0.f;
+            g_[r] = v ? gp[2 * LB_H] : 0.f;
+            o_[r] = v ? gp[3 * LB_H] : 0.f;
+            c_[r] = v ? gp[4 * LB_H] : 0.f;
+            p_[r] = (v && t > 0) ? *(gp - LB_H) : 0.f;          // c_{t-1}: slot 4 of step t-1 sits 64 floats below slot 0 of step t
+            d_[r] = v ? dh_out[hoff[r] + (size_t)(t >= 0 ? t : 0) * h_t] : 0.f;
+        }
+    };
+    load(T - 1, gi, gf, gg, go, ct, cp, du);
+
+    for (int t = T - 1; t >= 0; --t) {
+        const int buf = t & 1;
+        float ni[4], nf[4], ng[4], no[4], nc[4], np[4], nd[4];
+        load(t - 1, ni, nf, ng, no, nc, np, nd);                      // next step's operands in flight
+        // ---- elementwise: gate pre-activation gradients of step t
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dh = du[r] + dhr[r];
+            const float tc = lb_tanh(ct[r]);
+            const float d_o = dh * tc * go[r] * (1.0f - go[r]);
+            const float dc = dcc[r] + dh * go[r] * (1.0f - tc * tc);
+            const float d_i = dc * gg[r] * gi[r] * (1.0f - gi[r]);
+            const float d_g = dc * gi[r] * (1.0f - gg[r] * gg[r]);
+            const float d_f = dc * cp[r] * gf[r] * (1.0f - gf[r]);
+            dcc[r] = dc * gf[r];
+            float* row = &dg[buf][(4 * lk + r) * LB_LD + u];
+            row[0] = d_i;
+            row[LB_H] = d_f;
+            row[2 * LB_H] = d_g;
+            row[3 * LB_H] = d_o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // ---- dh_rec = dgates_t . W_hh   (four accumulation chains)
+        f32x4 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* arow = &dg[buf][ln * LB_LD + 4 * lk];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * j);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[j & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], whT[4 * j + s], acc[j & 3], 0, 0, 0);
+        }
+        // ---- coalesced write-back of the dgates tile: 1 KB per sequence row
+        if (wok) {
+            const float* src = &dg[buf][ws * LB_LD + wc];
+            float* dst = dgates + dg_base + (size_t)t * dg_t;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dst + 4 * q) = *reinterpret_cast<const f32x4*>(src + 4 * q);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dhr[r] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+            gi[r] = ni[r]; gf[r] = nf[r]; gg[r] = ng[r]; go[r] = no[r]; ct[r] = nc[r]; cp[r] = np[r]; du[r] = nd[r];
+        }
+    }
+}
+
+extern "C" int eab_lstm64_bwd_f32(const float* gates, const float* dh_out, const float* wcat, float* dgates, int B, int T, int F,
+                                  eab_stream_t stream) {
+    EAB_CHECK_ARG(gates && dh_out && wcat && dgates && B > 0 && T > 0 && F > 0);
+    const long long S = (long long)B * F;
+    EAB_CHECK_ARG(S * T * 5 * LB_H < (1ll << 40));
+    const int grid = (int)((S + LB_SEQ - 1) / LB_SEQ);
+    hipLaunchKernelGGL(lstm64_bwd_kernel, dim3(grid), dim3(256), 0, eab_stream(stream), gates, dh_out, wcat, dgates, T, F, (int)S);
+    EAB_RETURN_LAUNCH_STATUS();
+}

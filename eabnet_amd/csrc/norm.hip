@@ -16,7 +16,8 @@ __global__ __launch_bounds__(1024) void in_finalize_kernel(const float* __restri
                                                            const float* __restrict__ gamma0,
                                                            const float* __restrict__ beta0, float* __restrict__ xf0,
                                                            const float* __restrict__ gamma1,
-                                                           const float* __restrict__ beta1, float* __restrict__ xf1) {
+                                                           const float* __restrict__ beta1, float* __restrict__ xf1,
+                                                           float* __restrict__ mr0, float* __restrict__ mr1) {
     __shared__ double red[3][FIN_SLICES][64];
     const int b = blockIdx.x / nsets, s = blockIdx.x % nsets;
     const float* gamma = s == 0 ? gamma0 : gamma1;
@@ -62,18 +63,27 @@ __global__ __launch_bounds__(1024) void in_finalize_kernel(const float* __restri
         const double scale = (double)gamma[c] / sqrt(var + (double)eps);
         const double shift = (double)beta[c] - mean * scale;
         *reinterpret_cast<float2*>(&xf[((size_t)b * C + c) * 2]) = make_float2((float)scale, (float)shift);
+        float* mr = s == 0 ? mr0 : mr1;                                      // training: (mean, rstd) for the backward pass
+        if (mr) *reinterpret_cast<float2*>(&mr[((size_t)b * C + c) * 2]) = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
     }
 }
 
 extern "C" int eab_in_finalize_f32(const float* stats, int B, int C, int nsets, int stat_tiles, int count, float eps,
                                    const float* gamma0, const float* beta0, float* xf0, const float* gamma1,
                                    const float* beta1, float* xf1, eab_stream_t stream) {
+    return eab_in_finalize_mr_f32(stats, B, C, nsets, stat_tiles, count, eps, gamma0, beta0, xf0, gamma1, beta1, xf1, nullptr,
+                                  nullptr, stream);
+}
+
+extern "C" int eab_in_finalize_mr_f32(const float* stats, int B, int C, int nsets, int stat_tiles, int count, float eps,
+                                      const float* gamma0, const float* beta0, float* xf0, const float* gamma1,
+                                      const float* beta1, float* xf1, float* mr0, float* mr1, eab_stream_t stream) {
     EAB_CHECK_ARG(stats && B > 0 && C > 0 && stat_tiles > 0 && count > 0);
     EAB_CHECK_ARG(nsets == 1 || nsets == 2);
     EAB_CHECK_ARG(gamma0 && beta0 && xf0);
     EAB_CHECK_ARG(nsets == 1 || (gamma1 && beta1 && xf1));
     hipLaunchKernelGGL(in_finalize_kernel, dim3(B * nsets, (C + 63) / 64), dim3(1024), 0, eab_stream(stream), stats, C,
-                       nsets, stat_tiles, eps, gamma0, beta0, xf0, gamma1, beta1, xf1);
+                       nsets, stat_tiles, eps, gamma0, beta0, xf0, gamma1, beta1, xf1, mr0, mr1);
     EAB_RETURN_LAUNCH_STATUS();
 }
 

@@ -62,9 +62,10 @@ extern "C" int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream
                 rc = eab_conv_f32(&o.conv, stream);
                 break;
             case EAB_OP_IN_FINALIZE:
-                rc = eab_in_finalize_f32((const float*)o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.f[0],
-                                         (const float*)o.p[1], (const float*)o.p[2], (float*)o.p[3],
-                                         (const float*)o.p[4], (const float*)o.p[5], (float*)o.p[6], stream);
+                rc = eab_in_finalize_mr_f32((const float*)o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.f[0],
+                                            (const float*)o.p[1], (const float*)o.p[2], (float*)o.p[3],
+                                            (const float*)o.p[4], (const float*)o.p[5], (float*)o.p[6], (float*)o.p[7],
+                                            (float*)o.p[8], stream);
                 break;
             case EAB_OP_NORM_ACT:
                 if (o.win.pos)
@@ -117,6 +118,67 @@ extern "C" int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream
                                      (const float*)o.p[3], (float*)o.p[4], (float*)o.p[5], o.i[0], o.i[1], o.i[2], o.i[3],
                                      o.i[4], o.i[5], o.win, stream);
                 break;
+#define EAB_P(k) ((const float*)o.p[k])
+#define EAB_W(k) ((float*)const_cast<void*>(o.p[k]))
+#define EAB_N64(k) ((long long)(((unsigned long long)(uint32_t)o.i[(k) + 1] << 32) | (uint32_t)o.i[k]))
+            case EAB_OP_GATHER:
+                rc = eab_gather_f32(EAB_P(0), (const int32_t*)o.p[1], (const int32_t*)o.p[2], EAB_W(3), EAB_N64(0), stream);
+                break;
+            case EAB_OP_IN_STATS:
+                rc = eab_train_in_stats_f32(EAB_P(0), EAB_P(1), o.i[0], o.i[1], o.i[2], o.f[0], EAB_P(2), EAB_P(3), EAB_W(4),
+                                            EAB_W(5), stream);
+                break;
+            case EAB_OP_TR_NORM_ACT:
+                rc = eab_train_norm_act_f32(EAB_P(0), EAB_P(1), EAB_P(2), EAB_P(3), EAB_W(4), o.i[0], o.i[1], o.i[2], o.i[3],
+                                            stream);
+                break;
+            case EAB_OP_NORM_BWD:
+                rc = eab_train_norm_bwd_f32(EAB_P(0), EAB_P(1), EAB_P(2), EAB_P(3), EAB_P(4), EAB_P(5), EAB_W(6), EAB_P(7),
+                                            EAB_W(8), EAB_W(9), EAB_W(10), EAB_W(11), o.i[0], o.i[1], o.i[2], o.i[3], stream);
+                break;
+            case EAB_OP_GLU_BWD:
+                rc = eab_glu_bwd_f32(EAB_P(0), EAB_P(1), EAB_W(2), EAB_N64(0), o.i[2], stream);
+                break;
+            case EAB_OP_GATE_FWD:
+                rc = eab_gate_fwd_f32(EAB_P(0), EAB_P(1), EAB_W(2), EAB_N64(0), stream);
+                break;
+            case EAB_OP_GATE_BWD:
+                rc = eab_gate_bwd_f32(EAB_P(0), EAB_P(1), EAB_P(2), EAB_W(3), EAB_W(4), EAB_N64(0), stream);
+                break;
+            case EAB_OP_ADD:
+                rc = eab_add_f32(EAB_P(0), EAB_P(1), EAB_W(2), EAB_N64(0), stream);
+                break;
+            case EAB_OP_RELU_BWD:
+                rc = eab_relu_bwd_f32(EAB_P(0), EAB_P(1), EAB_W(2), EAB_N64(0), stream);
+                break;
+            case EAB_OP_COLSUM:
+                rc = eab_colsum_f32(EAB_P(0), EAB_W(1), EAB_N64(0), o.i[2], stream);
+                break;
+            case EAB_OP_FILTER_SUM:
+                rc = eab_filter_sum_ld_f32(EAB_P(0), EAB_P(1), EAB_W(2), o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], stream);
+                break;
+            case EAB_OP_FS_BWD:
+                rc = eab_filter_sum_bwd_f32(EAB_P(0), EAB_P(1), EAB_W(2), o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], stream);
+                break;
+            case EAB_OP_LN_FWD:
+                rc = eab_layernorm64_fwd_f32(EAB_P(0), EAB_P(1), EAB_P(2), o.f[0], EAB_W(3), EAB_W(4), EAB_N64(0), stream);
+                break;
+            case EAB_OP_LN_BWD:
+                rc = eab_layernorm64_bwd_f32(EAB_P(0), EAB_P(1), EAB_P(2), EAB_P(3), EAB_W(4), EAB_W(5), EAB_W(6), EAB_N64(0),
+                                             stream);
+                break;
+            case EAB_OP_LSTM_TRAIN:
+                rc = eab_lstm64_train_fwd_f32(EAB_P(0), EAB_P(1), EAB_P(2), EAB_W(3), EAB_W(4), o.i[0], o.i[1], o.i[2], stream);
+                break;
+            case EAB_OP_LSTM_BWD:
+                rc = eab_lstm64_bwd_f32(EAB_P(0), EAB_P(1), EAB_P(2), EAB_W(3), o.i[0], o.i[1], o.i[2], stream);
+                break;
+            case EAB_OP_WGRAD:
+                rc = eab_wgrad_f32(&o.wgrad, stream);
+                break;
+#undef EAB_P
+#undef EAB_W
+#undef EAB_N64
             default:
                 rc = EAB_EINVAL;
         }
@@ -128,3 +190,4 @@ extern "C" int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream
 // struct-layout handshake for the ctypes mirror (eabnet_amd/_lib.py)
 extern "C" int eab_sizeof_conv_desc(void) { return (int)sizeof(eab_conv_desc); }
 extern "C" int eab_sizeof_op(void) { return (int)sizeof(eab_op); }
+extern "C" int eab_sizeof_wgrad_desc(void) { return (int)sizeof(eab_wgrad_desc); }

@@ -1,0 +1,569 @@
+// Training-side kernels of the hot path: the HBM-bound forward pieces the fused inference
+// program never materialises, and every elementwise / reduction step of the backward pass.  The contractions of
+// the backward pass are eab_conv_f32 (dgrad = the gather form of the transposed / strided counterpart of each
+// forward convolution) and eab_wgrad_f32 (csrc/wgrad.hip).
+//
+// Reference call-sites (the autograd graph PyTorch builds for train_distributed.py:221-228):
+//   NormSwitch IN + PReLU        EaBNet.py:684-686, 187-188, 403-404, 426-427, 545-569
+//   GLU                          EaBNet.py:459-460, 489-490
+//   S-TCM gate                   EaBNet.py:575-576
+//   LayerNorm                    EaBNet.py:598, 608
+//   w_dnn ReLU                   EaBNet.py:595
+//   filter-and-sum               EaBNet.py:114-117
+// All tensors channels-last [B][P][C] fp32 (P = T*F positions); roofline "hbm" for every kernel in this file.
+#include "common.h"
+
+#define TR_THREADS 256
+
+// ---------------------------------------------------------------------------------------------------
+// parameter packing: out[i] = flat[ia[i]] (+ flat[ib[i]]); index < 0 = 0.0.  One launch turns the flat parameter
+// vector into every packed operand of the program (forward and dgrad layouts); the same kernel, driven by the
+// inverse table, turns the packed gradient arena back into the flat gradient.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TR_THREADS) void gather_kernel(const float* __restrict__ flat, const int32_t* __restrict__ ia,
+                                                            const int32_t* __restrict__ ib, float* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int a = ia[i];
+        float v = a >= 0 ? flat[a] : 0.0f;
+        if (ib) {
+            const int b = ib[i];
+            if (b >= 0) v += flat[b];
+        }
+        out[i] = v;
+    }
+}
+
+extern "C" int eab_gather_f32(const float* flat, const int32_t* ia, const int32_t* ib, float* out, long long n,
+                              eab_stream_t stream) {
+    EAB_CHECK_ARG(flat && ia && out && n >= 0);
+    if (n == 0) return EAB_OK;
+    long long g = (n + TR_THREADS - 1) / TR_THREADS;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)g), dim3(TR_THREADS), 0, eab_stream(stream), flat, ia, ib, out, n);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// InstanceNorm statistics of a materialised [B][P][C] tensor (1-D units: P = T), optional PReLU in front
+// (S-TCM order, EaBNet.py:545-547): per (b, c) mean / biased variance over P in fp64, then
+//   xf[b][c] = (gamma*rstd, beta - mean*gamma*rstd),  mr[b][c] = (mean, rstd).
+// grid (B, C/64), block 256 = 64 channels x 4 position lanes.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TR_THREADS) void in_stats_kernel(const float* __restrict__ x, const float* __restrict__ slope,
+                                                              int P, int C, float eps, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ xf,
+                                                              float* __restrict__ mr) {
+    __shared__ double red[2][4][64];
+    const int b = blockIdx.x, cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        const float a = slope ? slope[c] : 1.0f;
+        const float* p = x + (size_t)b * P * C + c;
+        // shifted sums (shift = the first value): no cancellation for nearly constant channels
+        const float k = eab_prelu(p[0], a);
+        for (int i = pl; i < P; i += 4) {
+            const double v = (double)(eab_prelu(p[(size_t)i * C], a) - k);
+            s += v;
+            q += v * v;
+        }
+        red[0][pl][cl] = s;
+        red[1][pl][cl] = q;
+    }
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        const float a = slope ? slope[c] : 1.0f;
+        const float k = eab_prelu(x[(size_t)b * P * C + c], a);
+        s = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+        q = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+        const double mean_s = s / P;
+        double var = q / P - mean_s * mean_s;
+        if (var < 0.0) var = 0.0;
+        const double mean = mean_s + (double)k;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const double scale = (double)gamma[c] * rstd;
+        *reinterpret_cast<float2*>(&xf[((size_t)b * C + c) * 2]) = make_float2((float)scale, (float)((double)beta[c] - mean * scale));
+        *reinterpret_cast<float2*>(&mr[((size_t)b * C + c) * 2]) = make_float2((float)mean, (float)rstd);
+    }
+}
+
+extern "C" int eab_train_in_stats_f32(const float* x, const float* slope, int B, int P, int C, float eps, const float* gamma,
+                                      const float* beta, float* xf, float* mr, eab_stream_t stream) {
+    EAB_CHECK_ARG(x && gamma && beta && xf && mr && B > 0 && P > 0 && C > 0 && B <= 65535);
+    hipLaunchKernelGGL(in_stats_kernel, dim3(B, (C + 63) / 64), dim3(TR_THREADS), 0, eab_stream(stream), x, slope, P, C, eps,
+                       gamma, beta, xf, mr);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// y = f(x) [+ add]   with f = prelu(x*scale + shift)  (EAB_XF_NORM_PRELU, 2-D units)
+//                        or prelu(x)*scale + shift    (EAB_XF_PRELU_NORM, S-TCM)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TR_THREADS) void tr_norm_act_kernel(const float* __restrict__ x, const float* __restrict__ xf,
+                                                                 const float* __restrict__ slope, const float* __restrict__ add,
+                                                                 float* __restrict__ y, int P, int C, int mode) {
+    const unsigned C4 = (unsigned)C >> 2, n4 = (unsigned)P * C4, b = blockIdx.y;
+    const size_t base = (size_t)b * n4;
+    for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < n4; r += gridDim.x * blockDim.x) {
+        const int c = (int)(r % C4) * 4;
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[base + r];
+        const float* xp = xf + ((size_t)b * C + c) * 2;
+        const f32x4 s01 = *reinterpret_cast<const f32x4*>(xp), s23 = *reinterpret_cast<const f32x4*>(xp + 4);
+        const f32x4 sl = *reinterpret_cast<const f32x4*>(slope + c);
+        const float sc[4] = {s01[0], s01[2], s23[0], s23[2]}, sh[4] = {s01[1], s01[3], s23[1], s23[3]};
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = mode == EAB_XF_NORM_PRELU ? eab_prelu(fmaf(v[j], sc[j], sh[j]), sl[j]) : fmaf(eab_prelu(v[j], sl[j]), sc[j], sh[j]);
+        if (add) {
+            const f32x4 a = reinterpret_cast<const f32x4*>(add)[base + r];
+            o += a;
+        }
+        reinterpret_cast<f32x4*>(y)[base + r] = o;
+    }
+}
+
+static inline unsigned tr_grid_x(long long n4, int B) {
+    long long gx = (n4 + TR_THREADS - 1) / TR_THREADS;
+    const long long cap = (256 * 8 + B - 1) / B;
+    if (gx > cap) gx = cap;
+    return (unsigned)(gx < 1 ? 1 : gx);
+}
+
+extern "C" int eab_train_norm_act_f32(const float* x, const float* xf, const float* slope, const float* add, float* y, int B,
+                                      int P, int C, int mode, eab_stream_t stream) {
+    EAB_CHECK_ARG(x && xf && slope && y && B > 0 && P > 0 && C > 0 && (C % 4) == 0 && B <= 65535);
+    EAB_CHECK_ARG(mode == EAB_XF_NORM_PRELU || mode == EAB_XF_PRELU_NORM);
+    EAB_CHECK_ARG((long long)P * (C / 4) < (1ll << 31));
+    hipLaunchKernelGGL(tr_norm_act_kernel, dim3(tr_grid_x((long long)P * (C / 4), B), B), dim3(TR_THREADS), 0, eab_stream(stream),
+                       x, xf, slope, add, y, P, C, mode);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Backward of y = f(x) with InstanceNorm statistics taken over P (per b, c).  xh = normalised value.
+//   NORM_PRELU: u = g*xh + be, y = prelu(u):  du = dy*(u > 0 ? 1 : a);  dslope += dy*min(u,0)... (u <= 0 ? u : 0)
+//               A = sum du, Q = sum du*xh;   dx = rstd*g*(du - A/P - xh*Q/P);   dgamma += Q, dbeta += A
+//   PRELU_NORM: p = prelu(x), xh = (p-mean)*rstd, y = g*xh + be:
+//               A = sum dy, Q = sum dy*xh;   dp = rstd*g*(dy - A/P - xh*Q/P);   dx = dp*(x > 0 ? 1 : a);
+//               dslope += dp*(x <= 0 ? x : 0)  (second pass);  dgamma += Q, dbeta += A
+// pass 1 (reduce): sums[b][c][4] += (A, Q, S, 0), S = the NORM_PRELU slope sum; fp32 atomics per block.
+// pass 2 (apply):  dx (= or +=), PRELU_NORM slope sum into sums[..][2].
+// pass 3 (params): dgamma[c] += sum_b Q, dbeta[c] += sum_b A, dslope[c] += sum_b S.
+// ---------------------------------------------------------------------------------------------------
+#define NB_ROWS 4       // position lanes per block: block = 64 channels x 4
+
+__global__ __launch_bounds__(TR_THREADS) void tr_zero_kernel(float* __restrict__ p, long long n4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) reinterpret_cast<f32x4*>(p)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+__global__ __launch_bounds__(TR_THREADS) void norm_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                     const float* __restrict__ mr, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, const float* __restrict__ slope,
+                                                                     float* __restrict__ sums, int P, int C, int mode, int chunk) {
+    __shared__ float red[3][NB_ROWS][64];
+    const int b = blockIdx.z, cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    float A = 0.f, Q = 0.f, S = 0.f;
+    if (c < C) {
+        const float2 m = *reinterpret_cast<const float2*>(&mr[((size_t)b * C + c) * 2]);
+        const float g = gamma[c], be = beta[c], a = slope[c];
+        const int p0 = blockIdx.x * chunk, p1 = p0 + chunk < P ? p0 + chunk : P;
+        const size_t base = (size_t)b * P * C + c;
+        for (int i = p0 + pl; i < p1; i += NB_ROWS) {
+            const float xv = x[base + (size_t)i * C], d = dy[base + (size_t)i * C];
+            if (mode == EAB_XF_NORM_PRELU) {
+                const float xh = (xv - m.x) * m.y, u = fmaf(g, xh, be);
+                const float du = u > 0.f ? d : a * d;
+                A += du;
+                Q = fmaf(du, xh, Q);
+                S += u > 0.f ? 0.f : d * u;
+            } else {
+                const float xh = (eab_prelu(xv, a) - m.x) * m.y;
+                A += d;
+                Q = fmaf(d, xh, Q);
+            }
+        }
+    }
+    red[0][pl][cl] = A;
+    red[1][pl][cl] = Q;
+    red[2][pl][cl] = S;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        float* o = &sums[((size_t)b * C + c) * 4];
+        atomicAdd(o + 0, red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
+        atomicAdd(o + 1, red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]);
+        if (mode == EAB_XF_NORM_PRELU) atomicAdd(o + 2, red[2][0][cl] + red[2][1][cl] + red[2][2][cl] + red[2][3][cl]);
+    }
+}
+
+__global__ __launch_bounds__(TR_THREADS) void norm_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                    const float* __restrict__ mr, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, const float* __restrict__ slope,
+                                                                    float* __restrict__ sums, const float* __restrict__ acc_in,
+                                                                    float* __restrict__ dx, int P, int C, int mode, int chunk) {
+    __shared__ float red[NB_ROWS][64];
+    const int b = blockIdx.z, cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    float S = 0.f;
+    if (c < C) {
+        const float2 m = *reinterpret_cast<const float2*>(&mr[((size_t)b * C + c) * 2]);
+        const float g = gamma[c], be = beta[c], a = slope[c];
+        const float inv_p = 1.0f / (float)P;
+        const float A = sums[((size_t)b * C + c) * 4] * inv_p, Q = sums[((size_t)b * C + c) * 4 + 1] * inv_p;
+        const float k = m.y * g;
+        const int p0 = blockIdx.x * chunk, p1 = p0 + chunk < P ? p0 + chunk : P;
+        const size_t base = (size_t)b * P * C + c;
+        for (int i = p0 + pl; i < p1; i += NB_ROWS) {
+            const size_t e = base + (size_t)i * C;
+            const float xv = x[e], d = dy[e];
+            float r;
+            if (mode == EAB_XF_NORM_PRELU) {
+                const float xh = (xv - m.x) * m.y, u = fmaf(g, xh, be);
+                const float du = u > 0.f ? d : a * d;
+                r = k * (du - A - xh * Q);
+            } else {
+                const float xh = (eab_prelu(xv, a) - m.x) * m.y;
+                const float dp = k * (d - A - xh * Q);
+                r = xv > 0.f ? dp : a * dp;
+                S += xv > 0.f ? 0.f : dp * xv;
+            }
+            dx[e] = acc_in ? r + acc_in[e] : r;
+        }
+    }
+    if (mode == EAB_XF_PRELU_NORM) {
+        red[pl][cl] = S;
+        __syncthreads();
+        if (pl == 0 && c < C) atomicAdd(&sums[((size_t)b * C + c) * 4 + 2], red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+    }
+}
+
+__global__ __launch_bounds__(64) void norm_bwd_params_kernel(const float* __restrict__ sums, int B, int C, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, float* __restrict__ dslope) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    float A = 0.f, Q = 0.f, S = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&sums[((size_t)b * C + c) * 4]);
+        A += v[0];
+        Q += v[1];
+        S += v[2];
+    }
+    dgamma[c] += Q;
+    dbeta[c] += A;
+    dslope[c] += S;
+}
+
+static inline int nb_chunk(int P, int B, int C) {
+    // positions per block: ~2048 blocks over the grid, at least 64 positions each
+    const long long blocks_bc = (long long)B * ((C + 63) / 64);
+    long long want = (2048 + blocks_bc - 1) / blocks_bc;
+    if (want < 1) want = 1;
+    long long chunk = (P + want - 1) / want;
+    if (chunk < 64) chunk = 64;
+    return (int)((chunk + NB_ROWS - 1) / NB_ROWS * NB_ROWS);
+}
+
+extern "C" int eab_train_norm_bwd_f32(const float* dy, const float* x, const float* mr, const float* gamma, const float* beta,
+                                      const float* slope, float* sums, const float* acc_in, float* dx, float* dgamma,
+                                      float* dbeta, float* dslope, int B, int P, int C, int mode, eab_stream_t stream) {
+    EAB_CHECK_ARG(dy && x && mr && gamma && beta && slope && sums && dx && dgamma && dbeta && dslope);
+    EAB_CHECK_ARG(B > 0 && P > 0 && C > 0 && B <= 65535 && (mode == EAB_XF_NORM_PRELU || mode == EAB_XF_PRELU_NORM));
+    const int chunk = nb_chunk(P, B, C);
+    dim3 grid((P + chunk - 1) / chunk, (C + 63) / 64, B);
+    hipStream_t s = eab_stream(stream);
+    // (a kernel, not hipMemsetAsync: memset nodes of a captured graph were not reliably ordered on this stack)
+    hipLaunchKernelGGL(tr_zero_kernel, dim3((B * C + TR_THREADS - 1) / TR_THREADS), dim3(TR_THREADS), 0, s, sums, (long long)B * C);
+    hipLaunchKernelGGL(norm_bwd_reduce_kernel, grid, dim3(TR_THREADS), 0, s, dy, x, mr, gamma, beta, slope, sums, P, C, mode, chunk);
+    hipLaunchKernelGGL(norm_bwd_apply_kernel, grid, dim3(TR_THREADS), 0, s, dy, x, mr, gamma, beta, slope, sums, acc_in, dx, P, C,
+                       mode, chunk);
+    hipLaunchKernelGGL(norm_bwd_params_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, B, C, dgamma, dbeta, dslope);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GLU backward.  Forward (eab_conv_f32, EAB_EPI_GLU with glu_dump): y[c] = a[c]*s[c], s = sigmoid(gate); the dump
+// holds a and s in the PACKED column order of the convolution (column r: half = (r%64)/32 (0 = value, 1 = gate),
+// channel c = (r/64)*32 + r%32).  dz (same packed order, N = 2*Cout columns) = (dy*s | dy*a*s*(1-s)).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TR_THREADS) void glu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dump,
+                                                             float* __restrict__ dz, long long rows, int N) {
+    const int Cout = N >> 1, N4 = N >> 2;
+    const long long n4 = rows * N4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / N4;
+        const int r = (int)(i - row * N4) * 4;                 // first packed column of this float4 (same half, same 32-group)
+        const int half = (r & 63) >> 5, c = (r >> 6) * 32 + (r & 31);
+        const int mate = half ? r - 32 : r + 32;               // packed column of the partner (gate <-> value)
+        const f32x4 d = *reinterpret_cast<const f32x4*>(&dy[row * Cout + c]);
+        const f32x4 me = *reinterpret_cast<const f32x4*>(&dump[row * N + r]);
+        const f32x4 ot = *reinterpret_cast<const f32x4*>(&dump[row * N + mate]);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = half ? d[j] * ot[j] * me[j] * (1.0f - me[j]) : d[j] * ot[j];
+        *reinterpret_cast<f32x4*>(&dz[row * N + r]) = o;
+    }
+}
+
+extern "C" int eab_glu_bwd_f32(const float* dy, const float* dump, float* dz, long long rows, int N, eab_stream_t stream) {
+    EAB_CHECK_ARG(dy && dump && dz && rows > 0 && N > 0 && (N % 64) == 0);
+    long long g = (rows * (N / 4) + TR_THREADS - 1) / TR_THREADS;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(glu_bwd_kernel, dim3((unsigned)g), dim3(TR_THREADS), 0, eab_stream(stream), dy, dump, dz, rows, N);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// S-TCM gate z = a * sigmoid(r) (EaBNet.py:575) and its backward; flat float4 kernels.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TR_THREADS) void gate_fwd_kernel(const float* __restrict__ a, const float* __restrict__ r,
+                                                              float* __restrict__ z, long long n4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const f32x4 av = reinterpret_cast<const f32x4*>(a)[i], rv = reinterpret_cast<const f32x4*>(r)[i];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = av[j] * eab_sigmoid(rv[j]);
+        reinterpret_cast<f32x4*>(z)[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(TR_THREADS) void gate_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ a,
+                                                              const float* __restrict__ r, float* __restrict__ da,
+                                                              float* __restrict__ dr, long long n4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const f32x4 d = reinterpret_cast<const f32x4*>(dz)[i], av = reinterpret_cast<const f32x4*>(a)[i],
+                    rv = reinterpret_cast<const f32x4*>(r)[i];
+        f32x4 oa, orr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s = eab_sigmoid(rv[j]);
+            oa[j] = d[j] * s;
+            orr[j] = d[j] * av[j] * s * (1.0f - s);
+        }
+        reinterpret_cast<f32x4*>(da)[i] = oa;
+        reinterpret_cast<f32x4*>(dr)[i] = orr;
+    }
+}
+
+static inline unsigned flat_grid(long long n4) {
+    long long g = (n4 + TR_THREADS - 1) / TR_THREADS;
+    if (g > 8192) g = 8192;
+    return (unsigned)(g < 1 ? 1 : g);
+}
+
+extern "C" int eab_gate_fwd_f32(const float* a, const float* r, float* z, long long n, eab_stream_t stream) {
+    EAB_CHECK_ARG(a && r && z && n > 0 && (n % 4) == 0);
+    hipLaunchKernelGGL(gate_fwd_kernel, dim3(flat_grid(n / 4)), dim3(TR_THREADS), 0, eab_stream(stream), a, r, z, n / 4);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int eab_gate_bwd_f32(const float* dz, const float* a, const float* r, float* da, float* dr, long long n,
+                                eab_stream_t stream) {
+    EAB_CHECK_ARG(dz && a && r && da && dr && n > 0 && (n % 4) == 0);
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(flat_grid(n / 4)), dim3(TR_THREADS), 0, eab_stream(stream), dz, a, r, da, dr, n / 4);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
+// out = a + b   /   dx = y > 0 ? dy : 0
+__global__ __launch_bounds__(TR_THREADS) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         float* __restrict__ out, long long n4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+        reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
+}
+
+__global__ __launch_bounds__(TR_THREADS) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                              float* __restrict__ dx, long long n4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const f32x4 d = reinterpret_cast<const f32x4*>(dy)[i], v = reinterpret_cast<const f32x4*>(y)[i];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = v[j] > 0.0f ? d[j] : 0.0f;
+        reinterpret_cast<f32x4*>(dx)[i] = o;
+    }
+}
+
+extern "C" int eab_add_f32(const float* a, const float* b, float* out, long long n, eab_stream_t stream) {
+    EAB_CHECK_ARG(a && b && out && n > 0 && (n % 4) == 0);
+    hipLaunchKernelGGL(add_kernel, dim3(flat_grid(n / 4)), dim3(TR_THREADS), 0, eab_stream(stream), a, b, out, n / 4);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int eab_relu_bwd_f32(const float* dy, const float* y, float* dx, long long n, eab_stream_t stream) {
+    EAB_CHECK_ARG(dy && y && dx && n > 0 && (n % 4) == 0);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(flat_grid(n / 4)), dim3(TR_THREADS), 0, eab_stream(stream), dy, y, dx, n / 4);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// column sums of a [rows][N] matrix (bias gradients): out[n] += sum_r x[r][n]
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TR_THREADS) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long long rows,
+                                                            int N, long long chunk) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    float s = 0.f;
+    const long long r0 = (long long)blockIdx.x * chunk, r1 = r0 + chunk < rows ? r0 + chunk : rows;
+    if (c < N)
+        for (long long r = r0 + pl; r < r1; r += 4) s += x[r * N + c];
+    red[pl][cl] = s;
+    __syncthreads();
+    if (pl == 0 && c < N) atomicAdd(&out[c], red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+
+extern "C" int eab_colsum_f32(const float* x, float* out, long long rows, int N, eab_stream_t stream) {
+    EAB_CHECK_ARG(x && out && rows > 0 && N > 0);
+    const int cb = (N + 63) / 64;
+    long long blocks = 1024 / cb;
+    if (blocks < 1) blocks = 1;
+    long long chunk = (rows + blocks - 1) / blocks;
+    if (chunk < 64) chunk = 64;
+    chunk = (chunk + 3) / 4 * 4;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((rows + chunk - 1) / chunk), cb), dim3(TR_THREADS), 0, eab_stream(stream), x,
+                       out, rows, N, chunk);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// filter-and-sum backward w.r.t. the beam-forming weights (EaBNet.py:114-117):
+//   Yr = sum_m Wr Xr - Wi Xi,  Yi = sum_m Wr Xi + Wi Xr   =>   dWr = dYr Xr + dYi Xi,  dWi = dYi Xr - dYr Xi
+//   dout [B][2][T][F], x [B][T][F][M][2] -> dw [B][T][F][ld] (first 2M columns, the rest zero)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TR_THREADS) void filter_sum_ld_kernel(const float* __restrict__ w, const float* __restrict__ x,
+                                                                   float* __restrict__ y, int T, int F, int M, int ld, long long bins) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < bins; i += (long long)gridDim.x * blockDim.x) {
+        const float2* wp = reinterpret_cast<const float2*>(w + i * ld);
+        const float2* xp = reinterpret_cast<const float2*>(x) + i * M;
+        float yr = 0.0f, yi = 0.0f;
+        for (int m = 0; m < M; ++m) {
+            const float2 a = wp[m], c = xp[m];
+            yr += a.x * c.x - a.y * c.y;
+            yi += a.x * c.y + a.y * c.x;
+        }
+        const long long f = i % F, bt = i / F, t = bt % T, b = bt / T;
+        y[((b * 2 + 0) * T + t) * F + f] = yr;
+        y[((b * 2 + 1) * T + t) * F + f] = yi;
+    }
+}
+
+__global__ __launch_bounds__(TR_THREADS) void filter_sum_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x,
+                                                                    float* __restrict__ dw, int T, int F, int M, int ld, long long bins) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < bins; i += (long long)gridDim.x * blockDim.x) {
+        const long long f = i % F, bt = i / F, t = bt % T, b = bt / T;
+        const float dr = dout[((b * 2 + 0) * T + t) * F + f], di = dout[((b * 2 + 1) * T + t) * F + f];
+        const float2* xp = reinterpret_cast<const float2*>(x) + i * M;
+        float2* wp = reinterpret_cast<float2*>(dw + i * ld);
+        for (int m = 0; m < M; ++m) {
+            const float2 c = xp[m];
+            wp[m] = make_float2(dr * c.x + di * c.y, di * c.x - dr * c.y);
+        }
+        for (int m = M; m < ld / 2; ++m) wp[m] = make_float2(0.0f, 0.0f);       // padding columns of the row
+    }
+}
+
+// w rows of `ld` floats (the first 2M used): the training program keeps the beam-forming weights in a 64-column tile
+extern "C" int eab_filter_sum_ld_f32(const float* w, const float* x, float* y, int B, int T, int F, int M, int ld, eab_stream_t stream) {
+    EAB_CHECK_ARG(w && x && y && B > 0 && T > 0 && F > 0 && M > 0 && ld >= 2 * M && (ld % 2) == 0);
+    const long long bins = (long long)B * T * F;
+    hipLaunchKernelGGL(filter_sum_ld_kernel, dim3(flat_grid(bins)), dim3(TR_THREADS), 0, eab_stream(stream), w, x, y, T, F, M, ld, bins);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int eab_filter_sum_bwd_f32(const float* dout, const float* x, float* dw, int B, int T, int F, int M, int ld,
+                                      eab_stream_t stream) {
+    EAB_CHECK_ARG(dout && x && dw && B > 0 && T > 0 && F > 0 && M > 0 && ld >= 2 * M && (ld % 2) == 0);
+    const long long bins = (long long)B * T * F;
+    hipLaunchKernelGGL(filter_sum_bwd_kernel, dim3(flat_grid(bins)), dim3(TR_THREADS), 0, eab_stream(stream), dout, x, dw, T, F, M, ld, bins);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm(64) over the channel axis of [rows][64] (EaBNet.py:598,608), forward with saved (mean, rstd), and
+// backward.  16 lanes x float4 per row (DPP row reductions); dgamma / dbeta through LDS + atomics.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float tr_row_sum(float v) {      // sum over the 16 lanes of a DPP row
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+__global__ __launch_bounds__(TR_THREADS) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                   const float* __restrict__ b, float eps, float* __restrict__ y,
+                                                                   float* __restrict__ mr, long long rows) {
+    const int lc = (threadIdx.x & 15) * 4;
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(g + lc), b4 = *reinterpret_cast<const f32x4*>(b + lc);
+    for (long long r = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); r < rows; r += (long long)gridDim.x * 16) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(&x[r * 64 + lc]);
+        const float mean = tr_row_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 64.0f);
+        const f32x4 d = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
+        const float q = tr_row_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
+        const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + eps);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = d[j] * rstd * g4[j] + b4[j];
+        *reinterpret_cast<f32x4*>(&y[r * 64 + lc]) = v;
+        if (lc == 0) *reinterpret_cast<float2*>(&mr[r * 2]) = make_float2(mean, rstd);
+    }
+}
+
+__global__ __launch_bounds__(TR_THREADS) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                   const float* __restrict__ mr, const float* __restrict__ g,
+                                                                   float* __restrict__ dx, float* __restrict__ dg,
+                                                                   float* __restrict__ db, long long rows) {
+    __shared__ float red[2][16][64];
+    const int lc = (threadIdx.x & 15) * 4, rl = threadIdx.x >> 4;
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(g + lc);
+    f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+    // every thread of a 16-lane row takes the same trip count (DPP reductions need all 16 lanes)
+    for (long long r = (long long)blockIdx.x * 16 + rl; r < rows; r += (long long)gridDim.x * 16) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(&dy[r * 64 + lc]), v = *reinterpret_cast<const f32x4*>(&x[r * 64 + lc]);
+        const float2 m = *reinterpret_cast<const float2*>(&mr[r * 2]);
+        f32x4 xh, dh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xh[j] = (v[j] - m.x) * m.y;
+            dh[j] = d[j] * g4[j];
+            sg[j] += d[j] * xh[j];
+            sb[j] += d[j];
+        }
+        const float A = tr_row_sum((dh[0] + dh[1]) + (dh[2] + dh[3])) * (1.0f / 64.0f);
+        const float Q = tr_row_sum((dh[0] * xh[0] + dh[1] * xh[1]) + (dh[2] * xh[2] + dh[3] * xh[3])) * (1.0f / 64.0f);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = m.y * (dh[j] - A - xh[j] * Q);
+        *reinterpret_cast<f32x4*>(&dx[r * 64 + lc]) = o;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[0][rl][lc + j] = sg[j];
+        red[1][rl][lc + j] = sb[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int k = threadIdx.x >> 6, c = threadIdx.x & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += red[k][i][c];
+        atomicAdd(k == 0 ? &dg[c] : &db[c], s);
+    }
+}
+
+extern "C" int eab_layernorm64_fwd_f32(const float* x, const float* g, const float* b, float eps, float* y, float* mr, long long rows,
+                                       eab_stream_t stream) {
+    EAB_CHECK_ARG(x && g && b && y && mr && rows > 0);
+    long long grid = (rows + 15) / 16;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)grid), dim3(TR_THREADS), 0, eab_stream(stream), x, g, b, eps, y, mr, rows);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int eab_layernorm64_bwd_f32(const float* dy, const float* x, const float* mr, const float* g, float* dx, float* dg,
+                                       float* db, long long rows, eab_stream_t stream) {
+    EAB_CHECK_ARG(dy && x && mr && g && dx && dg && db && rows > 0);
+    long long grid = (rows + 15) / 16;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)grid), dim3(TR_THREADS), 0, eab_stream(stream), dy, x, mr, g, dx, dg, db, rows);
+    EAB_RETURN_LAUNCH_STATUS();
+}

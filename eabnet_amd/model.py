@@ -273,6 +273,9 @@ class _HipModule(nn.Module):
         # arithmetic of the MFMA contractions: "f32" = exact fp32 MFMA; "f16x3" = error-compensated
         # fp16 split on the f16 matrix cores, same end-to-end error class as fp32
         self.precision = "f32"
+        # training forward/backward on the HIP programs (train.py) where the topology allows; False = the
+        # PyTorch-ROCm operator path (autograd_path.py) everywhere
+        self.use_hip_training = True
 
     def _param_fingerprint(self) -> tuple:
         """Change detector for the packed weights (runs on every forward).  Every parameter / buffer slot
@@ -374,8 +377,14 @@ class EaBNet(_HipModule):
         if inpt.ndim != 5 or inpt.shape[-1] != 2 or inpt.shape[-2] != self.M:
             raise ValueError(f"expected (B,T,F,{self.M},2), got {tuple(inpt.shape)}")
         if self._needs_graph(inpt):
-            # training: autograd needs a graph (or BatchNorm must see and update batch statistics)
-            # -> PyTorch-ROCm operator path (autograd_path.py)
+            # training: autograd needs a graph.  The default topology with InstanceNorm runs forward AND backward on
+            # the hand-written kernels (train.py: two static op programs behind one autograd node); the other
+            # constructor branches, BatchNorm in train mode, CPU tensors and a differentiable INPUT still take the
+            # PyTorch-ROCm operator path (autograd_path.py)
+            from . import train
+            if self.use_hip_training and inpt.is_cuda and not inpt.requires_grad and torch.is_grad_enabled() \
+                    and train.supported(self.cfg) and next(self.parameters()).is_cuda:
+                return train.forward_train(self, inpt)
             from .autograd_path import forward_autograd
             return forward_autograd(self, inpt)
         if not inpt.is_cuda:

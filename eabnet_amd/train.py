@@ -1,0 +1,789 @@
+"""Training on the hand-written kernels (BASELINE config 4): EaBNet.forward and its backward pass
+(what autograd executes for train_distributed.py:221-228 on the reference) lowered to TWO static op lists that
+libeabnet_hip.so replays -- forward (keeping what the backward needs) and backward -- behind one
+``torch.autograd.Function``.  PyTorch sees a single node: parameters in, (B,2,T,F) out; gradients of all
+parameters come back as views of one flat buffer.
+
+Differences to the inference lowering (program.py): every normalised activation is materialised (the
+convolutions read plain sources, so the same tensors are the operands of the weight gradients); gated
+convolutions also dump their two GLU factors; InstanceNorm finalisation keeps (mean, rstd); the LSTM layers keep
+their activated gates and cell states; the MLP and the filter-and-sum are separate ops.
+
+Backward contractions:
+  * dgrad = eab_conv_f32 on the output gradient with re-packed weights: the dgrad of a strided convolution
+    (GateConv2d / Conv2dunit, EaBNet.py:402,450) is the gather form of a transposed convolution, one launch per
+    input-column parity; the dgrad of a transposed convolution (EaBNet.py:423,478) is a strided convolution;
+  * wgrad = eab_wgrad_f32 (csrc/wgrad.hip) with the forward's own gather geometry;
+  * LSTM: eab_lstm64_bwd_f32 (reverse time) -> dgates, then dx / dW_ih / dW_hh / db as a 1x1 dgrad, two wgrads
+    (taps dt = 0 and dt = -1) and a column sum.
+Parameters reach the kernels through ONE gather launch (flat parameter vector -> every packed operand, forward
+and dgrad layouts; index tables built here from the same packing rules as program.py) and the packed gradient
+arena goes back to the flat gradient through the inverse table.
+
+Scope: the reference's default topology (U2 encoder/decoder, LSTM beam-former, mimo, 'cat' skips) with
+InstanceNorm; anything else keeps using autograd_path.py.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import program as prg
+from .program import ALIGN, EPS_IN, EPS_LN, Ref, conv_tiles, glu_row_order
+from .spec import NetConfig, param_specs
+
+XF_NORM_PRELU, XF_PRELU_NORM = prg.XF_NORM_PRELU, prg.XF_PRELU_NORM
+(OP_GATHER, OP_IN_STATS, OP_TR_NORM_ACT, OP_NORM_BWD, OP_GLU_BWD, OP_GATE_FWD, OP_GATE_BWD, OP_ADD, OP_RELU_BWD, OP_COLSUM,
+ OP_FILTER_SUM, OP_FS_BWD, OP_LN_FWD, OP_LN_BWD, OP_LSTM_TRAIN, OP_LSTM_BWD, OP_WGRAD) = range(16, 33)
+MLP_LD = 64          # the second Linear of w_dnn is run with its 2M rows padded to one 64-column tile
+
+
+def supported(cfg: NetConfig) -> bool:
+    return (cfg.is_u2 and cfg.bf_type == "lstm" and cfg.topo_type == "mimo" and cfg.intra_connect == "cat"
+            and cfg.norm_type == "IN" and (2 * cfg.M) % 4 == 0 and 2 * cfg.M <= MLP_LD)
+
+
+@dataclass
+class GenOp:
+    """A non-convolution op of the training programs: kind + the i / f / p fields of eab_op."""
+    kind: int
+    p: List[Optional[Ref]]
+    i: List[int] = field(default_factory=list)
+    f: List[float] = field(default_factory=list)
+    name: str = ""
+
+
+@dataclass
+class WgradOp:
+    dz: Ref
+    src0: Ref
+    src1: Optional[Ref]
+    dw: Ref
+    N: int
+    C0: int
+    C1: int
+    Kpad: int
+    B: int
+    T: int
+    Fin: int
+    Fz: int
+    No: int
+    ostride: int
+    ophase: int
+    istride: int
+    dt: List[int]
+    ioff: List[int]
+    name: str = ""
+    kind: int = OP_WGRAD
+
+
+class Slot:
+    """Gradient accumulator of one tensor (shared by all views of it)."""
+
+    def __init__(self):
+        self.ref: Optional[Ref] = None
+        self.owned = False
+
+
+@dataclass
+class TVar:
+    """A materialised channels-last activation [B][T][F][C] of the training forward."""
+    ref: Ref
+    F: int
+    C: int
+    slot: Slot = field(default_factory=Slot)
+    needs_grad: bool = True
+
+    def view(self, F: int, C: int) -> "TVar":
+        assert F * C == self.F * self.C
+        return TVar(self.ref, F, C, self.slot, self.needs_grad)
+
+
+def _split64(n: int) -> Tuple[int, int]:
+    return n & 0xFFFFFFFF, n >> 32
+
+
+class TrainLowering:
+    def __init__(self, cfg: NetConfig, B: int, T: int, F: int = 161):
+        if not supported(cfg):
+            raise NotImplementedError("the HIP training path covers the default topology with InstanceNorm")
+        cfg.check_supported()
+        self.cfg, self.B, self.T, self.F = cfg, B, T, F
+        self.specs = {k: s for k, s in param_specs(cfg).items() if s.kind != "bn_count"}
+        self.poff: Dict[str, int] = {}
+        n = 0
+        for k, s in self.specs.items():
+            self.poff[k] = n
+            n += int(np.prod(s.shape)) if s.shape else 1
+        self.n_params = n
+        self.a_size = 0
+        self.w_imgs: List[Tuple[np.ndarray, Optional[np.ndarray]]] = []      # packed-parameter images (flat indices, -1 = 0)
+        self.w_size = 0
+        self.w_index: Dict[str, Ref] = {}
+        self.g_imgs: List[Tuple[int, List[np.ndarray]]] = []                 # (offset, param-index images) of gradient entries
+        self.g_size = 0
+        self.fwd: list = []
+        self.bwd: list = []
+        self.tape: List[Callable[[], None]] = []
+        self.flops_fwd = 0
+        self.flops_bwd = 0
+        self.emit = self.fwd                                                  # the list ops are appended to
+
+    # ---- arenas ------------------------------------------------------------------------------------
+    def alloc(self, nfloats: int) -> Ref:
+        ref = Ref("a", self.a_size)
+        self.a_size += nfloats + ((-nfloats) % ALIGN)
+        return ref
+
+    def act(self, F: int, C: int, needs_grad: bool = True) -> TVar:
+        return TVar(self.alloc(self.B * self.T * F * C), F, C, Slot(), needs_grad)
+
+    def idx(self, key: str) -> np.ndarray:
+        s = self.specs[key]
+        return (self.poff[key] + np.arange(int(np.prod(s.shape)), dtype=np.int64)).reshape(s.shape)
+
+    def wadd(self, name: str, img: np.ndarray, img2: Optional[np.ndarray] = None) -> Ref:
+        """packed parameter operand: value[i] = flat[img[i]] (+ flat[img2[i]]), -1 = 0"""
+        if name in self.w_index:
+            return self.w_index[name]
+        flat = np.ascontiguousarray(img, dtype=np.int64).reshape(-1)
+        pad = (-flat.size) % ALIGN
+        ref = Ref("w", self.w_size)
+        f2 = None if img2 is None else np.ascontiguousarray(img2, dtype=np.int64).reshape(-1)
+        self.w_imgs.append((np.concatenate([flat, np.full(pad, -1, np.int64)]),
+                            None if f2 is None else np.concatenate([f2, np.full(pad, -1, np.int64)])))
+        self.w_size += flat.size + pad
+        self.w_index[name] = ref
+        return ref
+
+    def gadd(self, imgs: Sequence[np.ndarray]) -> Ref:
+        """gradient entry shaped like imgs[0]; element i is the gradient of flat[img[i]] for every image (-1: discarded)"""
+        flats = [np.ascontiguousarray(m, dtype=np.int64).reshape(-1) for m in imgs]
+        n = flats[0].size
+        assert all(f.size == n for f in flats)
+        ref = Ref("g", self.g_size)
+        self.g_imgs.append((self.g_size, flats))
+        self.g_size += n + ((-n) % ALIGN)
+        return ref
+
+    def vec(self, key: str) -> Ref:
+        return self.wadd(key, self.idx(key))
+
+    def gvec(self, key: str) -> Ref:
+        return self.gadd([self.idx(key)])
+
+    # ---- gradient bookkeeping ------------------------------------------------------------------------
+    def contribute(self, var: TVar, ref: Ref) -> None:
+        """grad(var) += tensor at `ref` (same shape), emitted into the backward list"""
+        if not var.needs_grad:
+            return
+        s = var.slot
+        n = self.B * self.T * var.F * var.C
+        if s.ref is None:
+            s.ref, s.owned = ref, False                          # alias: nobody may write into it
+            return
+        dst = s.ref if s.owned else self.alloc(n)
+        self.bwd.append(GenOp(OP_ADD, [s.ref, ref, dst], list(_split64(n)), name="grad+="))
+        s.ref, s.owned = dst, True
+
+    def grad_target(self, var: TVar) -> Tuple[Ref, Optional[Ref]]:
+        """(dst, aux) for a kernel that can compute dst = contribution + aux (aux None: plain store)"""
+        s = var.slot
+        n = self.B * self.T * var.F * var.C
+        if s.ref is None:
+            s.ref, s.owned = self.alloc(n), True
+            return s.ref, None
+        if s.owned:
+            return s.ref, s.ref
+        old = s.ref
+        s.ref, s.owned = self.alloc(n), True
+        return s.ref, old
+
+    def grad_of(self, var: TVar) -> Ref:
+        assert var.slot.ref is not None, "backward reached a tensor nobody differentiated"
+        return var.slot.ref
+
+    # ---- convolution machinery --------------------------------------------------------------------------
+    def pick_bm(self, No: int) -> int:
+        return 128 if self.B * conv_tiles(self.T, No, 128) >= 2 * prg.CUS else 64
+
+    @staticmethod
+    def pack_taps_idx(w_nck: np.ndarray, taps_k: Sequence[int]) -> np.ndarray:
+        N, Cc, _ = w_nck.shape
+        upt = (Cc + 15) // 16
+        out = np.full((N, len(taps_k), upt * 16), -1, dtype=np.int64)
+        for j, k in enumerate(taps_k):
+            out[:, j, :Cc] = w_nck[:, :, k]
+        return out.reshape(N, -1)
+
+    def conv_op(self, name, srcs: Sequence[TVar], w: Ref, bias: Optional[Ref], N: int, Kpad: int, Fin: int, Fout: int, No: int,
+                ostride: int, ophase: int, istride: int, dt, ioff, epi: int, dst: Ref, Cout: int, stats=None, stat_tiles=0,
+                stat_tile0=0, bm=None, aux=None, dst_acc=None, glu_dump=None) -> prg.ConvOp:
+        s0, s1 = srcs[0], (srcs[1] if len(srcs) > 1 else None)
+        bm = bm or self.pick_bm(No)
+        op = prg.ConvOp(src0=s0.ref, src1=s1.ref if s1 else None, xf0=None, xf1=None, slope0=None, slope1=None,
+                        C0=s0.C, C1=s1.C if s1 else 0, xf_mode=prg.XF_NONE, w=w, bias=bias, N=N, Kpad=Kpad, B=self.B, T=self.T,
+                        Fin=Fin, Fout=Fout, No=No, ostride=ostride, ophase=ophase, istride=istride, dt=list(dt), ioff=list(ioff),
+                        epi=epi, aux=aux, dst=dst, dst_acc=dst_acc, Cout=Cout, stats=stats, nsets=1 if stats else 0,
+                        stat_slope0=None, stat_slope1=None, stat_tiles=stat_tiles, stat_tile0=stat_tile0, bm=bm, name=name)
+        op.glu_dump = glu_dump
+        self.emit.append(op)
+        fl = 2 * self.B * self.T * No * N * len(dt) * (s0.C + (s1.C if s1 else 0))
+        if self.emit is self.fwd:
+            self.flops_fwd += fl
+        else:
+            self.flops_bwd += fl
+        return op
+
+    def wgrad_op(self, name, dz: Ref, N: int, Fz: int, srcs: Sequence[TVar], No, ostride, ophase, istride, dt, ioff, gimg) -> None:
+        s0, s1 = srcs[0], (srcs[1] if len(srcs) > 1 else None)
+        Ctot = s0.C + (s1.C if s1 else 0)
+        Kpad = len(dt) * ((Ctot + 15) // 16) * 16
+        assert tuple(gimg.shape) == (N, Kpad), (gimg.shape, N, Kpad)
+        self.bwd.append(WgradOp(dz=dz, src0=s0.ref, src1=s1.ref if s1 else None, dw=self.gadd([gimg]), N=N, C0=s0.C,
+                                C1=s1.C if s1 else 0, Kpad=Kpad, B=self.B, T=self.T, Fin=s0.F, Fz=Fz, No=No, ostride=ostride,
+                                ophase=ophase, istride=istride, dt=list(dt), ioff=list(ioff), name=name))
+        self.flops_bwd += 2 * self.B * self.T * No * N * len(dt) * Ctot
+
+    def colsum(self, name, x: Ref, rows: int, N: int, imgs: Sequence[np.ndarray]) -> None:
+        self.bwd.append(GenOp(OP_COLSUM, [x, self.gadd(imgs)], list(_split64(rows)) + [N], name=name))
+
+    def dgrad(self, name: str, var: TVar, dz: Ref, Kd: int, Fz: int, launches: Sequence[tuple]) -> None:
+        """grad(var) (+)= conv(dz; w) with the forward kernel on the gradient tensor dz [B][T][Fz][Kd]; `launches` =
+        (w, No, ostride, ophase, istride, dt, ioff) per launch -- the launches of one call write disjoint output
+        columns and share the accumulate operand."""
+        if not var.needs_grad or not launches:
+            return
+        dst, aux = self.grad_target(var)
+        src = TVar(dz, Fz, Kd)
+        self.emit = self.bwd
+        for k, (w, No, ostride, ophase, istride, dt, ioff) in enumerate(launches):
+            self.conv_op(f"{name}.{k}", [src], w, None, var.C, len(dt) * ((Kd + 15) // 16) * 16, Fz, var.F, No, ostride, ophase,
+                         istride, dt, ioff, prg.EPI_ADD if aux is not None else prg.EPI_LINEAR, dst, var.C, aux=aux)
+        self.emit = self.fwd
+
+    # ---- norm + activation ---------------------------------------------------------------------------------
+    def norm_act(self, name: str, raw: TVar, norm: str, act: str, mode: int, xf: Ref, mr: Ref, add: Optional[TVar] = None) -> TVar:
+        """a = f(raw) [+ add]; records the backward (norm/PReLU gradients, dparams)"""
+        out = self.act(raw.F, raw.C)
+        P = self.T * raw.F
+        gam, bet, slp = self.vec(f"{norm}.norm.weight"), self.vec(f"{norm}.norm.bias"), self.vec(f"{act}.weight")
+        self.fwd.append(GenOp(OP_TR_NORM_ACT, [raw.ref, xf, slp, add.ref if add else None, out.ref], [self.B, P, raw.C, mode],
+                              name=name))
+
+        def back():
+            d = self.grad_of(out)
+            if add is not None:
+                self.contribute(add, d)
+            dst, aux = self.grad_target(raw)
+            sums = self.alloc(self.B * raw.C * 4)
+            self.bwd.append(GenOp(OP_NORM_BWD, [d, raw.ref, mr, gam, bet, slp, sums, aux, dst, self.gvec(f"{norm}.norm.weight"),
+                                                self.gvec(f"{norm}.norm.bias"), self.gvec(f"{act}.weight")],
+                                  [self.B, P, raw.C, mode], name=name + ".bwd"))
+        self.tape.append(back)
+        return out
+
+    def finalize(self, name: str, stats: Ref, C: int, tiles: int, count: int, norm: str) -> Tuple[Ref, Ref]:
+        xf, mr = self.alloc(self.B * C * 2), self.alloc(self.B * C * 2)
+        op = prg.FinalizeOp(stats=stats, B=self.B, C=C, nsets=1, stat_tiles=tiles, count=count, eps=EPS_IN,
+                            gamma0=self.vec(f"{norm}.norm.weight"), beta0=self.vec(f"{norm}.norm.bias"), xf0=xf, name=name)
+        op.mr0 = mr
+        self.fwd.append(op)
+        return xf, mr
+
+    # ---- 2-D units -----------------------------------------------------------------------------------------
+    def conv2d_fwd(self, name: str, srcs: Sequence[TVar], wkey: str, glu: bool, norm: str, act: str,
+                   in_perm: Optional[np.ndarray] = None, add: Optional[TVar] = None) -> TVar:
+        """Strided causal Conv2d (+GLU) + InstanceNorm + PReLU (GateConv2d EaBNet.py:434-460 / Conv2dunit :391-407)."""
+        wi = self.idx(f"{wkey}.weight")                                      # (N, Cin, kt, kf) flat indices
+        N, Cin, kt, kf = wi.shape
+        if in_perm is not None:
+            wi = wi[:, in_perm]
+        Fin = srcs[0].F
+        Fout = (Fin - kf) // 2 + 1
+        order = glu_row_order(N) if glu else np.arange(N)
+        taps = [(a, c) for a in range(kt) for c in range(kf)]
+        wimg = self.pack_taps_idx(wi.reshape(N, Cin, kt * kf)[order], [a * kf + c for a, c in taps])
+        bimg = self.idx(f"{wkey}.bias")[order]
+        Cout = N // 2 if glu else N
+        raw = self.act(Fout, Cout)
+        bm = self.pick_bm(Fout)
+        tiles = conv_tiles(self.T, Fout, bm)
+        stats = self.alloc(self.B * tiles * Cout * 4)
+        dump = self.alloc(self.B * self.T * Fout * N) if glu else None
+        dts, ios = [a - (kt - 1) for a, _ in taps], [c for _, c in taps]
+        self.conv_op(name, srcs, self.wadd(f"{wkey}.w", wimg), self.wadd(f"{wkey}.b", bimg), N, wimg.shape[1], Fin, Fout, Fout, 1, 0,
+                     2, dts, ios, prg.EPI_GLU if glu else prg.EPI_LINEAR, raw.ref, Cout, stats, tiles, 0, bm, glu_dump=dump)
+        xf, mr = self.finalize(name + ".in", stats, Cout, tiles, self.T * Fout, norm)
+        rows = self.B * self.T * Fout
+
+        def back():
+            dr = self.grad_of(raw)
+            if glu:
+                dz = self.alloc(rows * N)
+                self.bwd.append(GenOp(OP_GLU_BWD, [dr, dump, dz], list(_split64(rows)) + [N], name=name + ".glu_bwd"))
+            else:
+                dz = dr
+            self.colsum(name + ".db", dz, rows, N, [bimg])
+            self.wgrad_op(name + ".wgrad", dz, N, Fout, srcs, Fout, 1, 0, 2, dts, ios, wimg)
+            # dgrad: per source, per input-column parity p:  dx[t'][2o'+p] = sum_{a, c = p, p+2, ..} W[:, ci, a, c]^T dz[t'+(kt-1)-a][o' - (c-p)/2]
+            c_lo = 0
+            for s in srcs:
+                launches = []
+                for p in (0, 1):
+                    tp = [(a, c) for a in range(kt) for c in range(p, kf, 2)]
+                    No = (Fin - p + 1) // 2
+                    if No <= 0 or not tp:
+                        continue
+                    wd = wi[order][:, c_lo:c_lo + s.C]                       # (N packed, C_s, kt, kf)
+                    img = self.pack_taps_idx(np.ascontiguousarray(wd.transpose(1, 0, 2, 3)).reshape(s.C, N, kt * kf),
+                                             [a * kf + c for a, c in tp])
+                    launches.append((self.wadd(f"{wkey}.wd.{c_lo}.{p}", img), No, 2, p, 1,
+                                     [(kt - 1) - a for a, _ in tp], [-(c - p) // 2 for _, c in tp]))
+                self.dgrad(f"{name}.dgrad", s, dz, N, Fout, launches)
+                c_lo += s.C
+        self.tape.append(back)          # before the norm/PReLU closure on the tape = after it in the backward
+        return self.norm_act(name + ".act", raw, norm, act, XF_NORM_PRELU, xf, mr, add)
+
+    def conv2d_transposed(self, name: str, srcs: Sequence[TVar], wkey: str, glu: bool, norm: str, act: str,
+                          add: Optional[TVar] = None) -> TVar:
+        """ConvTranspose2d (+chomp, +GLU) + InstanceNorm + PReLU as two gather-form launches (program.py), EaBNet.py:463-490, 410-431."""
+        wi = self.idx(f"{wkey}.weight")                                      # (Cin, N, kt, kf)
+        Cin, N, kt, kf = wi.shape
+        assert Cin == sum(s.C for s in srcs)
+        Fin = srcs[0].F
+        Fout = (Fin - 1) * 2 + kf
+        order = glu_row_order(N) if glu else np.arange(N)
+        wn = np.ascontiguousarray(wi.transpose(1, 0, 2, 3)).reshape(N, Cin, kt * kf)[order]
+        bimg = self.idx(f"{wkey}.bias")[order]
+        bref = self.wadd(f"{wkey}.b", bimg)
+        Cout = N // 2 if glu else N
+        raw = self.act(Fout, Cout)
+        Nos = [(Fout + 1) // 2, Fout // 2]
+        bm = self.pick_bm(Nos[0])
+        tiles = [conv_tiles(self.T, n, bm) for n in Nos]
+        stats = self.alloc(self.B * sum(tiles) * Cout * 4)
+        dump = self.alloc(self.B * self.T * Fout * N) if glu else None
+        phases = []
+        for ph in (0, 1):
+            tp = [(a, c) for a in range(kt) for c in range(ph, kf, 2)]
+            wimg = self.pack_taps_idx(wn, [a * kf + c for a, c in tp])
+            dts, ios = [-a for a, _ in tp], [-(c - ph) // 2 for _, c in tp]
+            self.conv_op(f"{name}.ph{ph}", srcs, self.wadd(f"{wkey}.w.ph{ph}", wimg), bref, N, wimg.shape[1], Fin, Fout, Nos[ph], 2, ph,
+                         1, dts, ios, prg.EPI_GLU if glu else prg.EPI_LINEAR, raw.ref, Cout, stats, sum(tiles),
+                         0 if ph == 0 else tiles[0], bm, glu_dump=dump)
+            phases.append((ph, dts, ios, wimg))
+        xf, mr = self.finalize(name + ".in", stats, Cout, sum(tiles), self.T * Fout, norm)
+        rows = self.B * self.T * Fout
+
+        def back():
+            dr = self.grad_of(raw)
+            if glu:
+                dz = self.alloc(rows * N)
+                self.bwd.append(GenOp(OP_GLU_BWD, [dr, dump, dz], list(_split64(rows)) + [N], name=name + ".glu_bwd"))
+            else:
+                dz = dr
+            self.colsum(name + ".db", dz, rows, N, [bimg])
+            for ph, dts, ios, wimg in phases:
+                self.wgrad_op(f"{name}.wgrad{ph}", dz, N, Fout, srcs, Nos[ph], 2, ph, 1, dts, ios, wimg)
+            # dgrad: a strided convolution over dz:  dx[t'][f] = sum_{a, c} W[ci, :, a, c] dz[t'+a][2f + c]
+            taps = [(a, c) for a in range(kt) for c in range(kf)]
+            c_lo = 0
+            for s in srcs:
+                wd = wi[c_lo:c_lo + s.C][:, order]                           # (C_s, N packed, kt, kf)
+                img = self.pack_taps_idx(wd.reshape(s.C, N, kt * kf), [a * kf + c for a, c in taps])
+                self.dgrad(f"{name}.dgrad", s, dz, N, Fout, [(self.wadd(f"{wkey}.wd.{c_lo}", img), Fin, 1, 0, 2,
+                                                              [a for a, _ in taps], [c for _, c in taps])])
+                c_lo += s.C
+        self.tape.append(back)
+        return self.norm_act(name + ".act", raw, norm, act, XF_NORM_PRELU, xf, mr, add)
+
+    def unet_module(self, pre: str, srcs: Sequence[TVar], scale: int, transposed: bool, in_perm=None) -> TVar:
+        """En_unet_module.forward (EaBNet.py:372-388): the residual add is fused into the last norm+PReLU."""
+        if transposed:
+            g = self.conv2d_transposed(f"{pre}.in_conv", srcs, f"{pre}.in_conv.0.conv.0", True, f"{pre}.in_conv.1", f"{pre}.in_conv.2")
+        else:
+            g = self.conv2d_fwd(f"{pre}.in_conv", srcs, f"{pre}.in_conv.0.conv.1", True, f"{pre}.in_conv.1", f"{pre}.in_conv.2", in_perm)
+        y, downs = g, []
+        for j in range(scale):
+            q = f"{pre}.enco.{j}.conv"
+            y = self.conv2d_fwd(q, [y], f"{q}.0", False, f"{q}.1", f"{q}.2")
+            downs.append(y)
+        for j in range(scale):
+            q = f"{pre}.deco.{j}.deconv"
+            ins = [y] if j == 0 else [y, downs[-(j + 1)]]
+            y = self.conv2d_transposed(q, ins, f"{q}.0", False, f"{q}.1", f"{q}.2", add=g if j == scale - 1 else None)
+        return y
+
+    # ---- 1-D units (S-TCM, Linear) -------------------------------------------------------------------------
+    def conv1d(self, name: str, src: TVar, wimg_nck: np.ndarray, dts: Sequence[int], bimg: Optional[np.ndarray], epi: int,
+               aux: Optional[TVar] = None, dst_acc: Optional[Ref] = None, wname: str = "") -> Tuple[TVar, Callable[[Ref], None]]:
+        """out[t] = sum_j W[:, :, j] src[t + dts[j]] (+ bias) with epilogue LINEAR / RELU / ADD(aux).  Returns the output
+        and a function that, given the gradient w.r.t. the pre-epilogue sum, emits wgrad / dbias / dgrad."""
+        N, Cc, K = wimg_nck.shape
+        wimg = self.pack_taps_idx(wimg_nck, range(K))
+        out = self.act(1, N)
+        wref = self.wadd(wname + ".w", wimg)
+        bref = self.wadd(wname + ".b", bimg) if bimg is not None else None
+        self.conv_op(name, [src], wref, bref, N, wimg.shape[1], 1, 1, 1, 1, 0, 1, list(dts), [0] * K, epi, out.ref, N, bm=64,
+                     aux=aux.ref if aux is not None else None, dst_acc=dst_acc)
+        rows = self.B * self.T
+
+        def back(dz: Ref):
+            if bimg is not None:
+                self.colsum(name + ".db", dz, rows, N, [bimg])
+            self.wgrad_op(name + ".wgrad", dz, N, 1, [src], 1, 1, 0, 1, list(dts), [0] * K, wimg)
+            img = self.pack_taps_idx(np.ascontiguousarray(wimg_nck.transpose(1, 0, 2)), range(K))      # (Cc, N, K)
+            self.dgrad(name + ".dgrad", src, dz, N, 1, [(self.wadd(wname + ".wd", img), 1, 1, 0, 1, [-d for d in dts], [0] * K)])
+        return out, back
+
+    def in1d(self, name: str, raw: TVar, norm: str, act: str) -> TVar:
+        """prelu -> InstanceNorm1d (S-TCM order, EaBNet.py:545-547): statistics by a stand-alone kernel"""
+        xf, mr = self.alloc(self.B * raw.C * 2), self.alloc(self.B * raw.C * 2)
+        self.fwd.append(GenOp(OP_IN_STATS, [raw.ref, self.vec(f"{act}.weight"), self.vec(f"{norm}.norm.weight"),
+                                            self.vec(f"{norm}.norm.bias"), xf, mr], [self.B, self.T * raw.F, raw.C], [EPS_IN],
+                              name=name + ".stats"))
+        return self.norm_act(name, raw, norm, act, XF_PRELU_NORM, xf, mr)
+
+    def tcm(self, pre: str, x: TVar, dilation: int, x_acc: Optional[Ref], perm: np.ndarray) -> TVar:
+        """SqueezedTCM.forward, EaBNet.py:572-578.  The closures go on the tape in forward order (they bind their
+        operands late): in_conv | left norm | right norm | branch convs + gate | out norm | out_conv."""
+        cfg = self.cfg
+        kd = cfg.kd1
+        n = self.B * self.T * cfg.cd1
+        w_in = self.idx(f"{pre}.in_conv.weight")[:, perm, :]                 # (cd, D, 1)
+        y, back_in = self.conv1d(f"{pre}.in_conv", x, w_in, [0], None, prg.EPI_LINEAR, wname=f"{pre}.in_conv")
+        self.tape.append(lambda: back_in(self.grad_of(y)))
+        yL = self.in1d(f"{pre}.left", y, f"{pre}.left_conv.1", f"{pre}.left_conv.0")
+        yR = self.in1d(f"{pre}.right", y, f"{pre}.right_conv.1", f"{pre}.right_conv.0")
+        span = (kd - 1) * dilation
+        lead = span if cfg.is_causal else span // 2
+        dts = [j * dilation - lead for j in range(kd)]
+        a, back_l = self.conv1d(f"{pre}.left_conv", yL, self.idx(f"{pre}.left_conv.3.weight"), dts, None, prg.EPI_LINEAR,
+                                wname=f"{pre}.left_conv")
+        r, back_r = self.conv1d(f"{pre}.right_conv", yR, self.idx(f"{pre}.right_conv.3.weight"), dts, None, prg.EPI_LINEAR,
+                                wname=f"{pre}.right_conv")
+        z = self.act(1, cfg.cd1)
+        self.fwd.append(GenOp(OP_GATE_FWD, [a.ref, r.ref, z.ref], list(_split64(n)), name=f"{pre}.gate"))
+
+        def back_gate():
+            da, dr = self.alloc(n), self.alloc(n)
+            self.bwd.append(GenOp(OP_GATE_BWD, [self.grad_of(z), a.ref, r.ref, da, dr], list(_split64(n)), name=f"{pre}.gate_bwd"))
+            back_l(da)
+            back_r(dr)
+        self.tape.append(back_gate)
+        zo = self.in1d(f"{pre}.out", z, f"{pre}.out_conv.1", f"{pre}.out_conv.0")
+        w_out = self.idx(f"{pre}.out_conv.2.weight")[perm]                   # (D, cd, 1), rows permuted
+        out, back_out = self.conv1d(f"{pre}.out_conv", zo, w_out, [0], None, prg.EPI_ADD, aux=x, dst_acc=x_acc,
+                                    wname=f"{pre}.out_conv")
+
+        def back():
+            d = self.grad_of(out)
+            self.contribute(x, d)                                            # residual
+            back_out(d)
+        self.tape.append(back)
+        return out
+
+    # ---- whole network -----------------------------------------------------------------------------------------
+    def build(self) -> "TrainProgram":
+        cfg, B, T, F = self.cfg, self.B, self.T, self.F
+        M, c = cfg.M, cfg.c
+        x_in = TVar(Ref("in"), F, 2 * M, Slot(), needs_grad=False)
+        mem = np.arange(2 * M)
+        in_perm = (mem % 2) * M + mem // 2                                   # memory channel m*2+ri <- reference ri*M+m
+        skips: List[TVar] = []
+        x = x_in
+        for i in range(4):
+            x = self.unet_module(f"en.meta_unet_list.{i}", [x], 4 - i, False, in_perm if i == 0 else None)
+            skips.append(x)
+        x = self.conv2d_fwd("en.last_conv", [x], "en.last_conv.0.conv.1", True, "en.last_conv.1", "en.last_conv.2")
+        skips.append(x)
+        Fb = x.F
+        assert Fb * x.C == cfg.d_feat
+        k = np.arange(cfg.d_feat)
+        perm = (k % c) * Fb + k // c                                         # memory channel f*64+c <- reference c*4+f
+        xt = x.view(1, cfg.d_feat)
+        x_acc = self.act(1, cfg.d_feat)
+        self.fwd.append(prg.MemsetOp(x_acc.ref, B * T * cfg.d_feat, name="stcns.acc0"))
+        lasts = []
+        for gi in range(cfg.q):
+            for i in range(cfg.p):
+                xt = self.tcm(f"stcns.{gi}.tcm_list.{i}", xt, 2 ** i, x_acc.ref if i == cfg.p - 1 else None, perm)
+            lasts.append(xt)
+
+        def back_acc():                                                      # x_acc = sum of the group outputs (EaBNet.py:101-105)
+            d = self.grad_of(x_acc)
+            for v in lasts:
+                self.contribute(v, d)
+        # the group outputs are produced before x_acc is complete, but every consumer of x_acc comes later:
+        # running this first in the backward hands d(x_acc) to the three group outputs before their own closures
+        self.tape.append(back_acc)
+        x = x_acc.view(Fb, c)
+        for i in range(4):
+            x = self.unet_module(f"de.meta_unet_list.{i}", [x, skips[-(i + 1)]], i + 1, True)
+        e = self.conv2d_transposed("de.last_conv", [x, skips[0]], "de.last_conv.0.conv.0", True, "de.last_conv.1", "de.last_conv.2")
+        assert e.F == F and e.C == 64
+
+        # ---- LSTM_BF (EaBNet.py:600-614), unfused
+        rows = B * T * F
+        x_ln, mr_ln = self.act(F, 64), self.alloc(rows * 2)
+        lg, lb = self.vec("bf_map.norm.weight"), self.vec("bf_map.norm.bias")
+        self.fwd.append(GenOp(OP_LN_FWD, [e.ref, lg, lb, x_ln.ref, mr_ln], list(_split64(rows)), [EPS_LN], name="bf_map.norm"))
+        h_in, layers = x_ln, []
+        for nm in ("rnn1", "rnn2"):
+            p = f"bf_map.{nm}"
+            wcat_img = np.concatenate([self.idx(f"{p}.weight_ih_l0"), self.idx(f"{p}.weight_hh_l0")], axis=1)
+            wcat = self.wadd(f"{p}.wcat", wcat_img)
+            bias = self.wadd(f"{p}.bias", self.idx(f"{p}.bias_ih_l0"), self.idx(f"{p}.bias_hh_l0"))
+            h, gates = self.act(F, 64), self.alloc(rows * 5 * 64)
+            self.fwd.append(GenOp(OP_LSTM_TRAIN, [h_in.ref, wcat, bias, h.ref, gates], [B, T, F], name=p))
+            self.flops_fwd += 2 * rows * 256 * 128
+            layers.append((p, h_in, h, gates, wcat))
+            h_in = h
+        h2 = h_in
+        # w_dnn: Linear 64->64 + ReLU, Linear 64->2M (rows padded to one 64-column tile), then the filter-and-sum
+        w1 = self.idx("bf_map.w_dnn.0.weight")[:, :, None]
+        y1 = self.act(F, 64)
+        w1img = self.pack_taps_idx(w1, [0])
+        b1img = self.idx("bf_map.w_dnn.0.bias")
+        self.conv_op("bf_map.w_dnn.0", [h2], self.wadd("w_dnn.0.w", w1img), self.wadd("w_dnn.0.b", b1img), 64, 64, F, F, F, 1, 0, 1,
+                     [0], [0], prg.EPI_RELU, y1.ref, 64)
+        w2 = np.full((MLP_LD, 64, 1), -1, np.int64)
+        w2[:2 * M] = self.idx("bf_map.w_dnn.2.weight")[:, :, None]
+        b2img = np.full(MLP_LD, -1, np.int64)
+        b2img[:2 * M] = self.idx("bf_map.w_dnn.2.bias")
+        w2img = self.pack_taps_idx(w2, [0])
+        bw = self.act(F, MLP_LD)
+        self.conv_op("bf_map.w_dnn.2", [y1], self.wadd("w_dnn.2.w", w2img), self.wadd("w_dnn.2.b", b2img), MLP_LD, 64, F, F, F, 1, 0,
+                     1, [0], [0], prg.EPI_LINEAR, bw.ref, MLP_LD)
+        self.fwd.append(GenOp(OP_FILTER_SUM, [bw.ref, Ref("in"), Ref("out")], [B, T, F, M, MLP_LD], name="filter_sum"))
+
+        def back_head():
+            dbw = self.alloc(rows * MLP_LD)
+            self.bwd.append(GenOp(OP_FS_BWD, [Ref("dout"), Ref("in"), dbw], [B, T, F, M, MLP_LD], name="filter_sum.bwd"))
+            self.colsum("w_dnn.2.db", dbw, rows, MLP_LD, [b2img])
+            self.wgrad_op("w_dnn.2.wgrad", dbw, MLP_LD, F, [y1], F, 1, 0, 1, [0], [0], w2img)
+            dy1 = self.alloc(rows * 64)
+            src = TVar(dbw, F, MLP_LD)
+            self.emit = self.bwd
+            w2d = self.pack_taps_idx(np.ascontiguousarray(w2.transpose(1, 0, 2)), [0])          # (64 y1-channels, 64 padded rows)
+            self.conv_op("w_dnn.2.dgrad", [src], self.wadd("w_dnn.2.wd", w2d), None, 64, 64, F, F, F, 1, 0, 1, [0], [0],
+                         prg.EPI_LINEAR, dy1, 64)
+            self.emit = self.fwd
+            dpre = self.alloc(rows * 64)
+            self.bwd.append(GenOp(OP_RELU_BWD, [dy1, y1.ref, dpre], list(_split64(rows * 64)), name="w_dnn.relu_bwd"))
+            self.colsum("w_dnn.0.db", dpre, rows, 64, [b1img])
+            self.wgrad_op("w_dnn.0.wgrad", dpre, 64, F, [h2], F, 1, 0, 1, [0], [0], w1img)
+            w1d = self.pack_taps_idx(np.ascontiguousarray(w1.transpose(1, 0, 2)), [0])
+            self.dgrad("w_dnn.0.dgrad", h2, dpre, 64, F, [(self.wadd("w_dnn.0.wd", w1d), F, 1, 0, 1, [0], [0])])
+            for p, hin, h, gates, wcat in reversed(layers):
+                dg = self.alloc(rows * 256)
+                self.bwd.append(GenOp(OP_LSTM_BWD, [gates, self.grad_of(h), wcat, dg], [B, T, F], name=p + ".bwd"))
+                self.flops_bwd += 2 * rows * 256 * 64
+                self.colsum(p + ".db", dg, rows, 256, [self.idx(f"{p}.bias_ih_l0"), self.idx(f"{p}.bias_hh_l0")])
+                self.wgrad_op(p + ".wgrad_ih", dg, 256, F, [hin], F, 1, 0, 1, [0], [0], self.idx(f"{p}.weight_ih_l0"))
+                self.wgrad_op(p + ".wgrad_hh", dg, 256, F, [h], F, 1, 0, 1, [-1], [0], self.idx(f"{p}.weight_hh_l0"))
+                wih_d = self.pack_taps_idx(np.ascontiguousarray(self.idx(f"{p}.weight_ih_l0").T)[:, :, None], [0])   # (64, 256)
+                self.dgrad(p + ".dgrad", hin, dg, 256, F, [(self.wadd(p + ".wd", wih_d), F, 1, 0, 1, [0], [0])])
+            de = self.alloc(rows * 64)
+            self.bwd.append(GenOp(OP_LN_BWD, [self.grad_of(x_ln), e.ref, mr_ln, lg, de, self.gvec("bf_map.norm.weight"),
+                                              self.gvec("bf_map.norm.bias")], list(_split64(rows)), name="bf_map.norm.bwd"))
+            self.contribute(e, de)
+        self.tape.append(back_head)
+
+        # ---- backward: replay the tape in reverse
+        for fn in reversed(self.tape):
+            fn()
+        return self.finish()
+
+    def finish(self) -> "TrainProgram":
+        ia = np.concatenate([a for a, _ in self.w_imgs]).astype(np.int32)
+        has_b = any(b is not None for _, b in self.w_imgs)
+        ib = np.concatenate([(b if b is not None else np.full(a.size, -1, np.int64)) for a, b in self.w_imgs]).astype(np.int32) \
+            if has_b else None
+        inv = np.full(self.n_params, -1, np.int64)
+        for off, flats in self.g_imgs:
+            for fl in flats:
+                m = fl >= 0
+                tgt = fl[m]
+                assert (inv[tgt] == -1).all(), "a parameter element received two gradient entries"
+                inv[tgt] = off + np.nonzero(m)[0]
+        return TrainProgram(cfg=self.cfg, B=self.B, T=self.T, F=self.F, fwd=self.fwd, bwd=self.bwd, a_floats=self.a_size,
+                            w_floats=self.w_size, g_floats=self.g_size, ia=ia, ib=ib, inv=inv.astype(np.int32),
+                            n_params=self.n_params, keys=list(self.specs), shapes=[tuple(s.shape) for s in self.specs.values()],
+                            flops_fwd=self.flops_fwd, flops_bwd=self.flops_bwd)
+
+
+@dataclass
+class TrainProgram:
+    cfg: NetConfig
+    B: int
+    T: int
+    F: int
+    fwd: list
+    bwd: list
+    a_floats: int
+    w_floats: int
+    g_floats: int
+    ia: np.ndarray
+    ib: Optional[np.ndarray]
+    inv: np.ndarray
+    n_params: int
+    keys: List[str]
+    shapes: List[tuple]
+    flops_fwd: int = 0
+    flops_bwd: int = 0
+
+
+def lower_train(cfg: NetConfig, B: int, T: int, F: int = 161) -> TrainProgram:
+    return TrainLowering(cfg, B, T, F).build()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# binding and execution
+# ----------------------------------------------------------------------------------------------------------------
+class TrainBound:
+    """Device arenas + the two ctypes op arrays of a lowered training program."""
+
+    def __init__(self, prog: TrainProgram, device: torch.device):
+        self.prog, self.device = prog, device
+        self.acts = torch.empty(max(prog.a_floats, 1), dtype=torch.float32, device=device)
+        self.w = torch.empty(max(prog.w_floats, 1), dtype=torch.float32, device=device)
+        self.g = torch.empty(max(prog.g_floats, 1), dtype=torch.float32, device=device)
+        self.ia = torch.from_numpy(prog.ia).to(device)
+        self.ib = torch.from_numpy(prog.ib).to(device) if prog.ib is not None else None
+        self.inv = torch.from_numpy(prog.inv).to(device)
+        self.fwd = (_lib.Op * len(prog.fwd))()
+        self.bwd = (_lib.Op * len(prog.bwd))()
+        self._bound = None
+
+    def bind(self, in_ptr: int, out_ptr: int, dout_ptr: int) -> None:
+        if self._bound == (in_ptr, out_ptr, dout_ptr):
+            return
+        bases = {"a": self.acts.data_ptr(), "w": self.w.data_ptr(), "g": self.g.data_ptr(), "in": in_ptr, "out": out_ptr,
+                 "dout": dout_ptr}
+
+        def A(r):
+            return None if r is None else bases[r.arena] + 4 * r.off
+        for ops, arr in ((self.prog.fwd, self.fwd), (self.prog.bwd, self.bwd)):
+            for k, op in enumerate(ops):
+                o = arr[k]
+                o.kind = op.kind
+                if op.kind == prg.OP_CONV:
+                    d = o.conv
+                    for f in ("src0", "src1", "xf0", "xf1", "slope0", "slope1", "w", "bias", "aux", "dst", "dst_acc", "stats",
+                              "stat_slope0", "stat_slope1", "fin_stats", "fin_gamma0", "fin_beta0", "fin_gamma1", "fin_beta1"):
+                        setattr(d, f, A(getattr(op, f)))
+                    d.glu_dump = A(getattr(op, "glu_dump", None))
+                    for f in ("C0", "C1", "xf_mode", "N", "Kpad", "B", "T", "Fin", "Fout", "No", "ostride", "ophase", "istride",
+                              "epi", "Cout", "nsets", "stat_tiles", "stat_tile0", "bm", "fin_tiles", "fin_nsets", "fin_count",
+                              "precision", "korder"):
+                        setattr(d, f, int(getattr(op, f)))
+                    d.fin_eps = float(op.fin_eps)
+                    d.ntaps = len(op.dt)
+                    for j in range(_lib.MAX_TAPS):
+                        d.dt[j] = op.dt[j] if j < len(op.dt) else 0
+                        d.ioff[j] = op.ioff[j] if j < len(op.ioff) else 0
+                elif op.kind == prg.OP_IN_FINALIZE:
+                    o.i[0:5] = [op.B, op.C, op.nsets, op.stat_tiles, op.count]
+                    o.f[0] = op.eps
+                    for j, r in enumerate((op.stats, op.gamma0, op.beta0, op.xf0, op.gamma1, op.beta1, op.xf1,
+                                           getattr(op, "mr0", None), None)):
+                        o.p[j] = A(r)
+                elif op.kind == prg.OP_MEMSET0:
+                    nbytes = 4 * op.nfloats
+                    o.i[0] = C.c_int32(nbytes & 0xFFFFFFFF).value
+                    o.i[1] = nbytes >> 32
+                    o.p[0] = A(op.ptr)
+                elif op.kind == OP_WGRAD:
+                    d = o.wgrad
+                    d.dz, d.src0, d.src1, d.dw = A(op.dz), A(op.src0), A(op.src1), A(op.dw)
+                    for f in ("N", "C0", "C1", "Kpad", "B", "T", "Fin", "Fz", "No", "ostride", "ophase", "istride"):
+                        setattr(d, f, int(getattr(op, f)))
+                    d.ntaps = len(op.dt)
+                    for j in range(_lib.MAX_TAPS):
+                        d.dt[j] = op.dt[j] if j < len(op.dt) else 0
+                        d.ioff[j] = op.ioff[j] if j < len(op.ioff) else 0
+                else:
+                    for j, r in enumerate(op.p):
+                        o.p[j] = A(r)
+                    for j, v in enumerate(op.i):
+                        o.i[j] = C.c_int32(int(v) & 0xFFFFFFFF).value if v > 0x7FFFFFFF else int(v)
+                    for j, v in enumerate(op.f):
+                        o.f[j] = float(v)
+        self._bound = (in_ptr, out_ptr, dout_ptr)
+
+    def run(self, which: str, stream: int, first: int = 0, count: Optional[int] = None) -> None:
+        arr = self.fwd if which == "fwd" else self.bwd
+        n = len(arr) - first if count is None else count
+        ops = C.cast(C.byref(arr, first * C.sizeof(_lib.Op)), C.POINTER(_lib.Op))
+        _lib.check(_lib.load().eab_run_program(ops, n, C.c_void_p(stream)), f"eab_run_program({which})")
+
+    def pack(self, flat: torch.Tensor, stream: int) -> None:
+        _lib.check(_lib.load().eab_gather_f32(flat.data_ptr(), self.ia.data_ptr(), self.ib.data_ptr() if self.ib is not None else None,
+                                              self.w.data_ptr(), self.prog.w_floats, C.c_void_p(stream)), "eab_gather_f32")
+
+    def unpack_grads(self, gflat: torch.Tensor, stream: int) -> None:
+        _lib.check(_lib.load().eab_gather_f32(self.g.data_ptr(), self.inv.data_ptr(), None, gflat.data_ptr(), self.prog.n_params,
+                                              C.c_void_p(stream)), "eab_gather_f32(grads)")
+
+
+class _EaBNetTrainFn(torch.autograd.Function):
+    """One autograd node for the whole network: forward program, backward program."""
+
+    @staticmethod
+    def forward(ctx, bound: TrainBound, x: torch.Tensor, *params: torch.Tensor) -> torch.Tensor:
+        prog = bound.prog
+        st = torch.cuda.current_stream().cuda_stream
+        flat = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in params])
+        out = torch.empty((prog.B, 2, prog.T, prog.F), dtype=torch.float32, device=x.device)
+        dout = torch.empty_like(out)
+        bound.bind(x.data_ptr(), out.data_ptr(), dout.data_ptr())
+        bound.pack(flat, st)
+        bound.run("fwd", st)
+        ctx.bound, ctx.x, ctx.dout, ctx.out = bound, x, dout, out
+        ctx.shapes = [p.shape for p in params]
+        ctx.dtypes = [p.dtype for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):
+        bound, prog = ctx.bound, ctx.bound.prog
+        st = torch.cuda.current_stream().cuda_stream
+        ctx.dout.copy_(grad_out.to(torch.float32))
+        bound.bind(ctx.x.data_ptr(), ctx.out.data_ptr(), ctx.dout.data_ptr())
+        bound.g.zero_()
+        bound.run("bwd", st)
+        gflat = torch.empty(prog.n_params, dtype=torch.float32, device=ctx.x.device)     # fresh per call: .grad may keep views of it
+        bound.unpack_grads(gflat, st)
+        grads, off = [], 0
+        for k, shp in enumerate(ctx.shapes):
+            n = int(np.prod(shp)) if len(shp) else 1
+            grads.append(gflat[off:off + n].view(shp).to(ctx.dtypes[k]) if ctx.needs_input_grad[2 + k] else None)
+            off += n
+        return (None, None, *grads)
+
+
+def forward_train(module, inpt: torch.Tensor) -> torch.Tensor:
+    """EaBNet.forward under autograd on the HIP training programs.  The gradient w.r.t. the input spectrogram is not
+    produced (the reference's training never needs it)."""
+    _lib.load()
+    B, T, F, M, _ = inpt.shape
+    x = inpt.detach().to(torch.float32).contiguous()
+    cache = module.__dict__.setdefault("_train_bound", {})
+    key = (B, T, F, str(x.device))
+    bound = cache.get(key)
+    if bound is None:
+        cache.clear()
+        with torch.cuda.device(x.device):
+            bound = cache[key] = TrainBound(lower_train(module.cfg, B, T, F), x.device)
+    sd = dict(module.named_parameters())
+    params = [sd[k] for k in bound.prog.keys]
+    with torch.cuda.device(x.device):
+        out = _EaBNetTrainFn.apply(bound, x, *params)
+    return out.to(inpt.dtype)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EAB_ABI_VERSION 2
+#define EAB_ABI_VERSION 3
 
 #define EAB_OK          0
 #define EAB_EINVAL      1   /* bad argument (shape, alignment, limit) */
@@ -236,6 +236,9 @@ typedef struct eab_conv_desc {
     /* streaming: restrict the launch to a window of time rows (see eab_time_window below);
      * needs stats == NULL, fin_stats == NULL and causal taps (dt <= 0) */
     eab_time_window win;
+    /* training (EAB_EPI_GLU only): optional [B][T][Fout][N] dump of the gated epilogue's two factors in the packed
+     * column order -- value columns hold acc+bias, gate columns hold sigmoid(acc+bias) -- read by eab_glu_bwd_f32 */
+    float* glu_dump;
 } eab_conv_desc;
 
 #define EAB_PREC_F32   0
@@ -317,13 +320,28 @@ int eab_bfw_filter_sum_f32(const float* y1, const float* w2, const float* b2, co
 #define EAB_OP_GAG_PACK    7
 #define EAB_OP_GAG_CRM     8
 
+/* geometry of a weight gradient (eab_wgrad_f32, documented with the training entry points below) */
+typedef struct eab_wgrad_desc {
+    const float* dz;        /* [B][T][Fz][N] */
+    const float* src0;      /* [B][T][Fin][C0] */
+    const float* src1;      /* [B][T][Fin][C1] or NULL */
+    float* dw;              /* [N][Kpad] */
+    int32_t N, C0, C1, Kpad;
+    int32_t B, T, Fin, Fz, No, ostride, ophase, istride;
+    int32_t ntaps;
+    int32_t dt[EAB_MAX_TAPS];
+    int32_t ioff[EAB_MAX_TAPS];
+    int32_t rows_per_wg;    /* set by the library */
+} eab_wgrad_desc;
+
 typedef struct eab_op {
     int32_t kind;
     int32_t i[8];
     float   f[2];
-    const void* p[10];
+    const void* p[12];
     eab_time_window win;    /* every kind except CONV (which carries it in conv.win) and IN_FINALIZE */
     eab_conv_desc conv;     /* EAB_OP_CONV only */
+    eab_wgrad_desc wgrad;   /* EAB_OP_WGRAD only */
 } eab_op;
 /* field use per kind:
  *  IN_FINALIZE i = {B, C, nsets, stat_tiles, count}       f = {eps}
@@ -359,9 +377,111 @@ int eab_mlp_bfw_filter_sum_f32(const float* h, const float* w1, const float* b1,
                                const float* x, float* out, float* bfw, int B, int T, int F, int M,
                                eab_time_window win, eab_stream_t stream);
 
+/* ==========================================================================================================
+ * Training: what autograd executes for train_distributed.py:221-228 (net(...), loss.backward())
+ * on the reference, as hand-written kernels.  The training forward materialises every normalised activation
+ * (convolutions take plain sources), keeps what the backward needs, and the backward is a second static op list.
+ * Contractions: dgrad = eab_conv_f32 on the gradient with re-packed weights (the strided convolution's dgrad is
+ * the gather form of a transposed convolution and vice versa), wgrad = eab_wgrad_f32.
+ * ========================================================================================================== */
+
+/* Parameter packing, one launch for the whole program: out[i] = flat[ia[i]] (+ flat[ib[i]] when ib != NULL); a
+ * negative index contributes 0.  Forward: flat parameter vector -> every packed operand; backward: packed
+ * gradient arena -> flat gradient (inverse table). */
+int eab_gather_f32(const float* flat, const int32_t* ia, const int32_t* ib, float* out, long long n, eab_stream_t stream);
+
+/* nn.InstanceNorm1d statistics of a materialised [B][P][C] tensor, optionally of prelu(x, slope) (S-TCM order,
+ * EaBNet.py:545-547,559-560): xf[b][c] = (gamma*rstd, beta - mean*gamma*rstd), mr[b][c] = (mean, rstd). */
+int eab_train_in_stats_f32(const float* x, const float* slope, int B, int P, int C, float eps, const float* gamma,
+                           const float* beta, float* xf, float* mr, eab_stream_t stream);
+/* eab_in_finalize_f32 that also emits mr0 / mr1 [B][C][2] = (mean, rstd) for the backward pass (NULL = skip) */
+int eab_in_finalize_mr_f32(const float* stats, int B, int C, int nsets, int stat_tiles, int count, float eps,
+                           const float* gamma0, const float* beta0, float* xf0, const float* gamma1,
+                           const float* beta1, float* xf1, float* mr0, float* mr1, eab_stream_t stream);
+/* y = f(x) [+ add], f = prelu(x*scale+shift) (mode EAB_XF_NORM_PRELU) or prelu(x)*scale+shift (EAB_XF_PRELU_NORM);
+ * x, add, y [B][P][C] */
+int eab_train_norm_act_f32(const float* x, const float* xf, const float* slope, const float* add, float* y, int B, int P,
+                           int C, int mode, eab_stream_t stream);
+/* Backward of y = f(x) through the InstanceNorm statistics (per (b, c) over P) and the PReLU:
+ *   dx = (acc_in ? acc_in : 0) + d loss / d x;   dgamma[c], dbeta[c], dslope[c] += their gradients.
+ * sums: scratch [B][C][4].  Reference: autograd of EaBNet.py:684-686 + nn.PReLU. */
+int eab_train_norm_bwd_f32(const float* dy, const float* x, const float* mr, const float* gamma, const float* beta,
+                           const float* slope, float* sums, const float* acc_in, float* dx, float* dgamma, float* dbeta,
+                           float* dslope, int B, int P, int C, int mode, eab_stream_t stream);
+/* GLU backward (EaBNet.py:459-460, 489-490): dy [rows][N/2], dump [rows][N] (eab_conv_desc.glu_dump) -> dz [rows][N]
+ * in the packed column order of the forward convolution */
+int eab_glu_bwd_f32(const float* dy, const float* dump, float* dz, long long rows, int N, eab_stream_t stream);
+/* S-TCM gate z = a*sigmoid(r) (EaBNet.py:575) and its backward; n floats, n % 4 == 0 */
+int eab_gate_fwd_f32(const float* a, const float* r, float* z, long long n, eab_stream_t stream);
+int eab_gate_bwd_f32(const float* dz, const float* a, const float* r, float* da, float* dr, long long n, eab_stream_t stream);
+int eab_add_f32(const float* a, const float* b, float* out, long long n, eab_stream_t stream);
+int eab_relu_bwd_f32(const float* dy, const float* y, float* dx, long long n, eab_stream_t stream);
+/* out[n] += sum over rows of x[row][n]  (bias gradients) */
+int eab_colsum_f32(const float* x, float* out, long long rows, int N, eab_stream_t stream);
+/* filter-and-sum with the weights in rows of `ld` floats (first 2M used; the training program keeps them in a
+ * 64-column tile), and d loss / d W (EaBNet.py:114-117): dout [B][2][T][F], x [B][T][F][M][2] -> dw [B][T][F][ld]
+ * (columns >= 2M zeroed) */
+int eab_filter_sum_ld_f32(const float* w, const float* x, float* y, int B, int T, int F, int M, int ld, eab_stream_t stream);
+int eab_filter_sum_bwd_f32(const float* dout, const float* x, float* dw, int B, int T, int F, int M, int ld, eab_stream_t stream);
+/* LayerNorm(64) (EaBNet.py:598,608) materialised with its (mean, rstd) per row, and its backward (dg, db accumulated) */
+int eab_layernorm64_fwd_f32(const float* x, const float* g, const float* b, float eps, float* y, float* mr, long long rows,
+                            eab_stream_t stream);
+int eab_layernorm64_bwd_f32(const float* dy, const float* x, const float* mr, const float* g, float* dx, float* dg,
+                            float* db, long long rows, eab_stream_t stream);
+/* one nn.LSTM(64->64) layer (EaBNet.py:610-611) that also stores the activated gates and cell states,
+ * gates [B*F][T][5][64] = (i, f, g, o, c); and the reverse-time pass: dh_out [B][T][F][64] (gradient w.r.t. every
+ * h_t) -> dgates [B][T][F][256] (gradient w.r.t. the gate pre-activations, row g*64+u), from which
+ * dx = dgates W_ih (eab_conv_f32), dW_ih / dW_hh / db (eab_wgrad_f32 with taps dt = 0 / -1, eab_colsum_f32). */
+int eab_lstm64_train_fwd_f32(const float* x, const float* wcat, const float* bias, float* h_out, float* gates, int B, int T,
+                             int F, eab_stream_t stream);
+int eab_lstm64_bwd_f32(const float* gates, const float* dh_out, const float* wcat, float* dgates, int B, int T, int F,
+                       eab_stream_t stream);
+
+/* Weight gradient on fp32 MFMA:
+ *   dw[n][tap*UPT*16 + c] += sum_{b,t,o} dz[b][t][o*ostride+ophase][n] * src[b][t+dt_tap][o*istride+ioff_tap][c]
+ * with the forward geometry of eab_conv_desc (plain sources, optional concatenation), tap-major columns,
+ * Kpad = ntaps*UPT*16, UPT = ceil((C0+C1)/16).  Accumulates with atomics: the caller zeroes dw. */
+/* (eab_wgrad_desc is declared next to eab_op above) */
+int eab_wgrad_f32(const eab_wgrad_desc* d, eab_stream_t stream);
+
+/* op kinds of the training programs (eab_run_program); field use:
+ *  GATHER       p = {flat, ia, ib, out}                 i = {n_lo, n_hi}
+ *  IN_STATS     p = {x, slope, gamma, beta, xf, mr}     i = {B, P, C}          f = {eps}
+ *  IN_FINALIZE  as before, plus p[7], p[8] = mr0, mr1
+ *  TR_NORM_ACT  p = {x, xf, slope, add, y}              i = {B, P, C, mode}
+ *  NORM_BWD     p = {dy, x, mr, gamma, beta, slope, sums, acc_in, dx, dgamma, dbeta, dslope}   i = {B, P, C, mode}
+ *  GLU_BWD      p = {dy, dump, dz}                      i = {rows_lo, rows_hi, N}
+ *  GATE_FWD     p = {a, r, z}        GATE_BWD p = {dz, a, r, da, dr}       i = {n_lo, n_hi}
+ *  ADD          p = {a, b, out}      RELU_BWD p = {dy, y, dx}              i = {n_lo, n_hi}
+ *  COLSUM       p = {x, out}                            i = {rows_lo, rows_hi, N}
+ *  FILTER_SUM   p = {w, x, y}        FS_BWD   p = {dout, x, dw}            i = {B, T, F, M, ld}
+ *  LN_FWD       p = {x, g, b, y, mr} f = {eps}          i = {rows_lo, rows_hi}
+ *  LN_BWD       p = {dy, x, mr, g, dx, dg, db}          i = {rows_lo, rows_hi}
+ *  LSTM_TRAIN   p = {x, wcat, bias, h_out, gates}       i = {B, T, F}
+ *  LSTM_BWD     p = {gates, dh_out, wcat, dgates}       i = {B, T, F}
+ *  WGRAD        the `wgrad` member */
+#define EAB_OP_GATHER      16
+#define EAB_OP_IN_STATS    17
+#define EAB_OP_TR_NORM_ACT 18
+#define EAB_OP_NORM_BWD    19
+#define EAB_OP_GLU_BWD     20
+#define EAB_OP_GATE_FWD    21
+#define EAB_OP_GATE_BWD    22
+#define EAB_OP_ADD         23
+#define EAB_OP_RELU_BWD    24
+#define EAB_OP_COLSUM      25
+#define EAB_OP_FILTER_SUM  26
+#define EAB_OP_FS_BWD      27
+#define EAB_OP_LN_FWD      28
+#define EAB_OP_LN_BWD      29
+#define EAB_OP_LSTM_TRAIN  30
+#define EAB_OP_LSTM_BWD    31
+#define EAB_OP_WGRAD       32
+
 /* struct-layout handshake for foreign-function mirrors of the structs above */
 int eab_sizeof_conv_desc(void);
 int eab_sizeof_op(void);
+int eab_sizeof_wgrad_desc(void);
 
 #ifdef __cplusplus
 }

@@ -1019,7 +1019,8 @@ def test_kernels_are_unaffected_by_co_running_kernels(dev):
             return bound.acts[op.out.off:op.out.off + op.B * op.P * op.C]
         return out.view(-1)
 
-    (ba, _, oa), (bb, _, _) = make(11), make(12)
+    A, Bq = make(11), make(12)                   # keep the bound inputs / outputs alive: the programs hold raw pointers
+    (ba, _, oa), (bb, _, _) = A, Bq
     idx = {op.name: k for k, op in enumerate(ba.prog.ops)}
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     reps = 6
@@ -1076,3 +1077,82 @@ def test_two_stage_loss_vs_reference_fixture(dev):
     l = eabnet_amd.eabnet_with_postnet_loss(output, label, [12])
     for k in ("eabnet", "postnet", "final"):
         assert abs(float(l[k]) - float(gl[f"full/{k}"])) <= 1e-5 * abs(float(gl[f"full/{k}"])), k
+
+
+# ------------------------------------------------------------------ training on the HIP programs
+def _oracle_grads(P, x, label, frames, **kw):
+    """fp64 autograd through the oracle: loss value and d loss / d parameter for every parameter"""
+    from oracle import eabnet_oracle as orc
+    Pd = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    y = orc.eabnet_forward(Pd, x.double(), **kw)
+    loss = orc.com_mag_mse_loss(y, label.double(), frames)
+    loss.backward()
+    return float(loss), y.detach(), {k: v.grad for k, v in Pd.items()}
+
+
+@pytest.mark.parametrize("M,B,T,pq", [(4, 2, 30, (2, 2)), (8, 1, 70, (6, 3))])
+def test_hip_training_gradients_vs_oracle_autograd(dev, M, B, T, pq):
+    """net(x) under autograd runs the two HIP training programs (eabnet_amd/train.py): the forward equals the
+    inference program's output, and loss.backward() gives every parameter the gradient fp64 autograd through the
+    oracle gives (1e-4 relative per tensor against the largest entry of that tensor, and over the whole gradient)."""
+    import eabnet_amd
+    p, q = pq
+    kw = dict(p=p, q=q)
+    P = torch_params(M, 910 + M, **kw)
+    net = _model(M, 910 + M, dev, **kw)
+    x = torch.from_numpy(paramgen.make_spec_input(B, T, 161, M, 920))
+    label = torch.from_numpy(paramgen.make_spec_input(B, T, 161, 1, 921)[..., 0, :]).permute(0, 3, 1, 2).contiguous()
+    frames = [T] * B
+    with torch.no_grad():
+        y_inf = net(x.to(dev))
+    net.train()
+    y = net(x.to(dev))
+    assert y.requires_grad and getattr(net, "_train_bound", None), "the HIP training path did not engage"
+    assert_close(y.detach().cpu().numpy(), y_inf.cpu().numpy(), 1e-5, "training forward vs inference program")
+    loss = eabnet_amd.com_mag_mse_loss(y, label.to(dev), frames)
+    loss.backward()
+    ref_loss, _, ref = _oracle_grads(P, x, label, frames, **kw)
+    assert abs(float(loss) - ref_loss) <= 1e-5 * abs(ref_loss)
+    worst, num, den = [], 0.0, 0.0
+    for k, g in ref.items():
+        got = net.get_parameter(k).grad
+        assert got is not None and torch.isfinite(got).all(), k
+        d = (got.cpu().double() - g)
+        scale = float(g.abs().max())
+        worst.append((float(d.abs().max()) / max(scale, 1e-30), k, scale))
+        num += float((d * d).sum())
+        den += float((g * g).sum())
+    worst.sort(reverse=True)
+    total = (num / den) ** 0.5
+    # tensors whose whole gradient is at the rounding floor of the global gradient are judged on the global measure
+    gmax = max(sc for _, _, sc in worst)
+    bad = [(e, k) for e, k, sc in worst if e > 1e-4 and sc > 1e-6 * gmax]
+    print(f"gradient parity: global l2-rel {total:.2e}; worst tensors {[(f'{e:.1e}', k) for e, k, _ in worst[:3]]}")
+    assert total <= 1e-4 and not bad, f"global l2-rel {total:.3e}; tensors over 1e-4: {bad[:8]}"
+
+
+def test_hip_training_step_matches_operator_path(dev):
+    """One optimiser step of the reference's loop (train_distributed.py:218-230: forward, loss, backward, clip, Adam)
+    on the HIP training programs against the same step on the PyTorch-ROCm operator path (autograd_path.py): same
+    loss, same clipped-gradient norm, and the updated model gives the same inference output."""
+    import copy
+    import eabnet_amd
+    net = _model(4, 930, dev, p=2, q=1)
+    ref = copy.deepcopy(net)
+    ref.use_hip_training = False
+    x = torch.from_numpy(paramgen.make_spec_input(2, 24, 161, 4, 931)).to(dev)
+    label = torch.from_numpy(paramgen.make_spec_input(2, 24, 161, 1, 932)[..., 0, :]).permute(0, 3, 1, 2).contiguous().to(dev)
+    out = []
+    for m in (net, ref):
+        m.train()
+        opt = torch.optim.Adam(m.parameters(), lr=5e-4)
+        opt.zero_grad()
+        loss = eabnet_amd.com_mag_mse_loss(m(x), label, [24, 24])
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        with torch.no_grad():
+            out.append((float(loss), float(gn), m.eval()(x).clone()))
+    assert abs(out[0][0] - out[1][0]) <= 1e-4 * abs(out[1][0])
+    assert abs(out[0][1] - out[1][1]) <= 2e-3 * abs(out[1][1])              # MIOpen's fp32 convolutions are the looser side
+    assert_close(out[0][2].cpu().numpy(), out[1][2].cpu().numpy(), 2e-3, "inference after one step")
