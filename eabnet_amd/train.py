@@ -133,6 +133,7 @@ class TrainLowering:
         self.flops_fwd = 0
         self.flops_bwd = 0
         self.emit = self.fwd                                                  # the list ops are appended to
+        self.gtaps: Dict[str, TVar] = {}                                      # named activations whose gradient tests read back
 
     # ---- arenas ------------------------------------------------------------------------------------
     def alloc(self, nfloats: int) -> Ref:
@@ -501,8 +502,10 @@ class TrainLowering:
         for i in range(4):
             x = self.unet_module(f"en.meta_unet_list.{i}", [x], 4 - i, False, in_perm if i == 0 else None)
             skips.append(x)
+            self.gtaps[f"en.{i}"] = x
         x = self.conv2d_fwd("en.last_conv", [x], "en.last_conv.0.conv.1", True, "en.last_conv.1", "en.last_conv.2")
         skips.append(x)
+        self.gtaps["en.4"] = x
         Fb = x.F
         assert Fb * x.C == cfg.d_feat
         k = np.arange(cfg.d_feat)
@@ -524,10 +527,13 @@ class TrainLowering:
         # running this first in the backward hands d(x_acc) to the three group outputs before their own closures
         self.tape.append(back_acc)
         x = x_acc.view(Fb, c)
+        self.gtaps["stcns"] = x
         for i in range(4):
             x = self.unet_module(f"de.meta_unet_list.{i}", [x, skips[-(i + 1)]], i + 1, True)
+            self.gtaps[f"de.{i}"] = x
         e = self.conv2d_transposed("de.last_conv", [x, skips[0]], "de.last_conv.0.conv.0", True, "de.last_conv.1", "de.last_conv.2")
         assert e.F == F and e.C == 64
+        self.gtaps["de.4"] = e
 
         # ---- LSTM_BF (EaBNet.py:600-614), unfused
         rows = B * T * F
@@ -544,6 +550,7 @@ class TrainLowering:
             self.fwd.append(GenOp(OP_LSTM_TRAIN, [h_in.ref, wcat, bias, h.ref, gates], [B, T, F], name=p))
             self.flops_fwd += 2 * rows * 256 * 128
             layers.append((p, h_in, h, gates, wcat))
+            self.gtaps[p] = h
             h_in = h
         h2 = h_in
         # w_dnn: Linear 64->64 + ReLU, Linear 64->2M (rows padded to one 64-column tile), then the filter-and-sum
@@ -563,8 +570,11 @@ class TrainLowering:
                      1, [0], [0], prg.EPI_LINEAR, bw.ref, MLP_LD)
         self.fwd.append(GenOp(OP_FILTER_SUM, [bw.ref, Ref("in"), Ref("out")], [B, T, F, M, MLP_LD], name="filter_sum"))
 
+        self.gtaps["bf_w"] = bw
+
         def back_head():
             dbw = self.alloc(rows * MLP_LD)
+            bw.slot.ref = dbw
             self.bwd.append(GenOp(OP_FS_BWD, [Ref("dout"), Ref("in"), dbw], [B, T, F, M, MLP_LD], name="filter_sum.bwd"))
             self.colsum("w_dnn.2.db", dbw, rows, MLP_LD, [b2img])
             self.wgrad_op("w_dnn.2.wgrad", dbw, MLP_LD, F, [y1], F, 1, 0, 1, [0], [0], w2img)
@@ -616,7 +626,8 @@ class TrainLowering:
         return TrainProgram(cfg=self.cfg, B=self.B, T=self.T, F=self.F, fwd=self.fwd, bwd=self.bwd, a_floats=self.a_size,
                             w_floats=self.w_size, g_floats=self.g_size, ia=ia, ib=ib, inv=inv.astype(np.int32),
                             n_params=self.n_params, keys=list(self.specs), shapes=[tuple(s.shape) for s in self.specs.values()],
-                            flops_fwd=self.flops_fwd, flops_bwd=self.flops_bwd)
+                            flops_fwd=self.flops_fwd, flops_bwd=self.flops_bwd,
+                            grad_taps={k: (v.slot.ref, v.F, v.C) for k, v in self.gtaps.items() if v.slot.ref is not None})
 
 
 @dataclass
@@ -638,6 +649,7 @@ class TrainProgram:
     shapes: List[tuple]
     flops_fwd: int = 0
     flops_bwd: int = 0
+    grad_taps: Dict[str, tuple] = field(default_factory=dict)       # name -> (Ref of d loss / d activation, F, C)
 
 
 def lower_train(cfg: NetConfig, B: int, T: int, F: int = 161) -> TrainProgram:

@@ -1080,26 +1080,58 @@ def test_two_stage_loss_vs_reference_fixture(dev):
 
 
 # ------------------------------------------------------------------ training on the HIP programs
-def _oracle_grads(P, x, label, frames, **kw):
-    """fp64 autograd through the oracle: loss value and d loss / d parameter for every parameter"""
+def _oracle_grads(P, x, label, frames, dtype=torch.float64, **kw):
+    """autograd through the oracle in `dtype`: loss value, d loss / d activation at the oracle's named taps and
+    d loss / d parameter for every parameter (all returned in fp64)"""
     from oracle import eabnet_oracle as orc
-    Pd = {k: v.double().requires_grad_(True) for k, v in P.items()}
-    y = orc.eabnet_forward(Pd, x.double(), **kw)
-    loss = orc.com_mag_mse_loss(y, label.double(), frames)
+    Pd = {k: v.to(dtype).requires_grad_(True) for k, v in P.items()}
+    taps = {}
+    y = orc.eabnet_forward(Pd, x.to(dtype), taps=taps, **kw)
+    taps = {k: v for k, v in taps.items() if torch.is_tensor(v) and v.requires_grad}
+    for v in taps.values():
+        v.retain_grad()
+    loss = orc.com_mag_mse_loss(y, label.to(dtype), frames)
     loss.backward()
-    return float(loss), y.detach(), {k: v.grad for k, v in Pd.items()}
+    return (float(loss.detach()), {k: v.grad.double() for k, v in taps.items() if v.grad is not None},
+            {k: v.grad.double() for k, v in Pd.items()})
 
 
-@pytest.mark.parametrize("M,B,T,pq", [(4, 2, 30, (2, 2)), (8, 1, 70, (6, 3))])
-def test_hip_training_gradients_vs_oracle_autograd(dev, M, B, T, pq):
+def _grad_errors(got: dict, ref: dict):
+    """global l2-rel over all tensors; per-tensor max-abs error relative to that tensor's largest entry (tensors whose
+    whole gradient is below 1e-6 of the largest gradient entry anywhere -- biases in front of an InstanceNorm -- are
+    left to the global measure)"""
+    num = sum(float(((got[k] - ref[k]) ** 2).sum()) for k in ref)
+    den = sum(float((ref[k] ** 2).sum()) for k in ref)
+    gmax = max(float(v.abs().max()) for v in ref.values())
+    per = {k: float((got[k] - ref[k]).abs().max()) / float(ref[k].abs().max()) for k in ref if float(ref[k].abs().max()) > 1e-6 * gmax}
+    return (num / den) ** 0.5, per
+
+
+@pytest.mark.parametrize("M,B,T,pq,smooth", [(4, 2, 30, (2, 2), True), (8, 1, 70, (6, 3), True), (4, 2, 30, (2, 2), False),
+                                             (8, 1, 70, (6, 3), False)])
+def test_hip_training_gradients_vs_oracle_autograd(dev, M, B, T, pq, smooth):
     """net(x) under autograd runs the two HIP training programs (eabnet_amd/train.py): the forward equals the
     inference program's output, and loss.backward() gives every parameter the gradient fp64 autograd through the
-    oracle gives (1e-4 relative per tensor against the largest entry of that tensor, and over the whole gradient)."""
+    oracle gives.
+
+    smooth=True: every PReLU slope is 1 (the activation has no kink), so the gradient is a smooth function of the
+    activations and fp32 rounding of the forward cannot flip a derivative: every parameter tensor must agree with fp64
+    autograd to 1e-4 (relative to its largest entry) and so must the activation gradients at the oracle's taps.
+    smooth=False (random slopes): the reference's OWN fp32 autograd deviates from its fp64 autograd by ~1e-3 on this
+    network (PReLU derivative flips amplified through the InstanceNorm chain; measured below with the oracle in
+    fp32) -- the HIP gradient must stay within 4x that floor, and exact at the head where no flip has happened yet."""
     import eabnet_amd
+    from eabnet_amd.spec import NetConfig, param_specs
     p, q = pq
     kw = dict(p=p, q=q)
     P = torch_params(M, 910 + M, **kw)
-    net = _model(M, 910 + M, dev, **kw)
+    if smooth:
+        for k, sp in param_specs(NetConfig(M=M, **kw)).items():
+            if sp.kind == "prelu":
+                P[k] = torch.ones_like(P[k])
+    net = eabnet_amd.EaBNet(M=M, **kw)
+    net.load_state_dict(P, strict=True)
+    net = net.to(dev).eval()
     x = torch.from_numpy(paramgen.make_spec_input(B, T, 161, M, 920))
     label = torch.from_numpy(paramgen.make_spec_input(B, T, 161, 1, 921)[..., 0, :]).permute(0, 3, 1, 2).contiguous()
     frames = [T] * B
@@ -1111,24 +1143,32 @@ def test_hip_training_gradients_vs_oracle_autograd(dev, M, B, T, pq):
     assert_close(y.detach().cpu().numpy(), y_inf.cpu().numpy(), 1e-5, "training forward vs inference program")
     loss = eabnet_amd.com_mag_mse_loss(y, label.to(dev), frames)
     loss.backward()
-    ref_loss, _, ref = _oracle_grads(P, x, label, frames, **kw)
+    ref_loss, ref_taps, ref = _oracle_grads(P, x, label, frames, **kw)
     assert abs(float(loss) - ref_loss) <= 1e-5 * abs(ref_loss)
-    worst, num, den = [], 0.0, 0.0
-    for k, g in ref.items():
-        got = net.get_parameter(k).grad
-        assert got is not None and torch.isfinite(got).all(), k
-        d = (got.cpu().double() - g)
-        scale = float(g.abs().max())
-        worst.append((float(d.abs().max()) / max(scale, 1e-30), k, scale))
-        num += float((d * d).sum())
-        den += float((g * g).sum())
-    worst.sort(reverse=True)
-    total = (num / den) ** 0.5
-    # tensors whose whole gradient is at the rounding floor of the global gradient are judged on the global measure
-    gmax = max(sc for _, _, sc in worst)
-    bad = [(e, k) for e, k, sc in worst if e > 1e-4 and sc > 1e-6 * gmax]
-    print(f"gradient parity: global l2-rel {total:.2e}; worst tensors {[(f'{e:.1e}', k) for e, k, _ in worst[:3]]}")
-    assert total <= 1e-4 and not bad, f"global l2-rel {total:.3e}; tensors over 1e-4: {bad[:8]}"
+    got = {k: net.get_parameter(k).grad.cpu().double() for k in ref}
+    assert all(torch.isfinite(g).all() for g in got.values())
+    total, per = _grad_errors(got, ref)
+    # activation gradients at the oracle's taps (backward order): localises a deviation to a stage
+    bound = next(iter(net._train_bound.values()))
+    acts = {}
+    for name in ("bf_w", "de.4", "de.3", "de.2", "de.1", "de.0", "stcns", "en.4", "en.3", "en.2", "en.1", "en.0"):
+        r, Fv, Cv = bound.prog.grad_taps[name]
+        g_ = bound.acts[r.off:r.off + B * T * Fv * Cv].view(B, T, Fv, Cv).cpu().double()
+        want = ref_taps[name]
+        want = want.reshape(B, T, Fv, -1) if name == "bf_w" else want.permute(0, 2, 3, 1)      # (B,C,T,F) -> (B,T,F,C)
+        acts[name] = rel_errs(g_[..., :want.shape[-1]].numpy(), want.numpy())[1]
+    print(f"smooth={smooth}: parameter gradients global l2-rel {total:.2e}, worst tensor {max(per.values()):.2e}; activation "
+          f"gradients l2-rel {[(n, f'{e:.1e}') for n, e in acts.items()]}")
+    if smooth:
+        bad = sorted(((e, k) for k, e in per.items() if e > 1e-4), reverse=True)
+        assert total <= 1e-4 and not bad, f"global l2-rel {total:.3e}; tensors over 1e-4: {bad[:8]}"
+        assert max(acts.values()) <= 1e-4, acts
+    else:
+        _, taps32, g32 = _oracle_grads(P, x, label, frames, dtype=torch.float32, **kw)
+        floor, _ = _grad_errors(g32, ref)
+        print(f"   reference fp32 autograd vs fp64: global l2-rel {floor:.2e}")
+        assert total <= max(1e-4, 4.0 * floor), f"global l2-rel {total:.3e} vs the reference's own fp32 floor {floor:.3e}"
+        assert acts["bf_w"] <= 1e-4 and acts["de.4"] <= max(1e-4, 4.0 * floor)
 
 
 def test_hip_training_step_matches_operator_path(dev):
