@@ -120,6 +120,120 @@ def cpu_baseline(state, M: int, L: int, budget_s: float = 15.0):
 _CALIBRATED: list = []
 
 
+def main_train(a, rank, world, dev, is_dist):
+    """BASELINE configs[3] / train_distributed.py:214-230 for the beam-former stage: per step
+    prepare_data (noisy + target STFT) -> net(noisy) -> com_mag_mse_loss -> backward -> clip_grad_norm_(1.0) -> Adam(5e-4),
+    forward and backward on the HIP training programs (eabnet_amd/train.py), gradients averaged over the ranks."""
+    from eabnet_amd import train as tr
+    B, M, seconds = 6, MICS, 6.0                            # train_distributed.py:273,279 (batch 6, wav_len 6 s)
+    L = int(seconds * SR)
+    T = 1 + L // HOP
+    net, _ = make_model(M, dev)
+    net.train()
+    pd_args = argparse.Namespace(mics=M, sr=SR, wav_len=seconds, win_size=0.020, win_shift=0.010, fft_num=N_FFT)
+    wav = synth_waves(B, M, L, 1234 + rank).to(dev)
+    tgt = synth_waves(B, 1, L, 4321 + rank).to(dev)
+    model = net
+    if is_dist:
+        tr.broadcast_parameters(net)
+        if a.train_ddp:
+            model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[dev.index], bucket_cap_mb=64,
+                                                              gradient_as_bucket_view=True, static_graph=True)
+        else:
+            tr.enable_flat_allreduce(net)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+    frames_list = [T] * B
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        noisy, target = eabnet_amd.prepare_data(wav, tgt, dev, pd_args)
+        out = model(noisy)
+        loss = eabnet_amd.com_mag_mse_loss(out, target, frames_list)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+        opt.step()
+        return loss
+
+    for _ in range(max(1, a.warmup)):
+        loss = step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    per_rank = dist.gather_over_ranks(el, dev)
+    elapsed = dist.max_over_ranks(el, dev)
+    assert bool(torch.isfinite(loss)), "training diverged"
+    frames = world * B * T * a.steps
+    bound = next(iter(net._train_bound.values()))
+    prog = bound.prog
+    out = {
+        "metric": "enhanced frames/sec (16 kHz, 8-mic) at 1/2/4/8 MI355X; RTF per utterance",
+        "mode": "training step (BASELINE configs[3])",
+        "value": frames / elapsed, "unit": "frames/s (trained)", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[3] (train_distributed.py:214-230) for the beam-former stage: per-GPU batch 6 x 6 s x "
+                               "8 mics; prepare_data (noisy + target STFT), EaBNet forward, com_mag_mse_loss, backward, "
+                               "clip_grad_norm_(1.0), Adam(5e-4); forward and backward on the HIP training programs",
+                   "batch_per_gpu": B, "global_batch": world * B, "mics": M, "frames_per_utt": T,
+                   "parallelism": f"dp{world}: " + ("torch DDP, one 64 MB bucket" if a.train_ddp else
+                                                    "one flat RCCL all-reduce of the 2.84 M-float gradient per step")},
+        "final_loss": float(loss),
+        "gflop_per_step": {"forward": prog.flops_fwd / 1e9, "backward": prog.flops_bwd / 1e9},
+        "ranks": {"world_size_seen_by_torch_distributed": torch.distributed.get_world_size() if is_dist else 1,
+                  "frames_per_s_per_rank": [B * T * a.steps / e for e in per_rank]},
+        "workspace_GB": prog.a_floats * 4 / 1e9,
+    }
+    try:
+        if rank == 0 and not a.no_roofline:
+            # per-op device time of both programs (HIP events on the launch stream, one more forward/backward state is live)
+            stream = torch.cuda.current_stream()
+            res = {}
+            for which, ops in (("fwd", prog.fwd), ("bwd", prog.bwd)):
+                evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(ops) + 1)]
+                if which == "bwd":
+                    bound.g.zero_()
+                torch.cuda._sleep(int(4e8))
+                for k in range(len(ops)):
+                    evs[k].record(stream)
+                    bound.run(which, stream.cuda_stream, k, 1)
+                evs[-1].record(stream)
+                torch.cuda.synchronize()
+                ms = np.array([evs[k].elapsed_time(evs[k + 1]) for k in range(len(ops))])
+                by = {}
+                for k, o in enumerate(ops):
+                    nm = {prg.OP_CONV: "conv_gemm(dgrad)" if which == "bwd" else "conv_gemm", tr.OP_WGRAD: "wgrad", tr.OP_NORM_BWD: "norm_bwd",
+                          tr.OP_LSTM_BWD: "lstm_bwd", tr.OP_LSTM_TRAIN: "lstm_fwd", tr.OP_TR_NORM_ACT: "norm_act", tr.OP_COLSUM: "colsum",
+                          tr.OP_GLU_BWD: "glu_bwd", prg.OP_IN_FINALIZE: "in_finalize"}.get(o.kind, "other")
+                    by[nm] = by.get(nm, 0.0) + float(ms[k])
+                res[which] = {"ms_total": float(ms.sum()), "ms_by_kernel": {k: round(v, 3) for k, v in sorted(by.items(), key=lambda kv: -kv[1])}}
+                if which == "bwd":
+                    wg = [k for k, o in enumerate(ops) if o.kind == tr.OP_WGRAD]
+                    wg_fl = sum(2.0 * o.B * o.T * o.No * o.N * len(o.dt) * (o.C0 + o.C1) for o in ops if o.kind == tr.OP_WGRAD)
+                    wg_ms = float(ms[wg].sum())
+                    out["roofline"] = {"kernel": "wgrad_kernel (fp32 MFMA 32x32x2, split-K, atomics)", "bound": "mfma",
+                                       "achieved": wg_fl / (wg_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": wg_fl / (wg_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                                       "launches_per_step": len(wg), "ms_per_step": wg_ms}
+                    dg = [k for k, o in enumerate(ops) if o.kind == prg.OP_CONV]
+                    dg_fl = sum(2.0 * o.B * o.T * o.No * o.N * len(o.dt) * (o.C0 + o.C1) for o in ops if o.kind == prg.OP_CONV)
+                    out["dgrad"] = {"achieved_tflops": dg_fl / (float(ms[dg].sum()) * 1e-3) / 1e12, "ms_per_step": float(ms[dg].sum())}
+            out["programs"] = res
+    except Exception as e:  # noqa: BLE001
+        out["secondary_sections_error"] = repr(e)
+    if rank == 0:
+        print(json.dumps(out))
+    if is_dist:
+        dist.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,6 +250,11 @@ def main():
     ap.add_argument("--precision", choices=("f32", "f16x3"), default="f32",
                     help="MFMA arithmetic of the timed path (DESIGN.md §4.4)")
     ap.add_argument("--per-op", type=str, default="", help="write the per-op timing table (instrumented replay) here")
+    ap.add_argument("--train", action="store_true",
+                    help="BASELINE configs[3]: training step (prepare_data, forward, loss, backward, clip, Adam) on the HIP "
+                         "training programs, per-GPU batch 6 x 6 s x 8 mics, one flat RCCL gradient all-reduce per step")
+    ap.add_argument("--train-ddp", action="store_true", help="with --train: wrap in torch DistributedDataParallel (one 64 MB bucket, "
+                                                             "gradient_as_bucket_view, static_graph) instead of the flat all-reduce")
     a = ap.parse_args()
 
     rank, world, local = dist.env_rank()
@@ -149,6 +268,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     is_dist = dist.init("nccl", dev)                        # RCCL; only barriers and one scalar MAX
+    if a.train:
+        return main_train(a, rank, world, dev, is_dist)
 
     L = int(SECONDS * SR)
     T = 1 + L // HOP

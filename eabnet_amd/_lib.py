@@ -86,6 +86,8 @@ _SIGS = {
     "eab_gag_crm_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 6 + [TimeWindow, C.c_void_p]),
     "eab_conv_tiles": (C.c_int, [C.c_int] * 3),
     "eab_conv_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "eab_conv_bf16": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "eab_lstm64_bf16": (C.c_int, [C.c_void_p] * 3 + [C.c_float] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
     "eab_in_finalize_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_float] + [C.c_void_p] * 6 + [C.c_void_p]),
     "eab_norm_act_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 3 + [C.c_void_p]),
     "eab_lstm64_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_float] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),

@@ -96,6 +96,14 @@ __device__ __forceinline__ int cg_div(int q, int n, float inv_n) {
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// two fp32 -> packed bf16 (round to nearest even: v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned cg_bf2(float x0, float x1) {
+    const bf16x2 v = {(__bf16)x0, (__bf16)x1};
+    return __builtin_bit_cast(unsigned, v);
+}
 
 // x = hi + lo with hi = x truncated to fp16 and lo = fp16(x - hi), two elements at a time
 // (v_cvt_pkrtz_f16_f32; fp16 subnormals are honoured by the f16 MFMA, probed on gfx950).
@@ -110,6 +118,7 @@ template <int MI, int NI, int KU, int MODE, int XF, bool VEC, int PREC, bool PAT
 __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_desc d) {
     static_assert(!PATCH || (KU == 1 && MODE != CG_DUAL && VEC), "patch mode: one unit per stage, single transform");
     constexpr bool H3 = PREC == EAB_PREC_F16X3;
+    constexpr bool BF = PREC == EAB_PREC_BF16;       // fp32 in memory, operands rounded to bf16 on their way into LDS, ONE bf16 MFMA
     constexpr bool GLU = MODE != CG_PLAIN;          // gated epilogue (value tile, gate tile per lane)
     constexpr bool DUAL = MODE == CG_DUAL;
     using Smem = CgSmem<MI, NI, KU, MODE, PATCH>;
@@ -312,7 +321,9 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
                     v = p_ok[pp] ? x : f32x4{0.f, 0.f, 0.f, 0.f};     // halo / causal zeros stay exactly 0
                 }
                 float* arow = &sm.a[pidx * LDK];
-                if (H3) {
+                if (BF) {
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(arow) + skq * 8) = make_uint2(cg_bf2(v[0], v[1]), cg_bf2(v[2], v[3]));
+                } else if (H3) {
                     unsigned h01, l01, h23, l23;
                     cg_split2(v[0], v[1], h01, l01);
                     cg_split2(v[2], v[3], h23, l23);
@@ -332,7 +343,10 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
 #pragma unroll
             for (int p = 0; p < NI; ++p) {
                 float* brow = &sm.b[buf][(srow + 64 * p) * LDK];
-                if (H3) {
+                if (BF) {
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(brow) + skq * 8) =
+                        make_uint2(cg_bf2(rbw[p][0], rbw[p][1]), cg_bf2(rbw[p][2], rbw[p][3]));
+                } else if (H3) {
                     const u32x4 w = __builtin_bit_cast(u32x4, rbw[p]);
                     *reinterpret_cast<uint2*>(reinterpret_cast<char*>(brow) + skq * 8) = make_uint2(w[0], w[1]);
                     *reinterpret_cast<uint2*>(reinterpret_cast<char*>(brow) + 32 + skq * 8) = make_uint2(w[2], w[3]);
@@ -343,7 +357,18 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
         };
         auto pcompute = [&](int cur, int tap) {
             const int toff = (sm.dt[tap] * Fp + sm.ioff[tap]) * LDK;  // per-tap shift inside the patch (wave-uniform)
-            if (H3) {
+            if (BF) {
+                bf16x8 ab[MI], bb[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) ab[mi] = *reinterpret_cast<const bf16x8*>(&sm.a[fa[mi] + toff]);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) bb[ni] = *reinterpret_cast<const bf16x8*>(&sm.b[cur][b_base + ni * 32 * LDK]);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[mi], bb[ni], acc[mi][ni], 0, 0, 0);
+            } else if (H3) {
                 h16x8 ah[MI], al[MI], bh[NI], bl[NI];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
@@ -491,7 +516,9 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
                         v = rg.st_ok[ku][p] ? x : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                     float* arow = &sm.a[(k * 2 + buf) * Smem::ATILE + (srow + 64 * p) * LDK + ku * 16];
-                    if (H3) {
+                    if (BF) {
+                        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(arow) + skq * 8) = make_uint2(cg_bf2(v[0], v[1]), cg_bf2(v[2], v[3]));
+                    } else if (H3) {
                         // unit layout in LDS (64 B): 16 fp16 hi | 16 fp16 lo; this thread owns channels 4*skq..+3
                         unsigned h01, l01, h23, l23;
                         cg_split2(v[0], v[1], h01, l01);
@@ -506,7 +533,10 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
 #pragma unroll
             for (int p = 0; p < NI; ++p) {
                 float* brow = &sm.b[buf][(srow + 64 * p) * LDK + ku * 16];
-                if (H3) {   // global: [4 hi | 4 lo] per 4-channel group  ->  LDS: [16 hi | 16 lo] per unit
+                if (BF) {
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(brow) + skq * 8) =
+                        make_uint2(cg_bf2(rg.rb[ku][p][0], rg.rb[ku][p][1]), cg_bf2(rg.rb[ku][p][2], rg.rb[ku][p][3]));
+                } else if (H3) {   // global: [4 hi | 4 lo] per 4-channel group  ->  LDS: [16 hi | 16 lo] per unit
                     const u32x4 w = __builtin_bit_cast(u32x4, rg.rb[ku][p]);
                     *reinterpret_cast<uint2*>(reinterpret_cast<char*>(brow) + skq * 8) = make_uint2(w[0], w[1]);
                     *reinterpret_cast<uint2*>(reinterpret_cast<char*>(brow) + 32 + skq * 8) = make_uint2(w[2], w[3]);
@@ -525,7 +555,24 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
     const int b_base = (wn * NI * 32 + li) * LDK + 4 * lh;
 
     auto compute = [&](int cur) {
-        if (H3) {
+        if (BF) {
+#pragma unroll
+            for (int ku = 0; ku < KU; ++ku) {
+                bf16x8 ab[Smem::NA][MI], bb[NI];
+#pragma unroll
+                for (int k = 0; k < Smem::NA; ++k)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        ab[k][mi] = *reinterpret_cast<const bf16x8*>(&sm.a[(k * 2 + cur) * Smem::ATILE + a_base + mi * 32 * LDK + ku * 16]);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) bb[ni] = *reinterpret_cast<const bf16x8*>(&sm.b[cur][b_base + ni * 32 * LDK + ku * 16]);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[DUAL ? ni : 0][mi], bb[ni], acc[mi][ni], 0, 0, 0);
+            }
+        } else if (H3) {
             // one v_mfma_f32_32x32x16_f16 spans a whole 16-channel unit: lane (i, h) holds k = 8h..8h+7
 #pragma unroll
             for (int ku = 0; ku < KU; ++ku) {
@@ -800,6 +847,9 @@ static int cg_launch(const eab_conv_desc* d, hipStream_t s) {
             if (d->precision == EAB_PREC_F16X3)
                 hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, 1, MODE, XF, true, EAB_PREC_F16X3, true>), grid,
                                    dim3(CG_THREADS), 0, s, *d);
+            else if (d->precision == EAB_PREC_BF16)
+                hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, 1, MODE, XF, true, EAB_PREC_BF16, true>), grid,
+                                   dim3(CG_THREADS), 0, s, *d);
             else
                 hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, 1, MODE, XF, true, EAB_PREC_F32, true>), grid,
                                    dim3(CG_THREADS), 0, s, *d);
@@ -811,6 +861,12 @@ static int cg_launch(const eab_conv_desc* d, hipStream_t s) {
     if (d->precision == EAB_PREC_F16X3) {
         if constexpr (VEC)
             hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, KU, MODE, XF, VEC, EAB_PREC_F16X3, false>), grid,
+                               dim3(CG_THREADS), 0, s, *d);
+        else
+            return EAB_EUNSUPPORTED;
+    } else if (d->precision == EAB_PREC_BF16) {
+        if constexpr (VEC)
+            hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, KU, MODE, XF, VEC, EAB_PREC_BF16, false>), grid,
                                dim3(CG_THREADS), 0, s, *d);
         else
             return EAB_EUNSUPPORTED;
@@ -851,15 +907,6 @@ static int cg_pick_ku(const eab_conv_desc* d, hipStream_t s, int ku) {
     return cg_launch<MI, NI, 1, MODE, XF, VEC>(d, s);
 }
 
-static int cg_ku_override() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("EAB_CG_KU");      // tuning knob, not part of the ABI
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
-
 extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
     EAB_CHECK_ARG(d && d->src0 && d->w && d->dst);
     EAB_CHECK_ARG(d->B > 0 && d->T > 0 && d->Fin > 0 && d->Fout > 0 && d->No > 0);
@@ -877,7 +924,7 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
         EAB_CHECK_ARG(d->dt[j] <= 0 || d->korder == EAB_KORDER_TAP);
     }
     EAB_CHECK_ARG(d->epi >= EAB_EPI_LINEAR && d->epi <= EAB_EPI_DUALGATE);
-    EAB_CHECK_ARG(d->precision == EAB_PREC_F32 || d->precision == EAB_PREC_F16X3);
+    EAB_CHECK_ARG(d->precision == EAB_PREC_F32 || d->precision == EAB_PREC_F16X3 || d->precision == EAB_PREC_BF16);
     EAB_CHECK_ARG(d->korder == EAB_KORDER_TAP || d->korder == EAB_KORDER_CHUNK);
     if (d->korder == EAB_KORDER_CHUNK) {   // patch pipeline: the tile's input patch must fit its LDS area
         EAB_CHECK_ARG(cg_patch_positions(d) <= CG_PMAX && d->epi != EAB_EPI_DUALGATE);
@@ -927,8 +974,7 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
     const int xf = has_xf ? d->xf_mode : EAB_XF_NONE;
     if (xf != EAB_XF_NONE)   // transform tables live in LDS: CG_XFC channels per source
         EAB_CHECK_ARG(d->C0 <= CG_XFC && d->C1 <= CG_XFC && vec);
-    int ku = cg_ku_override();
-    if (ku == 0) ku = (mi == 1 && !glu && vec && d->Fin == 1) ? 4 : 1;
+    int ku = (mi == 1 && !glu && vec && d->Fin == 1) ? 4 : 1;
     if (d->korder == EAB_KORDER_CHUNK) ku = 1;
     if (ku == 4 && !(mi == 1 && !glu && vec)) ku = 1;       // KU = 4 exists for the 64-row plain / dual tiles only
     if (ku == 2 && (!vec || dual)) ku = 1;
@@ -953,4 +999,11 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
     if (d->N % 64 == 0) return mi == 2 ? CG_DISPATCH_XF(2, 1) : CG_DISPATCH_XF(1, 1);
 #undef CG_DISPATCH_XF
     return EAB_EUNSUPPORTED;
+}
+
+extern "C" int eab_conv_bf16(const eab_conv_desc* d, eab_stream_t stream) {
+    EAB_CHECK_ARG(d);
+    eab_conv_desc dd = *d;
+    dd.precision = EAB_PREC_BF16;
+    return eab_conv_f32(&dd, stream);
 }

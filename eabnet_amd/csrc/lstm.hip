@@ -438,7 +438,8 @@ static void lstm64_q_launch(bool ln, int grid, hipStream_t st, const float* x, c
 }
 
 int eab_lstm64_h3_launch(const float* x, const float* ln_g, const float* ln_b, float ln_eps, const float* wcat,
-                         const float* bias, float* h_out, int T, int F, int S, hipStream_t stream);   // lstm_h3.hip
+                         const float* bias, float* h_out, int T, int F, int S, int precision, const int* t_pos, int t_count,
+                         float* c_state, hipStream_t stream);   // lstm_h3.hip
 
 extern "C" int eab_lstm64_f32(const float* x, const float* ln_g, const float* ln_b, float ln_eps, const float* wcat,
                               const float* bias, float* h_out, int B, int T, int F, eab_stream_t stream) {
@@ -457,18 +458,17 @@ extern "C" int eab_lstm64_stream_f32(const float* x, const float* ln_g, const fl
                                      int F, int precision, eab_time_window win, eab_stream_t stream) {
     EAB_CHECK_ARG(x && wcat && bias && h_out && B > 0 && T > 0 && F > 0);
     EAB_CHECK_ARG(win.pos == nullptr || (win.count > 0 && c_state));
-    if (win.pos && precision != EAB_PREC_F32) return EAB_EUNSUPPORTED;   // streaming state is carried in fp32
-    EAB_CHECK_ARG(precision == EAB_PREC_F32 || precision == EAB_PREC_F16X3);
+    EAB_CHECK_ARG(precision == EAB_PREC_F32 || precision == EAB_PREC_F16X3 || precision == EAB_PREC_BF16);
     EAB_CHECK_ARG((ln_g == nullptr) == (ln_b == nullptr));
     const long long S = (long long)B * F;
     EAB_CHECK_ARG(S * T * LS_H * 4 < (1ll << 31));          // 31-bit byte offsets in the buffer descriptors
-    if (precision == EAB_PREC_F16X3)
-        return eab_lstm64_h3_launch(x, ln_g, ln_b, ln_eps, wcat, bias, h_out, T, F, (int)S, eab_stream(stream));
     float* cs = win.pos ? c_state : nullptr;
+    if (precision != EAB_PREC_F32)      // streaming state (h in h_out, c in c_state) is carried in fp32 in every mode
+        return eab_lstm64_h3_launch(x, ln_g, ln_b, ln_eps, wcat, bias, h_out, T, F, (int)S, precision, win.pos, win.count, cs,
+                                    eab_stream(stream));
     // up to 2048 sequences (12 four-second utterances): 4-sequence workgroups on the 4x4x1 MFMA (measured faster
     // than the 16-sequence kernel up to there, even at two workgroups per CU; larger groups never won)
-    static const int g_env = getenv("EAB_LSTM_G") ? atoi(getenv("EAB_LSTM_G")) : 0;      // 1 / 4 force a kernel
-    if (g_env == 1 || (g_env != 4 && S <= 2048)) {
+    if (S <= 2048) {
         lstm64_q_launch<1>(ln_g != nullptr, (int)((S + 3) / 4), eab_stream(stream), x, ln_g, ln_b, ln_eps, wcat, bias, h_out,
                            T, F, (int)S, win.pos, win.count, cs);
         EAB_RETURN_LAUNCH_STATUS();
@@ -494,4 +494,9 @@ extern "C" int eab_lstm64_train_fwd_f32(const float* x, const float* wcat, const
     hipLaunchKernelGGL((lstm64_kernel<false, true>), dim3(grid), dim3(256), 0, eab_stream(stream), x, nullptr, nullptr, 0.0f, wcat,
                        bias, h_out, T, F, (int)S, nullptr, 0, nullptr, gates);
     EAB_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int eab_lstm64_bf16(const float* x, const float* ln_g, const float* ln_b, float ln_eps, const float* wcat,
+                               const float* bias, float* h_out, int B, int T, int F, eab_stream_t stream) {
+    return eab_lstm64_prec_f32(x, ln_g, ln_b, ln_eps, wcat, bias, h_out, B, T, F, EAB_PREC_BF16, stream);
 }

@@ -1,6 +1,9 @@
-// K10+K11 in EAB_PREC_F16X3 arithmetic: LayerNorm(64) + one LSTM(64->64) layer on the f16
-// matrix cores (v_mfma_f32_16x16x32_f16), every fp32 operand split x = hi + lo and every
-// product taken as lo*hi + hi*lo + hi*hi with fp32 accumulation (include/eabnet_hip.h).
+// K10+K11 in reduced-precision arithmetic: LayerNorm(64) + one LSTM(64->64) layer on the 16-bit matrix cores.
+//   EAB_PREC_F16X3: v_mfma_f32_16x16x32_f16, every fp32 operand split x = hi + lo and every product taken as
+//                   lo*hi + hi*lo + hi*hi with fp32 accumulation (include/eabnet_hip.h);
+//   EAB_PREC_BF16 : v_mfma_f32_16x16x32_bf16, operands rounded to bf16, ONE product, fp32 accumulation and fp32
+//                   cell state / activations (the arithmetic of torch.autocast(bfloat16) on nn.LSTM).
+// Both also run the streaming window (eab_time_window): state h_{t-1} from h_out, c from c_state.
 // Reference: LSTM_BF.forward, EaBNet.py:608-611.
 //
 // Same ownership as the fp32 kernel (csrc/lstm.hip): one workgroup = 16 sequences for all T
@@ -20,6 +23,8 @@
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float lh_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -36,27 +41,48 @@ __device__ __forceinline__ float lh_row_sum(float v) {     // sum over the 16 la
     return v;
 }
 
+template <bool BF>
 __device__ __forceinline__ void lh_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
-    const h16x2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-    const h16x2 l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
-    hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, l);
+    if (BF) {
+        const bf16x2 h = {(__bf16)x0, (__bf16)x1};
+        const bf16x2 l = {(__bf16)(x0 - (float)h[0]), (__bf16)(x1 - (float)h[1])};
+        hi = __builtin_bit_cast(unsigned, h);
+        lo = __builtin_bit_cast(unsigned, l);
+    } else {
+        const h16x2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+        const h16x2 l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
+        hi = __builtin_bit_cast(unsigned, h);
+        lo = __builtin_bit_cast(unsigned, l);
+    }
 }
 
-template <bool LN>
+// 16-bit pair (hi, lo) -> fp32 hi + lo
+template <bool BF>
+__device__ __forceinline__ float lh_join(unsigned short hi, unsigned short lo) {
+    if (BF) return __builtin_bit_cast(float, (unsigned)hi << 16) + __builtin_bit_cast(float, (unsigned)lo << 16);
+    return (float)__builtin_bit_cast(_Float16, hi) + (float)__builtin_bit_cast(_Float16, lo);
+}
+
+template <bool LN, bool BF>
 __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict__ x, const float* __restrict__ ln_g,
                                                         const float* __restrict__ ln_b, float ln_eps,
                                                         const float* __restrict__ wcat, const float* __restrict__ bias,
-                                                        float* __restrict__ h_out, int T, int F, int S) {
+                                                        float* __restrict__ h_out, int T, int F, int S,
+                                                        const int* __restrict__ t_pos, int t_count, float* __restrict__ c_state) {
+    using v8 = std::conditional_t<BF, bf16x8, h16x8>;
+    using e16 = std::conditional_t<BF, __bf16, _Float16>;
     __shared__ __attribute__((aligned(16))) char xs[2][LH_SEQ * LH_ROW];
     __shared__ __attribute__((aligned(16))) char hs[2][LH_SEQ * LH_ROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ln = lane & 15, lk = lane >> 4;
     const int s0 = blockIdx.x * LH_SEQ;
+    // streaming (eab_time_window): steps [t_lo, t_hi) only
+    const int t_lo = t_pos ? *t_pos : 0;
+    const int t_hi = t_pos ? (t_lo + t_count < T ? t_lo + t_count : T) : T;
 
-    // ---- stationary weights as fp16 hi/lo B fragments:
+    // ---- stationary weights as 16-bit hi/lo B fragments (bf16 mode: hi only is multiplied):
     //      w?[g][kb] = W[g*64 + 16w + ln][(x:0 | h:64) + 32*kb + 8*lk + j], j = 0..7
-    h16x8 wxh[4][2], wxl[4][2], whh[4][2], whl[4][2];
+    v8 wxh[4][2], wxl[4][2], whh[4][2], whl[4][2];
     float bia[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -68,12 +94,12 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
             for (int kb = 0; kb < 2; ++kb) {
                 const float* p = &wcat[(size_t)row * 128 + half * 64 + 32 * kb + 8 * lk];
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
-                h16x8 hi, lo;
+                v8 hi, lo;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float w = j < 4 ? v0[j] : v1[j - 4];
-                    hi[j] = (_Float16)w;
-                    lo[j] = (_Float16)(w - (float)hi[j]);
+                    hi[j] = (e16)w;
+                    lo[j] = (e16)(w - (float)hi[j]);
                 }
                 if (half == 0) { wxh[g][kb] = hi; wxl[g][kb] = lo; } else { whh[g][kb] = hi; whl[g][kb] = lo; }
             }
@@ -98,7 +124,7 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
     const int lrow = ls * LH_ROW + (lc >> 5) * 128 + (lc & 31) * 2;
 
     auto load_x = [&](int t) -> f32x4 {
-        const unsigned off = (sv && t < T) ? seq_off + (unsigned)t * t_stride : LH_OOB;
+        const unsigned off = (sv && t < t_hi) ? seq_off + (unsigned)t * t_stride : LH_OOB;
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
     };
     auto norm_store = [&](f32x4 v, int buf) {
@@ -111,40 +137,60 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
             for (int j = 0; j < 4; ++j) v[j] = dlt[j] * rstd * g4[j] + b4[j];
         }
         unsigned h01, l01, h23, l23;
-        lh_split2(v[0], v[1], h01, l01);
-        lh_split2(v[2], v[3], h23, l23);
+        lh_split2<BF>(v[0], v[1], h01, l01);
+        lh_split2<BF>(v[2], v[3], h23, l23);
         *reinterpret_cast<uint2*>(&xs[buf][lrow]) = make_uint2(h01, h23);
-        *reinterpret_cast<uint2*>(&xs[buf][lrow + 64]) = make_uint2(l01, l23);
+        if (!BF) *reinterpret_cast<uint2*>(&xs[buf][lrow + 64]) = make_uint2(l01, l23);
     };
     // A fragments of a 16 x 64 tile: lane (m = ln, kq = lk) holds k = 32*kb + 8*kq + j
-    auto frags = [&](const char* tile, h16x8 (&ah)[2], h16x8 (&al)[2]) {
+    auto frags = [&](const char* tile, v8 (&ah)[2], v8 (&al)[2]) {
         const char* p = tile + ln * LH_ROW + lk * 16;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            ah[kb] = *reinterpret_cast<const h16x8*>(p + kb * 128);
-            al[kb] = *reinterpret_cast<const h16x8*>(p + kb * 128 + 64);
+            ah[kb] = *reinterpret_cast<const v8*>(p + kb * 128);
+            if (!BF) al[kb] = *reinterpret_cast<const v8*>(p + kb * 128 + 64);
         }
     };
-    auto mma = [&](const h16x8 (&ah)[2], const h16x8 (&al)[2], const h16x8 (&wh)[4][2], const h16x8 (&wl)[4][2],
-                   f32x4 (&acc)[4]) {
+    auto mma = [&](const v8 (&ah)[2], const v8 (&al)[2], const v8 (&wh)[4][2], const v8 (&wl)[4][2], f32x4 (&acc)[4]) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kb], wh[g][kb], acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kb], wl[g][kb], acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kb], wh[g][kb], acc[g], 0, 0, 0);
+                if constexpr (BF) {
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[kb], wh[g][kb], acc[g], 0, 0, 0);
+                } else {
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kb], wh[g][kb], acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kb], wl[g][kb], acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kb], wh[g][kb], acc[g], 0, 0, 0);
+                }
             }
     };
 
-    // prologue: h_{-1} = 0 (hi and lo), x_0 / x_1 in LDS, accx = b + W_x x_0
+    // prologue: h_{t_lo-1} (0 at the start of the utterance; hi and lo), c_{t_lo-1}, x_{t_lo} / x_{t_lo+1} in LDS,
+    // accx = b + W_x x_{t_lo}
     for (int e = tid; e < LH_SEQ * LH_ROW / 4; e += 256) reinterpret_cast<unsigned*>(hs[0])[e] = 0u;
-    norm_store(load_x(0), 0);
-    norm_store(load_x(1), 1);
+    __syncthreads();
+    if (t_lo > 0) {
+        const f32x4 hp = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                       rh, sv ? seq_off + (unsigned)(t_lo - 1) * t_stride : LH_OOB, 0, 0));
+        unsigned h01, l01, h23, l23;
+        lh_split2<BF>(hp[0], hp[1], h01, l01);
+        lh_split2<BF>(hp[2], hp[3], h23, l23);
+        *reinterpret_cast<uint2*>(&hs[0][lrow]) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(&hs[0][lrow + 64]) = make_uint2(l01, l23);
+    }
+    norm_store(load_x(t_lo), 0);
+    norm_store(load_x(t_lo + 1), 1);
+    const int uq = wave * 16 + ln;
     float cst[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c_state && t_lo > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (s0 + 4 * lk + r < S) cst[r] = c_state[(size_t)(s0 + 4 * lk + r) * 64 + uq];
+    }
     __syncthreads();
     f32x4 accx[4];
-    h16x8 xh[2], xl[2], hh[2], hl[2];
+    v8 xh[2], xl[2], hh[2], hl[2];
 #pragma unroll
     for (int g = 0; g < 4; ++g) accx[g] = f32x4{bia[g], bia[g], bia[g], bia[g]};
     frags(xs[0], xh, xl);
@@ -154,12 +200,12 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
     // (a wave that leads by the 24 recurrent MFMAs of step 0 would otherwise clobber rows a slower wave
     // has not read yet: a cross-wave write-after-read race that shows when other kernels share the CU)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    f32x4 xq = load_x(2), xr = load_x(3);
+    f32x4 xq = load_x(t_lo + 2), xr = load_x(t_lo + 3);
 
     const int u = wave * 16 + ln;
     const int hcol = (u >> 5) * 128 + (u & 31) * 2;         // byte offset of unit u inside a row (hi; lo at +64)
-    for (int t = 0; t < T; ++t) {
-        const int cur = t & 1, nxt = cur ^ 1;
+    for (int t = t_lo; t < t_hi; ++t) {
+        const int cur = (t - t_lo) & 1, nxt = cur ^ 1;
         const f32x4 xn = load_x(t + 4);
 
         // ---- recurrence: acc = accx + W_h h_{t-1}, then the cell update
@@ -182,10 +228,10 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
             const float og = lh_sigmoid(acc[3][r]);
             cst[r] = fmaf(fg, cst[r], ig * gg);
             const float h = og * lh_tanh(cst[r]);
-            const _Float16 hi = (_Float16)h;
-            const _Float16 lo = (_Float16)(h - (float)hi);
-            *reinterpret_cast<_Float16*>(hrow + (4 * lk + r) * LH_ROW) = hi;
-            *reinterpret_cast<_Float16*>(hrow + (4 * lk + r) * LH_ROW + 64) = lo;
+            const e16 hi = (e16)h;
+            const e16 lo = (e16)(h - (float)hi);           // (bf16 mode: only the write-back of h_t uses the residual)
+            *reinterpret_cast<e16*>(hrow + (4 * lk + r) * LH_ROW) = hi;
+            *reinterpret_cast<e16*>(hrow + (4 * lk + r) * LH_ROW + 64) = lo;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: keep the x prefetch in flight
         frags(hs[nxt], hh, hl);
@@ -199,27 +245,34 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
         for (int g = 0; g < 4; ++g) accx[g] = f32x4{bia[g], bia[g], bia[g], bia[g]};
         mma(xh, xl, wxh, wxl, accx);
         {
-            const h16x2 a0 = __builtin_bit_cast(h16x2, ph.x), a1 = __builtin_bit_cast(h16x2, ph.y);
-            const h16x2 c0 = __builtin_bit_cast(h16x2, pl.x), c1 = __builtin_bit_cast(h16x2, pl.y);
-            const f32x4 hv = {(float)a0[0] + (float)c0[0], (float)a0[1] + (float)c0[1], (float)a1[0] + (float)c1[0],
-                              (float)a1[1] + (float)c1[1]};
+            const f32x4 hv = {lh_join<BF>(ph.x & 0xFFFF, pl.x & 0xFFFF), lh_join<BF>(ph.x >> 16, pl.x >> 16),
+                              lh_join<BF>(ph.y & 0xFFFF, pl.y & 0xFFFF), lh_join<BF>(ph.y >> 16, pl.y >> 16)};
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), rh,
                                                    sv ? seq_off + (unsigned)t * t_stride : LH_OOB, 0, 0);
         }
         xq = xr;
         xr = xn;
     }
+    if (c_state) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (s0 + 4 * lk + r < S) c_state[(size_t)(s0 + 4 * lk + r) * 64 + u] = cst[r];
+    }
 }
 
 // dispatcher shared with csrc/lstm.hip
 int eab_lstm64_h3_launch(const float* x, const float* ln_g, const float* ln_b, float ln_eps, const float* wcat,
-                         const float* bias, float* h_out, int T, int F, int S, hipStream_t stream) {
+                         const float* bias, float* h_out, int T, int F, int S, int precision, const int* t_pos, int t_count,
+                         float* c_state, hipStream_t stream) {
     const int grid = (S + LH_SEQ - 1) / LH_SEQ;
-    if (ln_g)
-        hipLaunchKernelGGL(lstm64_h3_kernel<true>, dim3(grid), dim3(256), 0, stream, x, ln_g, ln_b, ln_eps, wcat, bias,
-                           h_out, T, F, S);
-    else
-        hipLaunchKernelGGL(lstm64_h3_kernel<false>, dim3(grid), dim3(256), 0, stream, x, ln_g, ln_b, ln_eps, wcat,
-                           bias, h_out, T, F, S);
+#define LH_GO(LN_, BF_)                                                                                                     \
+    hipLaunchKernelGGL((lstm64_h3_kernel<LN_, BF_>), dim3(grid), dim3(256), 0, stream, x, ln_g, ln_b, ln_eps, wcat, bias, h_out, \
+                       T, F, S, t_pos, t_count, c_state)
+    if (precision == EAB_PREC_BF16) {
+        if (ln_g) LH_GO(true, true); else LH_GO(false, true);
+    } else {
+        if (ln_g) LH_GO(true, false); else LH_GO(false, false);
+    }
+#undef LH_GO
     EAB_RETURN_LAUNCH_STATUS();
 }

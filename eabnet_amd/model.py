@@ -271,7 +271,9 @@ class _HipModule(nn.Module):
         # device copy of the input and of the output per call); False = direct kernel launches
         self.use_graph = True
         # arithmetic of the MFMA contractions: "f32" = exact fp32 MFMA; "f16x3" = error-compensated
-        # fp16 split on the f16 matrix cores, same end-to-end error class as fp32
+        # fp16 split on the f16 matrix cores, same end-to-end error class as fp32;
+        # "bf16" = operands rounded to bf16, fp32 accumulate / norms / activations (BASELINE configs[3]/[4];
+        # outside the 1e-4 bar: ~1e-2)
         self.precision = "f32"
         # training forward/backward on the HIP programs (train.py) where the topology allows; False = the
         # PyTorch-ROCm operator path (autograd_path.py) everywhere

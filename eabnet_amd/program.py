@@ -35,7 +35,8 @@ OP_CONV, OP_IN_FINALIZE, OP_NORM_ACT, OP_LSTM64, OP_BFW_FS, OP_MEMSET0, OP_GAG_P
 ACT_SIGMOID, ACT_TANH, ACT_RELU = 0, 1, 2
 GAG_PRE_LD = 324   # floats per (b, t) row of the interleaved previous estimate: 2*161 rounded up to a float4
 GAG_LIN_LD = 192   # 161 linear outputs padded to three 64-column tiles
-PREC_F32, PREC_F16X3 = 0, 1
+PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
+PREC_CODE = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16": PREC_BF16}
 KORDER_TAP, KORDER_CHUNK = 0, 1
 PATCH_MAX = 352    # CG_PMAX in csrc/conv_gemm.hip
 MAX_TAPS = 16
@@ -355,10 +356,10 @@ class Lowering:
             if cfg.norm_type != "BN" or not cfg.is_causal:
                 raise NotImplementedError("streaming needs norm_type='BN' (eval) and is_causal=True: InstanceNorm "
                                           "statistics and centred S-TCM taps look at the whole utterance")
-            if precision != "f32":
-                raise NotImplementedError("streaming carries its recurrent state in fp32: precision must be 'f32'")
-        if precision not in ("f32", "f16x3"):
-            raise ValueError(f"precision must be 'f32' or 'f16x3', got {precision!r}")
+            if precision == "f16x3":
+                raise NotImplementedError("streaming runs in 'f32' or 'bf16' (BASELINE config 5); 'f16x3' is an offline mode")
+        if precision not in ("f32", "f16x3", "bf16"):
+            raise ValueError(f"precision must be 'f32', 'f16x3' or 'bf16', got {precision!r}")
         self.precision = precision
         self.patch = os.environ.get("EAB_PATCH", "1") != "0"      # tuning knob: 0 = gather pipeline everywhere
         specs = self.spec_fn(cfg)
@@ -474,8 +475,10 @@ class Lowering:
             w = self.W.add(key + ".chunk", np.ascontiguousarray(wt.transpose(0, 2, 1, 3)).reshape(N, Kpad))
         # f16x3 needs bounded operands: every source except the raw network input is either
         # instance-normalised or a sum of such tensors; the first conv stays on exact fp32.
-        prec = PREC_F16X3 if (self.precision == "f16x3" and s0.ref.arena != "in" and C0 % 4 == 0 and C1 % 4 == 0
-                              and not any(s.raw for s in srcs)) else PREC_F32
+        # bf16 (torch.autocast semantics for the reference's convolutions): same rule, weights stay plain fp32 in
+        # memory -- the kernel rounds both operands on their way into LDS
+        lowp = self.precision != "f32" and s0.ref.arena != "in" and C0 % 4 == 0 and C1 % 4 == 0 and not any(s.raw for s in srcs)
+        prec = PREC_CODE[self.precision] if lowp else PREC_F32
         if prec == PREC_F16X3:
             key = next(k for k, r in self.W.index.items() if r == w)
             wf = self.W.chunks_by_name[key].reshape(N, Kpad)
@@ -745,7 +748,7 @@ class Lowering:
                                    ln_b=self.vec("bf_map.norm.bias") if li == 0 else None, ln_eps=EPS_LN,
                                    wcat=self.W.add(f"{p}#wcat", wcat), bias=self.W.add(f"{p}#bias", bias),
                                    h_out=out, B=B, T=T, F=F, name=p,
-                                   precision=PREC_F16X3 if os.environ.get("EAB_LSTM_PREC", self.precision) == "f16x3" else PREC_F32,
+                                   precision=PREC_CODE[os.environ.get("EAB_LSTM_PREC", self.precision)],
                                    c_state=self.alloc(B * F * 64) if self.chunk else None, win=bool(self.chunk)))
             self.flops += 2 * B * T * F * 256 * 128
             h = Act(out, F, 64)

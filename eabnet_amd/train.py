@@ -749,8 +749,9 @@ class _EaBNetTrainFn(torch.autograd.Function):
     """One autograd node for the whole network: forward program, backward program."""
 
     @staticmethod
-    def forward(ctx, bound: TrainBound, x: torch.Tensor, *params: torch.Tensor) -> torch.Tensor:
+    def forward(ctx, bound: TrainBound, sync_group, x: torch.Tensor, *params: torch.Tensor) -> torch.Tensor:
         prog = bound.prog
+        ctx.sync_group = sync_group
         st = torch.cuda.current_stream().cuda_stream
         flat = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in params])
         out = torch.empty((prog.B, 2, prog.T, prog.F), dtype=torch.float32, device=x.device)
@@ -773,12 +774,19 @@ class _EaBNetTrainFn(torch.autograd.Function):
         bound.run("bwd", st)
         gflat = torch.empty(prog.n_params, dtype=torch.float32, device=ctx.x.device)     # fresh per call: .grad may keep views of it
         bound.unpack_grads(gflat, st)
+        if ctx.sync_group is not None:
+            # data-parallel training: the whole gradient is ONE contiguous buffer, so the reference's DDP bucket
+            # all-reduce (train_distributed.py:198,228) is a single RCCL all-reduce of n_params floats -- the "one flat
+            # bucket" SURVEY §5 asks for, without per-parameter hooks or bucket copies
+            import torch.distributed as td
+            td.all_reduce(gflat, group=ctx.sync_group if ctx.sync_group is not True else None)
+            gflat.div_(td.get_world_size(ctx.sync_group if ctx.sync_group is not True else None))
         grads, off = [], 0
         for k, shp in enumerate(ctx.shapes):
             n = int(np.prod(shp)) if len(shp) else 1
-            grads.append(gflat[off:off + n].view(shp).to(ctx.dtypes[k]) if ctx.needs_input_grad[2 + k] else None)
+            grads.append(gflat[off:off + n].view(shp).to(ctx.dtypes[k]) if ctx.needs_input_grad[3 + k] else None)
             off += n
-        return (None, None, *grads)
+        return (None, None, None, *grads)
 
 
 def forward_train(module, inpt: torch.Tensor) -> torch.Tensor:
@@ -796,6 +804,21 @@ def forward_train(module, inpt: torch.Tensor) -> torch.Tensor:
             bound = cache[key] = TrainBound(lower_train(module.cfg, B, T, F), x.device)
     sd = dict(module.named_parameters())
     params = [sd[k] for k in bound.prog.keys]
+    sync = module.__dict__.get("grad_allreduce", None)          # None | True (default group) | a process group
     with torch.cuda.device(x.device):
-        out = _EaBNetTrainFn.apply(bound, x, *params)
+        out = _EaBNetTrainFn.apply(bound, sync, x, *params)
     return out.to(inpt.dtype)
+
+
+def enable_flat_allreduce(module, group=True) -> None:
+    """Data-parallel training without a DistributedDataParallel wrapper: every backward of ``module`` (an
+    eabnet_amd.EaBNet on the HIP training path) all-reduces its flat gradient once and averages it over the ranks.
+    Parameters must start identical on all ranks (broadcast them once, as DDP's constructor does)."""
+    module.grad_allreduce = group
+
+
+def broadcast_parameters(module, src: int = 0) -> None:
+    import torch.distributed as td
+    if td.is_available() and td.is_initialized():
+        for t in list(module.parameters()) + list(module.buffers()):
+            td.broadcast(t.data, src)

@@ -243,12 +243,21 @@ typedef struct eab_conv_desc {
 
 #define EAB_PREC_F32   0
 #define EAB_PREC_F16X3 1
+/* EAB_PREC_BF16 (BASELINE configs[3]/[4], "bf16 mixed precision"): tensors and `w` stay fp32 in memory (plain fp32
+ * layout, no host-side packing); both operands are rounded to bf16 (nearest even) on their way into LDS and
+ * multiplied on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16) with fp32 accumulation, bias, norms and
+ * activations in fp32 -- the arithmetic torch.autocast(bfloat16) gives the reference's convolutions.  NOT inside the
+ * 1e-4 parity bar: its measured error is stated per test. */
+#define EAB_PREC_BF16  2
 #define EAB_KORDER_TAP   0
 #define EAB_KORDER_CHUNK 1
 
 /* number of tiles per batch element a launch with this geometry produces */
 int eab_conv_tiles(int T, int No, int bm);
 int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream);
+/* the same launch with the contraction on the bf16 matrix cores whatever d->precision says (BASELINE configs[3]/[4]);
+ * fp32 tensors and weights in memory, see EAB_PREC_BF16 */
+int eab_conv_bf16(const eab_conv_desc* d, eab_stream_t stream);
 
 /* --------------------------------------------------------------------------
  * K8 (statistics half)  InstanceNorm finalisation.  Replaces the reduction in
@@ -293,6 +302,9 @@ int eab_lstm64_f32(const float* x, const float* ln_g, const float* ln_b, float l
 int eab_lstm64_prec_f32(const float* x, const float* ln_g, const float* ln_b, float ln_eps,
                         const float* wcat, const float* bias, float* h_out,
                         int B, int T, int F, int precision, eab_stream_t stream);
+/* bf16 variant (operands rounded to bf16, v_mfma_f32_16x16x32_bf16, fp32 accumulate and cell state) */
+int eab_lstm64_bf16(const float* x, const float* ln_g, const float* ln_b, float ln_eps,
+                    const float* wcat, const float* bias, float* h_out, int B, int T, int F, eab_stream_t stream);
 
 /* --------------------------------------------------------------------------
  * K12(second Linear)+K13  beam-forming weights + filter-and-sum, fused.

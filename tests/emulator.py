@@ -40,6 +40,13 @@ def f16_rtz(x):
     return h.astype(np.float32)
 
 
+def bf16_round(x):
+    """fp32 -> bf16 (round to nearest even) -> fp32, what v_cvt_pk_bf16_f32 does"""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return r.view(np.float32).reshape(np.shape(x))
+
+
 def split_f16x3(x):
     hi = f16_rtz(x)
     return hi, f16_rtz(np.asarray(x, np.float32) - hi)
@@ -123,7 +130,11 @@ class Emulator:
             W = by_tap(self.v(op.w, (op.N, op.Kpad)))
         assert not np.any(W[:, :, Ct:]), "padding columns of the packed weights must be zero"
 
+        bf = op.precision == prg.PREC_BF16
+
         def mm(G, rows, j):
+            if bf:               # both operands rounded to bf16, fp32 accumulate
+                return bf16_round(G) @ bf16_round(W[rows, j, :Ct]).T
             if not h3:
                 return G @ W[rows, j, :Ct].T
             gh, gl = split_f16x3(G)           # the kernel's three MFMAs: lo*hi + hi*lo + hi*hi
@@ -220,9 +231,14 @@ class Emulator:
         if h3:      # weights split with round-to-nearest in the kernel, activations with round-toward-zero
             Wh = W.astype(np.float16).astype(np.float32)
             Wl = (W - Wh).astype(np.float16).astype(np.float32)
+        bf = op.precision == prg.PREC_BF16
+        if bf:
+            Wb = bf16_round(W)
         for t in range(T):
             a = np.concatenate([x[:, t], h], -1)
-            if h3:
+            if bf:
+                g = bf16_round(a) @ Wb.T + bias
+            elif h3:
                 ah, al = split_f16x3(a)
                 g = ((al @ Wh.T + ah @ Wl.T) + ah @ Wh.T) + bias
             else:
@@ -234,6 +250,10 @@ class Emulator:
             if h3:  # the kernel carries h as fp16 hi + lo (both round-to-nearest)
                 hh = h.astype(np.float16).astype(np.float32)
                 h = hh + (h - hh).astype(np.float16).astype(np.float32)
+                out[:, t] = h
+            if bf:  # h_t leaves as bf16 hi + bf16 residual; the recurrence multiplies the bf16 value (rounded again above)
+                hh = bf16_round(h)
+                h = hh + bf16_round(h - hh)
                 out[:, t] = h
 
     def bfw(self, op: prg.BfwOp):

@@ -122,7 +122,7 @@ def test_filter_sum_vs_oracle_and_linearity(dev):
 # ------------------------------------------------------------------ op by op
 @pytest.mark.parametrize("M,B,T,pq,precision", [(8, 1, 12, (6, 3), "f32"), (9, 2, 21, (2, 1), "f32"),
                                                  (16, 1, 9, (1, 1), "f32"), (8, 2, 21, (2, 1), "f16x3"),
-                                                 (9, 1, 12, (1, 1), "f16x3")])
+                                                 (9, 1, 12, (1, 1), "f16x3"), (8, 2, 21, (2, 1), "bf16")])
 def test_every_op_matches_the_emulator(dev, M, B, T, pq, precision):
     """Run the device program one op at a time next to the numpy interpreter of
     the same program (tests/emulator.py, itself pinned to the reference fixtures
@@ -156,13 +156,15 @@ def test_every_op_matches_the_emulator(dev, M, B, T, pq, precision):
         scale = max(np.abs(want[m]).max(), 1e-20) if m.any() else 1.0
         # compare only what this op may have touched: cheap global check, tight tolerance per op
         err = np.abs(got[m] - want[m]).max() / scale if m.any() else 0.0
-        assert err < 2e-4, f"op {k} {op.name} (kind {op.kind}): workspace deviates by {err:.3e} (relative to max)"
+        # bf16: an operand one ulp(fp32) apart on the two sides can round to different bf16 values (2^-9 relative)
+        lim = 2e-4 if precision != "bf16" else 2e-3
+        assert err < lim, f"op {k} {op.name} (kind {op.kind}): workspace deviates by {err:.3e} (relative to max)"
         # keep both sides in lockstep so that errors do not compound across ops
         emu.arena["a"][:] = got
         worst = max(worst, err)
     got_out = out.cpu().numpy()
     assert not np.isnan(got_out).any()
-    assert_close(got_out, emu.arena["out"].reshape(got_out.shape), TOL_HIP, "out")
+    assert_close(got_out, emu.arena["out"].reshape(got_out.shape), TOL_HIP if precision != "bf16" else 2e-3, "out")
 
 
 # ------------------------------------------------------------------ end to end
@@ -1196,3 +1198,53 @@ def test_hip_training_step_matches_operator_path(dev):
     assert abs(out[0][0] - out[1][0]) <= 1e-4 * abs(out[1][0])
     assert abs(out[0][1] - out[1][1]) <= 2e-3 * abs(out[1][1])              # MIOpen's fp32 convolutions are the looser side
     assert_close(out[0][2].cpu().numpy(), out[1][2].cpu().numpy(), 2e-3, "inference after one step")
+
+
+# ------------------------------------------------------------------ bf16 mode (BASELINE configs[3]/[4])
+BF16_BOUND = 5e-2      # stated bound of the bf16 mode against the fp32 reference (max-abs/max and L2); measured 1-2.5e-2
+
+
+@pytest.mark.parametrize("name,M,B,T", [("e2e_M8_B2_T20.npz", 8, 2, 20), ("e2e_M9_B1_T10.npz", 9, 1, 10)])
+def test_bf16_mode_vs_reference_fixtures(dev, name, M, B, T):
+    """precision='bf16' (operands rounded to bf16 on the bf16 matrix cores, fp32 accumulate / norms / activations -- the
+    arithmetic autocast(bfloat16) gives the reference) cannot meet the 1e-4 bar; its error against the fp32 reference
+    fixtures is bounded at BF16_BOUND and printed."""
+    g = load(name)
+    net = _model(M, int(g["param_seed"]), dev)
+    net.precision = "bf16"
+    x = torch.from_numpy(paramgen.make_spec_input(B, T, 161, M, int(g["input_seed"]))).to(dev)
+    with torch.no_grad():
+        y = net(x)
+    m, l2 = assert_close(y.cpu().numpy(), g["out"], BF16_BOUND, "bf16 vs fp32 reference")
+    print(f"bf16 {name}: max-rel {m:.2e}, l2-rel {l2:.2e}")
+
+
+def test_bf16_c1_full_size_and_streaming_config5(dev):
+    """bf16 at the C1 size against the reference fixture, and BASELINE configs[4] as stated: 16 microphones, 8 s,
+    BatchNorm norms, streaming in bf16 -- streamed frames equal the offline bf16 call bit for bit, and the offline
+    call stays within BF16_BOUND of the oracle."""
+    import eabnet_amd
+    from oracle import eabnet_oracle as orc
+    g = load("c1_M8_T401.npz")
+    net = _model(8, int(g["param_seed"]), dev)
+    net.precision = "bf16"
+    wav = torch.from_numpy(paramgen.make_wave(1, 8, 64000, int(g["wave_seed"])))
+    with torch.no_grad():
+        y = net(eabnet_amd.stft_compress(wav.to(dev), 320, 160, torch.hann_window(320)))
+    m, l2 = assert_close(y.cpu().numpy(), g["out"], BF16_BOUND, "bf16 C1")
+    print(f"bf16 C1: max-rel {m:.2e}, l2-rel {l2:.2e}")
+    kw = dict(norm_type="BN")
+    M, T = 16, 801
+    net = _model(M, 1230, dev, **kw)
+    net.precision = "bf16"
+    x = torch.from_numpy(paramgen.make_spec_input(1, T, 161, M, 1231))
+    xd = x.to(dev)
+    with torch.no_grad():
+        off = net(xd)
+        ref = orc.eabnet_forward(torch_params(M, 1230, **kw), x, fast_lstm=True, **kw)
+    m, l2 = assert_close(off.cpu().numpy(), ref.numpy(), BF16_BOUND, "bf16 offline BN vs oracle")
+    print(f"bf16 config-5 shape: max-rel {m:.2e}, l2-rel {l2:.2e}")
+    for chunk in (1, 16):
+        st = net.stream_begin(1, T_max=T, chunk=chunk)
+        ys = torch.cat([st.step(xd[:, t:t + chunk]) for t in range(0, T, chunk)], dim=2)
+        assert torch.equal(ys, off), f"bf16 streaming chunk {chunk} differs from the offline bf16 call"

@@ -136,7 +136,7 @@ def test_f16x3_lowering_matches_reference_fixture():
     y = Emulator(prog, x).run()
     assert_close(y, g["out"], 2e-5)
     with pytest.raises(ValueError):
-        prg.lower(NetConfig(M=8), P, 1, 4, 161, precision="bf16")
+        prg.lower(NetConfig(M=8), P, 1, 4, 161, precision="fp8")
 
 
 def test_pack_f16x3_round_trip():
@@ -208,3 +208,20 @@ def test_emulated_post_filter_streaming_equals_offline():
     assert all(op.win for op in prog.ops) and prog.chunk == 3
     y = Emulator(prog, a, b).run_stream()
     assert np.array_equal(y, off)
+
+
+def test_bf16_lowering_stays_within_its_stated_bound():
+    """precision='bf16' (EAB_PREC_BF16: both operands of every contraction rounded to bf16, fp32 accumulation) against
+    the fp32 reference fixture: not a 1e-4 mode -- its error is stated (5e-2) and measured here on the emulator."""
+    g = load("e2e_M8_B2_T20.npz")
+    P = _params(8, int(g["param_seed"]))
+    x = paramgen.make_spec_input(2, 20, 161, 8, int(g["input_seed"]))
+    prog = prg.lower(NetConfig(M=8), P, 2, 20, 161, precision="bf16")
+    assert any(op.kind == prg.OP_CONV and op.precision == prg.PREC_BF16 for op in prog.ops)
+    assert prog.ops[0].precision == prg.PREC_F32, "the convolution on the raw network input stays exact"
+    y = Emulator(prog, x).run()
+    assert_close(y, g["out"], 5e-2, "bf16")
+    # streaming in bf16 is allowed (BASELINE config 5), f16x3 is not
+    prg.lower(NetConfig(M=2, norm_type="BN", p=1, q=1), _params(2, 3, norm_type="BN", p=1, q=1), 1, 8, 161, precision="bf16", chunk=2)
+    with pytest.raises(NotImplementedError):
+        prg.lower(NetConfig(M=2, norm_type="BN", p=1, q=1), _params(2, 3, norm_type="BN", p=1, q=1), 1, 8, 161, precision="f16x3", chunk=2)
