@@ -130,6 +130,8 @@ def main_train(a, rank, world, dev, is_dist):
     T = 1 + L // HOP
     net, _ = make_model(M, dev)
     net.train()
+    net.use_hip_training = not a.train_operator_path
+    net.precision = "bf16" if a.precision == "bf16" else "f32"
     pd_args = argparse.Namespace(mics=M, sr=SR, wav_len=seconds, win_size=0.020, win_shift=0.010, fft_num=N_FFT)
     wav = synth_waves(B, M, L, 1234 + rank).to(dev)
     tgt = synth_waves(B, 1, L, 4321 + rank).to(dev)
@@ -170,6 +172,15 @@ def main_train(a, rank, world, dev, is_dist):
     elapsed = dist.max_over_ranks(el, dev)
     assert bool(torch.isfinite(loss)), "training diverged"
     frames = world * B * T * a.steps
+    if a.train_operator_path:
+        if rank == 0:
+            print(json.dumps({"mode": "training step on PyTorch-ROCm operators (autograd_path.py): comparison line", "value": frames / elapsed,
+                              "unit": "frames/s (trained)", "n_gpus": world, "steps": a.steps, "ms_per_step": 1e3 * elapsed / a.steps,
+                              "final_loss": float(loss.detach())}))
+        if is_dist:
+            dist.barrier()
+            torch.distributed.destroy_process_group()
+        return
     bound = next(iter(net._train_bound.values()))
     prog = bound.prog
     out = {
@@ -177,14 +188,15 @@ def main_train(a, rank, world, dev, is_dist):
         "mode": "training step (BASELINE configs[3])",
         "value": frames / elapsed, "unit": "frames/s (trained)", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if net.precision == "f32" else "bf16 products (forward + dgrad convolutions), fp32 accumulate / wgrad / LSTM / norms / Adam",
+        "data": "synthetic",
         "config": {"workload": "BASELINE configs[3] (train_distributed.py:214-230) for the beam-former stage: per-GPU batch 6 x 6 s x "
                                "8 mics; prepare_data (noisy + target STFT), EaBNet forward, com_mag_mse_loss, backward, "
                                "clip_grad_norm_(1.0), Adam(5e-4); forward and backward on the HIP training programs",
                    "batch_per_gpu": B, "global_batch": world * B, "mics": M, "frames_per_utt": T,
                    "parallelism": f"dp{world}: " + ("torch DDP, one 64 MB bucket" if a.train_ddp else
                                                     "one flat RCCL all-reduce of the 2.84 M-float gradient per step")},
-        "final_loss": float(loss),
+        "final_loss": float(loss.detach()),
         "gflop_per_step": {"forward": prog.flops_fwd / 1e9, "backward": prog.flops_bwd / 1e9},
         "ranks": {"world_size_seen_by_torch_distributed": torch.distributed.get_world_size() if is_dist else 1,
                   "frames_per_s_per_rank": [B * T * a.steps / e for e in per_rank]},
@@ -247,12 +259,14 @@ def main():
     ap.add_argument("--pipeline", type=int, default=2,
                     help="batches in flight on separate HIP streams (eabnet_amd.Pipeline); 1 = strictly one step after the other")
     ap.add_argument("--no-next", action="store_true", help="skip the next-row measurements (post-filter, ISTFT)")
-    ap.add_argument("--precision", choices=("f32", "f16x3"), default="f32",
+    ap.add_argument("--precision", choices=("f32", "f16x3", "bf16"), default="f32",
                     help="MFMA arithmetic of the timed path (DESIGN.md §4.4)")
     ap.add_argument("--per-op", type=str, default="", help="write the per-op timing table (instrumented replay) here")
     ap.add_argument("--train", action="store_true",
                     help="BASELINE configs[3]: training step (prepare_data, forward, loss, backward, clip, Adam) on the HIP "
                          "training programs, per-GPU batch 6 x 6 s x 8 mics, one flat RCCL gradient all-reduce per step")
+    ap.add_argument("--train-operator-path", action="store_true",
+                    help="with --train: forward/backward on PyTorch-ROCm operators (autograd_path.py, MIOpen) -- the comparison line")
     ap.add_argument("--train-ddp", action="store_true", help="with --train: wrap in torch DistributedDataParallel (one 64 MB bucket, "
                                                              "gradient_as_bucket_view, static_graph) instead of the flat all-reduce")
     a = ap.parse_args()
@@ -619,8 +633,9 @@ def main():
             # latency of one step of `chunk` 10-ms frames = one hipGraph replay of the windowed program
             torch.manual_seed(2)
             sn = eabnet_amd.EaBNet(M=16, norm_type="BN").to(dev).eval()
-            stream_rows = {"config": "B=1, M=16, T_max=801 (8 s), norm_type=BN, fp32", "hop_ms": 10.0}
-            for chunk in (1, 16):
+            stream_rows = {"config": "B=1, M=16, T_max=801 (8 s), norm_type=BN; fp32 and (suffix _bf16) bf16 products", "hop_ms": 10.0}
+            for chunk, sprec in ((1, "f32"), (16, "f32"), (1, "bf16"), (16, "bf16")):
+                sn.precision = sprec
                 st = sn.stream_begin(1, T_max=801, chunk=chunk)
                 xs = 0.3 * torch.randn(1, chunk, 161, 16, 2, device=dev)
                 for _ in range(3):
@@ -633,7 +648,7 @@ def main():
                 torch.cuda.synchronize()
                 dts = (time.perf_counter() - t0) / nstep
                 assert bool(torch.isfinite(ys).all())
-                stream_rows[f"chunk{chunk}"] = {"ms_per_step": 1e3 * dts, "rtf": dts / (chunk * 0.010),
+                stream_rows[f"chunk{chunk}" + ("" if sprec == "f32" else "_bf16")] = {"ms_per_step": 1e3 * dts, "rtf": dts / (chunk * 0.010),
                                                 "algorithmic_latency_ms": 10.0 * chunk + 10.0}
                 st = None
             nxt["streaming"] = stream_rows

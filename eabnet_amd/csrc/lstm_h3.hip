@@ -204,6 +204,15 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
 
     const int u = wave * 16 + ln;
     const int hcol = (u >> 5) * 128 + (u & 31) * 2;         // byte offset of unit u inside a row (hi; lo at +64)
+    // bf16 mode writes h_t to HBM straight from the registers (exact fp32: a streamed chunk then restarts from the
+    // very value the offline run rounded): byte offsets of (sequence 4*lk + r, unit u)
+    unsigned hdir[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int sq = s0 + 4 * lk + r;
+        const int b = sq < S ? sq / F : 0, f = sq < S ? sq - b * F : 0;
+        hdir[r] = sq < S ? (unsigned)((((size_t)b * T * F + f) * 64 + u) * 4) : LH_OOB;
+    }
     for (int t = t_lo; t < t_hi; ++t) {
         const int cur = (t - t_lo) & 1, nxt = cur ^ 1;
         const f32x4 xn = load_x(t + 4);
@@ -229,9 +238,14 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
             cst[r] = fmaf(fg, cst[r], ig * gg);
             const float h = og * lh_tanh(cst[r]);
             const e16 hi = (e16)h;
-            const e16 lo = (e16)(h - (float)hi);           // (bf16 mode: only the write-back of h_t uses the residual)
             *reinterpret_cast<e16*>(hrow + (4 * lk + r) * LH_ROW) = hi;
-            *reinterpret_cast<e16*>(hrow + (4 * lk + r) * LH_ROW + 64) = lo;
+            if (BF) {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h), rh,
+                                                      hdir[r] != LH_OOB ? hdir[r] + (unsigned)t * t_stride : LH_OOB, 0, 0);
+            } else {
+                const e16 lo = (e16)(h - (float)hi);
+                *reinterpret_cast<e16*>(hrow + (4 * lk + r) * LH_ROW + 64) = lo;
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: keep the x prefetch in flight
         frags(hs[nxt], hh, hl);
@@ -244,7 +258,7 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
 #pragma unroll
         for (int g = 0; g < 4; ++g) accx[g] = f32x4{bia[g], bia[g], bia[g], bia[g]};
         mma(xh, xl, wxh, wxl, accx);
-        {
+        if (!BF) {
             const f32x4 hv = {lh_join<BF>(ph.x & 0xFFFF, pl.x & 0xFFFF), lh_join<BF>(ph.x >> 16, pl.x >> 16),
                               lh_join<BF>(ph.y & 0xFFFF, pl.y & 0xFFFF), lh_join<BF>(ph.y >> 16, pl.y >> 16)};
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), rh,

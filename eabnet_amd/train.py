@@ -109,7 +109,11 @@ def _split64(n: int) -> Tuple[int, int]:
 
 
 class TrainLowering:
-    def __init__(self, cfg: NetConfig, B: int, T: int, F: int = 161):
+    def __init__(self, cfg: NetConfig, B: int, T: int, F: int = 161, precision: str = "f32"):
+        if precision not in ("f32", "bf16"):
+            raise ValueError("training precision is 'f32' or 'bf16' (bf16: forward and dgrad contractions on the bf16 matrix "
+                             "cores; weight gradients, LSTM, norms and the optimiser state stay fp32)")
+        self.prec = prg.PREC_CODE[precision]
         if not supported(cfg):
             raise NotImplementedError("the HIP training path covers the default topology with InstanceNorm")
         cfg.check_supported()
@@ -233,6 +237,8 @@ class TrainLowering:
                         epi=epi, aux=aux, dst=dst, dst_acc=dst_acc, Cout=Cout, stats=stats, nsets=1 if stats else 0,
                         stat_slope0=None, stat_slope1=None, stat_tiles=stat_tiles, stat_tile0=stat_tile0, bm=bm, name=name)
         op.glu_dump = glu_dump
+        if self.prec != prg.PREC_F32 and s0.ref.arena != "in" and s0.C % 4 == 0 and (s1 is None or s1.C % 4 == 0):
+            op.precision = self.prec                  # the convolution on the raw network input stays exact
         self.emit.append(op)
         fl = 2 * self.B * self.T * No * N * len(dt) * (s0.C + (s1.C if s1 else 0))
         if self.emit is self.fwd:
@@ -652,8 +658,8 @@ class TrainProgram:
     grad_taps: Dict[str, tuple] = field(default_factory=dict)       # name -> (Ref of d loss / d activation, F, C)
 
 
-def lower_train(cfg: NetConfig, B: int, T: int, F: int = 161) -> TrainProgram:
-    return TrainLowering(cfg, B, T, F).build()
+def lower_train(cfg: NetConfig, B: int, T: int, F: int = 161, precision: str = "f32") -> TrainProgram:
+    return TrainLowering(cfg, B, T, F, precision).build()
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -796,12 +802,13 @@ def forward_train(module, inpt: torch.Tensor) -> torch.Tensor:
     B, T, F, M, _ = inpt.shape
     x = inpt.detach().to(torch.float32).contiguous()
     cache = module.__dict__.setdefault("_train_bound", {})
-    key = (B, T, F, str(x.device))
+    prec = "bf16" if module.precision == "bf16" else "f32"
+    key = (B, T, F, str(x.device), prec)
     bound = cache.get(key)
     if bound is None:
         cache.clear()
         with torch.cuda.device(x.device):
-            bound = cache[key] = TrainBound(lower_train(module.cfg, B, T, F), x.device)
+            bound = cache[key] = TrainBound(lower_train(module.cfg, B, T, F, prec), x.device)
     sd = dict(module.named_parameters())
     params = [sd[k] for k in bound.prog.keys]
     sync = module.__dict__.get("grad_allreduce", None)          # None | True (default group) | a process group

@@ -251,10 +251,7 @@ class Emulator:
                 hh = h.astype(np.float16).astype(np.float32)
                 h = hh + (h - hh).astype(np.float16).astype(np.float32)
                 out[:, t] = h
-            if bf:  # h_t leaves as bf16 hi + bf16 residual; the recurrence multiplies the bf16 value (rounded again above)
-                hh = bf16_round(h)
-                h = hh + bf16_round(h - hh)
-                out[:, t] = h
+            # bf16: h_t leaves as exact fp32; the recurrence multiplies its bf16 rounding (applied to `a` above)
 
     def bfw(self, op: prg.BfwOp):
         B, T, F, M = op.B, op.T, op.F, op.M
