@@ -107,6 +107,7 @@ _SIGS = {
     "eab_gate_fwd_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_longlong, C.c_void_p]),
     "eab_gate_bwd_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong, C.c_void_p]),
     "eab_add_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_longlong, C.c_void_p]),
+    "eab_copy_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_longlong, C.c_void_p]),
     "eab_relu_bwd_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_longlong, C.c_void_p]),
     "eab_colsum_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_longlong, C.c_int, C.c_void_p]),
     "eab_filter_sum_bwd_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p]),

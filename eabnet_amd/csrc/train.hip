@@ -365,6 +365,25 @@ extern "C" int eab_gate_bwd_f32(const float* dz, const float* a, const float* r,
     EAB_RETURN_LAUNCH_STATUS();
 }
 
+// dst = src, 16 bytes per thread.  Used for host -> device uploads from PINNED host memory (device-visible): a copy
+// KERNEL instead of hipMemcpyAsync, because DMA-engine copies submitted between compute kernels cost ~5 ms each on
+// the measured stack (tools/diag_pd.py) while the same bytes through a kernel take 0.6 ms.
+__global__ __launch_bounds__(TR_THREADS) void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n4, long long n) {
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = i0; i < n4; i += stride) reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[i];
+    for (long long i = 4 * n4 + i0; i < n; i += stride) dst[i] = src[i];
+}
+
+extern "C" int eab_copy_f32(const float* src, float* dst, long long n, eab_stream_t stream) {
+    EAB_CHECK_ARG(src && dst && n >= 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0);
+    if (n == 0) return EAB_OK;
+    long long g = (n / 4 + TR_THREADS - 1) / TR_THREADS;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)g), dim3(TR_THREADS), 0, eab_stream(stream), src, dst, n / 4, n);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
 // out = a + b   /   dx = y > 0 ? dy : 0
 __global__ __launch_bounds__(TR_THREADS) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                          float* __restrict__ out, long long n4) {

@@ -884,6 +884,65 @@ def stft_compress(wav: torch.Tensor, n_fft: int, hop: int, window: torch.Tensor,
     return out
 
 
+class _HostStager:
+    """Host -> device path of ``prepare_data`` (train_distributed.py:76-77 does two blocking ``.to(device)``): a ring of
+    pinned staging buffers and resident device buffers plus a dedicated copy stream.  The upload of batch k+1 is
+    enqueued while batch k still computes and nothing on the path allocates or synchronises the device; a slot is
+    reused only after the kernels that read its device buffer have been enqueued AND its previous copy completed."""
+
+    always_stage = False
+
+    def __init__(self, device: torch.device, depth: int = 3):
+        self.device, self.depth, self.k = device, depth, 0
+        self.slots: Dict[tuple, list] = {}
+        self.stream = torch.cuda.Stream(device=device)
+
+    def upload(self, t: torch.Tensor) -> Tuple[torch.Tensor, "torch.cuda.Event"]:
+        """CPU tensor -> contiguous fp32 device tensor, ordered on the CURRENT stream.  Returns (tensor, consumed):
+        record `consumed` on the current stream after the last kernel that reads the tensor has been enqueued."""
+        key = tuple(t.shape)
+        ring = self.slots.get(key)
+        if ring is None:
+            if len(self.slots) > 8:
+                torch.cuda.synchronize(self.device)
+                self.slots.clear()
+            ring = self.slots[key] = [dict(pin=torch.empty(key, dtype=torch.float32).pin_memory(),
+                                           dev=torch.empty(key, dtype=torch.float32, device=self.device),
+                                           copied=torch.cuda.Event(), consumed=torch.cuda.Event(), used=False)
+                                      for _ in range(self.depth)]
+        self.k += 1
+        slot = ring[self.k % self.depth]
+        if slot["used"]:
+            slot["copied"].synchronize()                 # the pinned buffer is free again (depth steps ago)
+            self.stream.wait_event(slot["consumed"])     # the device buffer's readers were enqueued before this
+        src = t
+        if self.always_stage or not (t.is_pinned() and t.is_contiguous() and t.dtype == torch.float32):
+            slot["pin"].copy_(t)                         # pageable / strided / other dtype: one host pass into pinned memory
+            src = slot["pin"]
+        with torch.cuda.stream(self.stream):
+            # a copy KERNEL reading the pinned buffer over the bus (device-visible under unified addressing), not
+            # hipMemcpyAsync: DMA copies submitted between compute kernels cost milliseconds each on this stack
+            _lib.check(_lib.load().eab_copy_f32(src.data_ptr(), slot["dev"].data_ptr(), src.numel(), C.c_void_p(self.stream.cuda_stream)),
+                       "eab_copy_f32")
+            slot["copied"].record(self.stream)
+        torch.cuda.current_stream(self.device).wait_event(slot["copied"])
+        slot["used"] = True
+        return slot["dev"], slot["consumed"]
+
+
+_STAGERS: Dict[str, _HostStager] = {}
+
+
+def _upload(t: torch.Tensor, device: torch.device):
+    """(device tensor, event to record after its consumers) for any input of prepare_data"""
+    if t.is_cuda:
+        return t.to(device), None
+    st = _STAGERS.get(str(device))
+    if st is None:
+        st = _STAGERS[str(device)] = _HostStager(device)
+    return st.upload(t)
+
+
 def prepare_data(x: torch.Tensor, target: torch.Tensor, device, args):
     """Reference train_distributed.py:68-95.  ``args`` provides mics, sr,
     wav_len, win_size, win_shift (seconds) and fft_num.
@@ -895,11 +954,20 @@ def prepare_data(x: torch.Tensor, target: torch.Tensor, device, args):
     if win_size != fft_num:
         raise NotImplementedError("the HIP front end implements win_size == fft_num (the reference's 320/320)")
     batch_size = x.shape[0]
-    noisy_wav = x.to(device).contiguous().view(batch_size, args.mics, -1)
-    target_wav = target.to(device).reshape(batch_size, 1, -1)
-    window = torch.hann_window(win_size)
-    noisy_stft = stft_compress(noisy_wav, fft_num, win_shift, window, 0)
-    target_stft = stft_compress(target_wav, fft_num, win_shift, window, 1)
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    with torch.cuda.device(device):
+        xd, ev_x = _upload(x, device)
+        td, ev_t = _upload(target, device)
+        noisy_wav = xd.contiguous().view(batch_size, args.mics, -1)
+        target_wav = td.reshape(batch_size, 1, -1)
+        window = torch.hann_window(win_size)
+        noisy_stft = stft_compress(noisy_wav, fft_num, win_shift, window, 0)
+        target_stft = stft_compress(target_wav, fft_num, win_shift, window, 1)
+        for ev in (ev_x, ev_t):
+            if ev is not None:
+                ev.record(torch.cuda.current_stream(device))         # the staged waves have no reader after this point
     return noisy_stft, target_stft
 
 

@@ -427,6 +427,8 @@ int eab_glu_bwd_f32(const float* dy, const float* dump, float* dz, long long row
 int eab_gate_fwd_f32(const float* a, const float* r, float* z, long long n, eab_stream_t stream);
 int eab_gate_bwd_f32(const float* dz, const float* a, const float* r, float* da, float* dr, long long n, eab_stream_t stream);
 int eab_add_f32(const float* a, const float* b, float* out, long long n, eab_stream_t stream);
+/* dst = src as a kernel; src may be PINNED host memory (the upload of prepare_data, train_distributed.py:76-77) */
+int eab_copy_f32(const float* src, float* dst, long long n, eab_stream_t stream);
 int eab_relu_bwd_f32(const float* dy, const float* y, float* dx, long long n, eab_stream_t stream);
 /* out[n] += sum over rows of x[row][n]  (bias gradients) */
 int eab_colsum_f32(const float* x, float* out, long long rows, int N, eab_stream_t stream);
