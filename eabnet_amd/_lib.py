@@ -43,6 +43,8 @@ class ConvDesc(C.Structure):
         ("fin_tiles", C.c_int32), ("fin_nsets", C.c_int32), ("fin_count", C.c_int32), ("fin_eps", C.c_float),
         ("precision", C.c_int32), ("korder", C.c_int32),
         ("win", TimeWindow),
+        ("fz_counter", C.c_void_p), ("fz_gamma0", C.c_void_p), ("fz_beta0", C.c_void_p), ("fz_xf0", C.c_void_p),
+        ("fz_gamma1", C.c_void_p), ("fz_beta1", C.c_void_p), ("fz_xf1", C.c_void_p), ("fz_eps", C.c_float),
         ("glu_dump", C.c_void_p),
     ]
 

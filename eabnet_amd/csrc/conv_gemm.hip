@@ -54,6 +54,7 @@ struct CgSmem {
     float xsl[2][CG_XFC];        // PReLU slopes
     int dt[EAB_MAX_TAPS];
     int ioff[EAB_MAX_TAPS];
+    int last;                    // fused finalisation: this workgroup wrote the last partial of its batch element
 };
 
 template <int XF>
@@ -827,6 +828,57 @@ __global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_de
                 }
             }
         }
+        if (d.fz_counter) {
+            // ---- fused finalisation: the last-arriving tile of batch element b merges all partials.
+            // release our partial (agent scope), count the arrival, and if we are last acquire everyone else's.
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) sm.last = atomicAdd(&d.fz_counter[b], 1) == d.stat_tiles - 1;
+            __syncthreads();
+            if (sm.last) {
+                __threadfence();
+                // thread -> (set s, channel c, tile slice): partial sums over tiles slice, slice+NSL, .. in fp64,
+                // combined through LDS in slice order: the same fixed order whichever workgroup does it.
+                const int nch = d.nsets * Cout;                       // <= 256
+                const int NSL = CG_THREADS / nch;                     // tile slices (host: 1 <= nch <= 256)
+                const int e = tid % nch, slice = tid / nch;
+                const int s = e / Cout, c = e - s * Cout;
+                double* dred = reinterpret_cast<double*>(&sm.a[0]);   // [3][NSL][nch] doubles (<= 6 KB)
+                double sn = 0.0, sm_ = 0.0, sq = 0.0;
+                if (slice < NSL) {
+                    const float* p = d.stats + (((size_t)b * d.stat_tiles) * d.nsets + s) * Cout * 4 + (size_t)c * 4;
+                    const size_t stride = (size_t)d.nsets * Cout * 4;
+                    for (int t = slice; t < d.stat_tiles; t += NSL) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(p + (size_t)t * stride);
+                        const double n = (double)v[0], mu = (double)v[1];
+                        sn += n;
+                        sm_ = fma(n, mu, sm_);
+                        sq += fma(n * mu, mu, (double)v[2]);
+                    }
+                    dred[(0 * NSL + slice) * nch + e] = sn;
+                    dred[(1 * NSL + slice) * nch + e] = sm_;
+                    dred[(2 * NSL + slice) * nch + e] = sq;
+                }
+                __syncthreads();
+                if (slice == 0) {
+                    sn = sm_ = sq = 0.0;
+                    for (int k = 0; k < NSL; ++k) {
+                        sn += dred[(0 * NSL + k) * nch + e];
+                        sm_ += dred[(1 * NSL + k) * nch + e];
+                        sq += dred[(2 * NSL + k) * nch + e];
+                    }
+                    const double mean = sn > 0.0 ? sm_ / sn : 0.0;
+                    double var = sn > 0.0 ? sq / sn - mean * mean : 0.0;
+                    if (var < 0.0) var = 0.0;
+                    const float* gm = s == 0 ? d.fz_gamma0 : d.fz_gamma1;
+                    const float* bt = s == 0 ? d.fz_beta0 : d.fz_beta1;
+                    float* xf = s == 0 ? d.fz_xf0 : d.fz_xf1;
+                    const double scale = (double)gm[c] / sqrt(var + (double)d.fz_eps);
+                    *reinterpret_cast<float2*>(&xf[((size_t)b * Cout + c) * 2]) = make_float2((float)scale, (float)((double)bt[c] - mean * scale));
+                }
+                if (tid == 0) d.fz_counter[b] = 0;                    // re-armed for the next replay of the program
+            }
+        }
     }
 }
 
@@ -962,6 +1014,10 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
     EAB_CHECK_ARG((d->epi != EAB_EPI_MULSIG && d->epi != EAB_EPI_ADD) || d->aux);
     EAB_CHECK_ARG(d->nsets >= 0 && d->nsets <= 2 && (d->nsets == 0) == (d->stats == nullptr));
     EAB_CHECK_ARG(d->bm == 64 || d->bm == 128);
+    if (d->fz_counter) {
+        EAB_CHECK_ARG(d->stats && d->nsets >= 1 && d->nsets * d->Cout <= CG_THREADS && d->win.pos == nullptr);
+        EAB_CHECK_ARG(d->fz_gamma0 && d->fz_beta0 && d->fz_xf0 && (d->nsets == 1 || (d->fz_gamma1 && d->fz_beta1 && d->fz_xf1)));
+    }
     if (d->stats) {
         const int tiles = eab_conv_tiles(d->T, d->No, d->bm);
         EAB_CHECK_ARG(d->stat_tile0 >= 0 && d->stat_tile0 + tiles <= d->stat_tiles);

@@ -81,6 +81,7 @@ class _Bound:
         self.device = device
         self.weights = torch.from_numpy(prog.weights).to(device)
         self.acts = torch.empty(max(prog.act_floats, 1), dtype=torch.float32, device=device)
+        self.reset_counters()
         self.ops = (_lib.Op * len(prog.ops))()
         # streaming programs: the frame position every windowed op reads (device memory, so one captured
         # graph serves all chunks)
@@ -93,6 +94,12 @@ class _Bound:
         self.static_in2 = None
         self.static_out = None
         self.graph_failed = False
+
+    def reset_counters(self) -> None:
+        """arrival counters of the fused InstanceNorm finalisation: zero before the first run (the kernels re-arm them
+        after every complete run; needed again only if the arena was overwritten from outside, as the tests do)"""
+        for ref, n in self.prog.zero_init:
+            self.acts[ref.off:ref.off + n].zero_()
 
     def __del__(self):
         # The arenas may have been used on streams other than the one they were allocated under (Pipeline slot
@@ -159,8 +166,10 @@ class _Bound:
                 d = o.conv
                 for f in ("src0", "src1", "xf0", "xf1", "slope0", "slope1", "w", "bias", "aux", "dst", "dst_acc",
                           "stats", "stat_slope0", "stat_slope1", "fin_stats", "fin_gamma0", "fin_beta0",
-                          "fin_gamma1", "fin_beta1"):
+                          "fin_gamma1", "fin_beta1", "fz_counter", "fz_gamma0", "fz_beta0", "fz_xf0", "fz_gamma1", "fz_beta1",
+                          "fz_xf1"):
                     setattr(d, f, A(getattr(op, f)))
+                d.fz_eps = float(op.fz_eps)
                 for f in ("C0", "C1", "xf_mode", "N", "Kpad", "B", "T", "Fin", "Fout", "No", "ostride", "ophase",
                           "istride", "epi", "Cout", "nsets", "stat_tiles", "stat_tile0", "bm", "fin_tiles",
                           "fin_nsets", "fin_count", "precision", "korder"):

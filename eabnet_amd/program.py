@@ -119,6 +119,14 @@ class ConvOp:
     win: bool = False                    # streaming: only the time rows of the current chunk
     name: str = ""
     kind: int = OP_CONV
+    fz_counter: Optional[Ref] = None     # fused InstanceNorm finalisation by the last-arriving tile (eab_conv_desc.fz_*)
+    fz_gamma0: Optional[Ref] = None
+    fz_beta0: Optional[Ref] = None
+    fz_xf0: Optional[Ref] = None
+    fz_gamma1: Optional[Ref] = None
+    fz_beta1: Optional[Ref] = None
+    fz_xf1: Optional[Ref] = None
+    fz_eps: float = 0.0
 
 
 @dataclass
@@ -341,6 +349,7 @@ class Program:
     lanes: List[int] = field(default_factory=list)
     sync: Dict[int, list] = field(default_factory=dict)
     chunk: int = 0                 # > 0: streaming program, every op works on `chunk` frames from a device-side position
+    zero_init: List[Tuple[Ref, int]] = field(default_factory=list)      # (arena ref, floats) that must be zero before the first replay
 
 
 class Lowering:
@@ -379,6 +388,8 @@ class Lowering:
         self.dump_bfw = dump_bfw
         self.bn = cfg.norm_type == "BN"
         self.add = cfg.intra_connect == "add"
+        self.zero_init: List[Tuple[Ref, int]] = []              # arena regions that must be zero before the first replay
+        self.fuse_fin = os.environ.get("EAB_FUSE_FIN", "1") != "0"  # tuning knob: 0 = stand-alone finalize launches
         self._lane_marks: List[Tuple[int, int]] = [(0, 0)]      # (first op index, stream lane from there on)
         self.sync: Dict[int, list] = {}
 
@@ -504,6 +515,23 @@ class Lowering:
         self.flops += 2 * self.B * self.T * No * N * len(dt) * (C0 + C1)
         return op
 
+    def fuse_finalize(self, ops: Sequence[ConvOp], C: int, norms: Sequence[str]) -> List[Ref]:
+        """InstanceNorm finalisation inside the producing launches `ops` (all feeding the same statistics): the tile
+        that arrives last per utterance merges the partials and writes the (scale, shift) tables -- no extra launch.
+        The arrival counters live in the activation arena (zeroed when the program is bound, re-armed by the kernel)."""
+        nsets = len(norms)
+        xfs = [self.alloc(self.B * C * 2) for _ in range(nsets)]
+        counter = self.alloc(self.B)
+        self.zero_init.append((counter, self.B))
+        g = [self.vec(f"{n}.norm.weight") for n in norms]
+        b = [self.vec(f"{n}.norm.bias") for n in norms]
+        for op in ops:
+            op.fz_counter, op.fz_eps = counter, EPS_IN
+            op.fz_gamma0, op.fz_beta0, op.fz_xf0 = g[0], b[0], xfs[0]
+            if nsets == 2:
+                op.fz_gamma1, op.fz_beta1, op.fz_xf1 = g[1], b[1], xfs[1]
+        return xfs
+
     def emit_finalize(self, name, stats, C, nsets, stat_tiles, count, norms: Sequence[str]) -> List[Ref]:
         xfs = [self.alloc(self.B * C * 2) for _ in range(nsets)]
         g = [self.vec(f"{n}.norm.weight") for n in norms]
@@ -537,12 +565,15 @@ class Lowering:
         tiles = conv_tiles(self.T, Fout, bm)
         xf = self.fixed_norm(norm, Cout)
         stats = self.alloc(self.B * tiles * Cout * 4) if xf is None else None
-        self.emit_conv(name, srcs, wref, bref, N, wp.shape[1], Fout, Fout, 1, 0, 2,
-                       [a - (kt - 1) for a, _ in taps], [c for _, c in taps],
-                       EPI_GLU if glu else EPI_LINEAR, dst, stats, 1 if stats else 0, (None, None),
-                       tiles if stats else 0, 0, bm)
+        op = self.emit_conv(name, srcs, wref, bref, N, wp.shape[1], Fout, Fout, 1, 0, 2,
+                            [a - (kt - 1) for a, _ in taps], [c for _, c in taps],
+                            EPI_GLU if glu else EPI_LINEAR, dst, stats, 1 if stats else 0, (None, None),
+                            tiles if stats else 0, 0, bm)
         if xf is None:
-            xf, = self.emit_finalize(name + ".in", stats, Cout, 1, tiles, self.T * Fout, [norm])
+            if self.fuse_fin:
+                xf, = self.fuse_finalize([op], Cout, [norm])
+            else:
+                xf, = self.emit_finalize(name + ".in", stats, Cout, 1, tiles, self.T * Fout, [norm])
         return Act(dst, Fout, Cout, xf, self.vec(f"{act}.weight"), XF_NORM_PRELU)
 
     def conv2d_transposed(self, name: str, srcs: Sequence[Act], wkey: str, glu: bool, norm: str, act: str,
@@ -571,16 +602,20 @@ class Lowering:
         tiles = [conv_tiles(self.T, n, bm) for n in No]
         xf = self.fixed_norm(norm, Cout)
         stats = self.alloc(self.B * sum(tiles) * Cout * 4) if xf is None else None
+        phase_ops = []
         for ph in (0, 1):
             taps = [(a, c) for a in range(kt) for c in range(ph, kf, 2)]
             wp = pack_taps(wn, [a * kf + c for a, c in taps])
             wref = self.W.add(f"{wkey}.weight#packed.ph{ph}", wp)
-            self.emit_conv(f"{name}.ph{ph}", srcs, wref, bref, N, wp.shape[1], Fout, No[ph], 2, ph, 1,
-                           [-a for a, _ in taps], [-(c - ph) // 2 for _, c in taps],
-                           EPI_GLU if glu else EPI_LINEAR, dst, stats, 1 if stats else 0, (None, None),
-                           sum(tiles) if stats else 0, (0 if ph == 0 else tiles[0]) if stats else 0, bm)
+            phase_ops.append(self.emit_conv(f"{name}.ph{ph}", srcs, wref, bref, N, wp.shape[1], Fout, No[ph], 2, ph, 1,
+                                            [-a for a, _ in taps], [-(c - ph) // 2 for _, c in taps],
+                                            EPI_GLU if glu else EPI_LINEAR, dst, stats, 1 if stats else 0, (None, None),
+                                            sum(tiles) if stats else 0, (0 if ph == 0 else tiles[0]) if stats else 0, bm))
         if xf is None:
-            xf, = self.emit_finalize(name + ".in", stats, Cout, 1, sum(tiles), self.T * Fout, [norm])
+            if self.fuse_fin:
+                xf, = self.fuse_finalize(phase_ops, Cout, [norm])
+            else:
+                xf, = self.emit_finalize(name + ".in", stats, Cout, 1, sum(tiles), self.T * Fout, [norm])
         return Act(dst, Fout, Cout, xf, self.vec(f"{act}.weight"), XF_NORM_PRELU)
 
     def materialise(self, name: str, a: Act, b: Optional[Act] = None) -> Act:
@@ -735,7 +770,7 @@ class Lowering:
                                   name="bf_map+fs"))
             self.flops += 2 * B * T * F * 64 * wk.shape[0]
             return Program(cfg, B, T, F, self.ops, self.W.flat(), self.act_size, self.taps, self.flops,
-                           lanes=[0] * len(self.ops), chunk=self.chunk)
+                           lanes=[0] * len(self.ops), chunk=self.chunk, zero_init=self.zero_init)
 
         # LSTM_BF (EaBNet.py:600-614)
         h = e
@@ -764,7 +799,7 @@ class Lowering:
                               name="bf_map.w_dnn+fs"))
         self.flops += 2 * B * T * F * 64 * (64 + 2 * M)
         return Program(cfg, B, T, F, self.ops, self.W.flat(), self.act_size, self.taps, self.flops,
-                       lanes=[0] * len(self.ops), chunk=self.chunk)
+                       lanes=[0] * len(self.ops), chunk=self.chunk, zero_init=self.zero_init)
 
 
 class GagLowering(Lowering):
@@ -893,7 +928,7 @@ class GagLowering(Lowering):
                                      B=B, T=T, F=F, act=act, win=bool(self.chunk), name=f"gags.{gi}.crm"))
             pre = nxt
         return Program(cfg, B, T, F, self.ops, self.W.flat(), self.act_size, self.taps, self.flops,
-                       lanes=self.lane_of_ops(), sync=self.sync, chunk=self.chunk)
+                       lanes=self.lane_of_ops(), sync=self.sync, chunk=self.chunk, zero_init=self.zero_init)
 
 
 def lower(cfg, params: Dict[str, np.ndarray], B: int, T: int, F: int = 161,

@@ -236,6 +236,19 @@ typedef struct eab_conv_desc {
     /* streaming: restrict the launch to a window of time rows (see eab_time_window below);
      * needs stats == NULL, fin_stats == NULL and causal taps (dt <= 0) */
     eab_time_window win;
+    /* Fused InstanceNorm finalisation (replaces the eab_in_finalize_f32 launch behind this convolution): when
+     * fz_counter != NULL, the workgroup that writes the LAST of the stat_tiles partials of batch element b (over all
+     * launches feeding this norm; arrival counted in fz_counter[b], which must be zero before the first launch and is
+     * re-armed to zero by that workgroup) merges them -- fp64, fixed tile order, so the result does not depend on which
+     * workgroup came last -- and writes fz_xf<s>[b][c] = (scale, shift) for s < nsets with (fz_gamma<s>, fz_beta<s>). */
+    int32_t* fz_counter;
+    const float* fz_gamma0;
+    const float* fz_beta0;
+    float* fz_xf0;
+    const float* fz_gamma1;
+    const float* fz_beta1;
+    float* fz_xf1;
+    float fz_eps;
     /* training (EAB_EPI_GLU only): optional [B][T][Fout][N] dump of the gated epilogue's two factors in the packed
      * column order -- value columns hold acc+bias, gate columns hold sigmoid(acc+bias) -- read by eab_glu_bwd_f32 */
     float* glu_dump;

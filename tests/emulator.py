@@ -71,6 +71,8 @@ class Emulator:
         }
         if x_in2 is not None:
             self.arena["in2"] = np.ascontiguousarray(x_in2, dtype=np.float32).reshape(-1)
+        for ref, n in getattr(prog, "zero_init", ()):           # arrival counters of the fused finalisation (zeroed at bind)
+            self.arena[ref.arena][ref.off:ref.off + n] = 0.0
 
     def v(self, ref, shape):
         if ref is None:
@@ -195,6 +197,21 @@ class Emulator:
                     st[:, op.stat_tile0 + t, s, :, 1] = mu
                     st[:, op.stat_tile0 + t, s, :, 2] = ((blk - mu[:, None]) ** 2).sum(1)
                     st[:, op.stat_tile0 + t, s, :, 3] = 0.0
+            if op.fz_counter is not None:
+                # fused finalisation: the tile that completes the count of a batch element merges all partials (the
+                # counter is an int32 in the kernel; its bit pattern is kept in the fp32 arena here) and re-arms it
+                cnt = self.v(op.fz_counter, (B,)).view(np.int32)
+                cnt += tiles
+                assert np.all(cnt <= op.stat_tiles)
+                if np.all(cnt == op.stat_tiles):
+                    full = st.astype(np.float64)
+                    assert not np.isnan(full).any(), f"{op.name}: statistics partials not fully written"
+                    for s, (g, b, xf) in enumerate(((op.fz_gamma0, op.fz_beta0, op.fz_xf0), (op.fz_gamma1, op.fz_beta1, op.fz_xf1))[:op.nsets]):
+                        mean, var = _merge_welford(full[:, :, s])
+                        scale = self.v(g, (Cout,)) / np.sqrt(var + op.fz_eps)
+                        o = self.v(xf, (B, Cout, 2))
+                        o[..., 0], o[..., 1] = scale, self.v(b, (Cout,)) - mean * scale
+                    cnt[:] = 0
 
     def finalize(self, op: prg.FinalizeOp):
         st = self.v(op.stats, (op.B, op.stat_tiles, op.nsets, op.C, 4)).astype(np.float64)

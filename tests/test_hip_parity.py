@@ -140,6 +140,7 @@ def test_every_op_matches_the_emulator(dev, M, B, T, pq, precision):
     emu = Emulator(prog, x)
     bound = _Bound(prog, dev)
     bound.acts.fill_(float("nan"))
+    bound.reset_counters()
     xin = torch.from_numpy(x).to(dev)
     out = torch.full((B, 2, T, 161), float("nan"), device=dev)
     bound.bind(xin.data_ptr(), out.data_ptr())
@@ -937,6 +938,7 @@ def test_c2_size_nan_poisoned_workspace(dev, precision):
         assert bound.graph is not None
         for _ in range(2):
             bound.acts.fill_(float("nan"))
+            bound.reset_counters()
             bound.static_out.fill_(float("nan"))
             bound.static_in.fill_(float("nan"))
             y = net(ns)
@@ -945,6 +947,7 @@ def test_c2_size_nan_poisoned_workspace(dev, precision):
         y0 = net(ns).clone()
         b2 = net._last[0]
         b2.acts.fill_(float("nan"))
+        b2.reset_counters()
         y1 = net(ns)
         assert torch.isfinite(y1).all() and torch.equal(y1, y0) and torch.equal(y0, ref)
     assert_close(ref[0:1].cpu().numpy(), g["out"], TOL_HIP, "slot 0 vs reference fixture")
