@@ -389,7 +389,10 @@ class Lowering:
         self.bn = cfg.norm_type == "BN"
         self.add = cfg.intra_connect == "add"
         self.zero_init: List[Tuple[Ref, int]] = []              # arena regions that must be zero before the first replay
-        self.fuse_fin = os.environ.get("EAB_FUSE_FIN", "1") != "0"  # tuning knob: 0 = stand-alone finalize launches
+        # InstanceNorm finalisation inside the producing convolution (last-arriving tile): implemented and parity-green, but
+        # the agent-scope release every tile needs (__threadfence = L2 write-back on a multi-XCD part) doubled the
+        # convolution time (7.2 -> 14.3 ms per step, gpurun_out/r02_b4.json), so the stand-alone launches stay the default
+        self.fuse_fin = os.environ.get("EAB_FUSE_FIN", "0") == "1"
         self._lane_marks: List[Tuple[int, int]] = [(0, 0)]      # (first op index, stream lane from there on)
         self.sync: Dict[int, list] = {}
 
