@@ -1251,3 +1251,53 @@ def test_bf16_c1_full_size_and_streaming_config5(dev):
         st = net.stream_begin(1, T_max=T, chunk=chunk)
         ys = torch.cat([st.step(xd[:, t:t + chunk]) for t in range(0, T, chunk)], dim=2)
         assert torch.equal(ys, off), f"bf16 streaming chunk {chunk} differs from the offline bf16 call"
+
+
+def test_config4_ddp_training_on_the_hip_programs(dev):
+    """BASELINE configs[3] on one rank: train_distributed.py's step (:218-230) for the beam-former stage with forward and
+    backward on the HIP training programs, (a) under torch DistributedDataParallel over the RCCL backend (one 64 MB
+    bucket, gradient_as_bucket_view, static_graph -- SURVEY §5) and (b) with the built-in flat gradient all-reduce; both
+    give the gradients of a plain (unsynchronised) step, fp32 and bf16 products both train."""
+    import os
+    import torch.distributed as dist
+    import eabnet_amd
+    from eabnet_amd import train as tr
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        x = torch.from_numpy(paramgen.make_spec_input(2, 24, 161, 4, 170)).to(dev)
+        label = torch.from_numpy(paramgen.make_spec_input(2, 24, 161, 1, 171)[..., 0, :]).permute(0, 3, 1, 2).contiguous().to(dev)
+        grads = {}
+        for mode in ("plain", "ddp", "flat"):
+            net = _model(4, 940, dev, p=2, q=1).train()
+            model = net
+            if mode == "ddp":
+                model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[dev.index], bucket_cap_mb=64,
+                                                                  gradient_as_bucket_view=True, static_graph=True)
+            elif mode == "flat":
+                tr.broadcast_parameters(net)
+                tr.enable_flat_allreduce(net)
+            opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+            loss = eabnet_amd.com_mag_mse_loss(model(x), label, [24, 24])
+            loss.backward()
+            assert getattr(net, "_train_bound", None), "the HIP training path did not engage"
+            grads[mode] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()
+            torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+            opt.step()
+            assert torch.isfinite(loss)
+        assert_close(grads["ddp"].cpu().numpy(), grads["plain"].cpu().numpy(), 1e-5, "DDP gradients")          # (wgrad accumulates with atomics: order varies)
+        assert_close(grads["flat"].cpu().numpy(), grads["plain"].cpu().numpy(), 1e-5, "flat all-reduce gradients")
+        net = _model(4, 940, dev, p=2, q=1).train()
+        net.precision = "bf16"
+        loss_b = eabnet_amd.com_mag_mse_loss(net(x), label, [24, 24])
+        loss_b.backward()
+        gb = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+        assert torch.isfinite(gb).all()
+        m, l2 = rel_errs(gb.cpu().numpy(), grads["plain"].cpu().numpy())
+        print(f"bf16 training gradients vs fp32: max-rel {m:.2e}, l2-rel {l2:.2e}")
+        assert l2 < 0.1
+    finally:
+        dist.destroy_process_group()
