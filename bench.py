@@ -41,6 +41,17 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0
 
 
+def kernel_source_sha() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources: committed PMC summaries carry it, and `roofline.traffic`
+    is reported only when the summary was taken on the kernels of this tree (there is no git on the GPU box)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "eabnet_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "eabnet_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def mac_per_frame(M: int) -> int:
     """SURVEY §0 / BASELINE.md: conv + linear + LSTM-gate MACs per STFT frame."""
     return 44_404_736 + 222_848 * M
@@ -450,7 +461,9 @@ def main():
             # half of a wide coalesced read stream on gfx950.
             traffic = None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_final", "pmc_summary.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_final", "pmc_summary.json")))
+                if pmc.get("_meta", {}).get("kernel_source_sha16") != kernel_source_sha():
+                    raise LookupError("the committed PMC summary was taken on other kernel sources")
                 tag = "conv_gemm_kernel<2, 2, 1, 1, 0, true, %d, true>" % (0 if a.precision == "f32" else 1)
                 ent = next(v for k, v in pmc.items() if tag in k)
                 c = ent["counters"]
@@ -463,7 +476,7 @@ def main():
                 "kernel": "conv_gemm_kernel<MI=2,NI=2,KU=1,GLU,XF=0,VEC," + ("f32" if a.precision == "f32" else "f16x3")
                           + "> (128x128-tile gated gather-GEMM convolution)",
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r01_final)",
+                "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r02_final; null when that profile is of other kernel sources)",
                 "launches_per_step": len(dom), "avg_launch_ms": dom_ms / max(len(dom), 1),
                 "algorithmic_gflop_per_launch": dom_flop / max(len(dom), 1) / 1e9,
                 "share_of_program_time": dom_ms / float(ms.sum()),

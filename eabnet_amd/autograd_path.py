@@ -21,6 +21,16 @@ import torch.nn.functional as F
 def _norm(m, x, norm: str):
     """NormSwitch (EaBNet.py:662-694).  BatchNorm follows nn.BatchNorm*d: batch statistics and a
     momentum-0.1 update of the running buffers in training mode, running statistics in eval mode."""
+    if m.norm_type == "cLN":                  # CumulativeLayerNorm1d / 2d (EaBNet.py:696-769), differentiable
+        g, b = m.get_parameter(f"{norm}.norm.gain"), m.get_parameter(f"{norm}.norm.bias")
+        dims = (1,) if x.ndim == 3 else (1, 3)
+        per_frame = x.shape[1] * (x.shape[3] if x.ndim == 4 else 1)
+        cs, cq = torch.cumsum(x.sum(dims), dim=1), torch.cumsum(x.pow(2).sum(dims), dim=1)
+        cnt = per_frame * torch.arange(1, x.shape[2] + 1, dtype=x.dtype, device=x.device).view(1, -1)
+        mean = cs / cnt
+        std = ((cq - 2 * mean * cs) / cnt + mean.pow(2) + 1e-5).sqrt()
+        shape = (x.shape[0], 1, x.shape[2]) + ((1,) if x.ndim == 4 else ())
+        return (x - mean.view(shape)) / std.view(shape) * g + b
     w, b = m.get_parameter(f"{norm}.norm.weight"), m.get_parameter(f"{norm}.norm.bias")
     if m.norm_type == "BN":
         if m.training:

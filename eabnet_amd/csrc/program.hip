@@ -176,6 +176,17 @@ extern "C" int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream
             case EAB_OP_WGRAD:
                 rc = eab_wgrad_f32(&o.wgrad, stream);
                 break;
+            case EAB_OP_CLN_STATS:
+                rc = eab_cln_stats_f32(EAB_P(0), EAB_P(1), o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], (double*)const_cast<void*>(o.p[2]),
+                                       (double*)const_cast<void*>(o.p[3]), EAB_W(4), o.win, stream);
+                break;
+            case EAB_OP_CLN_APPLY:
+                rc = eab_cln_apply_f32(EAB_P(0), EAB_P(1), EAB_P(2), EAB_P(3), EAB_P(4), EAB_P(5), EAB_W(6), o.i[0], o.i[1], o.i[2],
+                                       o.i[3], o.i[4], o.win, stream);
+                break;
+            case EAB_OP_GATE_ROWS:
+                rc = eab_gate_rows_f32(EAB_P(0), EAB_P(1), EAB_W(2), o.i[0], o.i[1], o.i[2], o.win, stream);
+                break;
 #undef EAB_P
 #undef EAB_W
 #undef EAB_N64

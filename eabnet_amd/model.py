@@ -203,6 +203,19 @@ class _Bound:
                 o.i[1] = nbytes >> 32
                 o.i[2:5] = [op.B, op.T, op.row]
                 o.p[0] = A(op.ptr)
+            elif op.kind == prg.OP_CLN_STATS:
+                o.i[0:4] = [op.B, op.T, op.P, op.C]
+                o.f[0] = op.eps
+                for j, r in enumerate((op.x, op.slope, op.sums, op.state, op.mr)):
+                    o.p[j] = A(r)
+            elif op.kind == prg.OP_CLN_APPLY:
+                o.i[0:5] = [op.B, op.T, op.P, op.C, op.mode]
+                for j, r in enumerate((op.x, op.mr, op.gain, op.bias, op.slope, op.add, op.out)):
+                    o.p[j] = A(r)
+            elif op.kind == prg.OP_GATE_ROWS:
+                o.i[0:3] = [op.B, op.T, op.row]
+                for j, r in enumerate((op.a, op.r, op.z)):
+                    o.p[j] = A(r)
             elif op.kind == prg.OP_GAG_PACK:
                 o.i[0:4] = [op.B, op.T, op.F, prg.GAG_PRE_LD]
                 for j, r in enumerate((op.inpt, op.pre_x, op.enc_in, op.pre)):
@@ -333,8 +346,9 @@ class _HipModule(nn.Module):
     def stream_begin(self, B: int, T_max: int, chunk: int = 1, F: int = 161, device=None) -> EaBNetStream:
         """Frame-synchronous inference (BASELINE config 5): returns a stream object whose
         ``step`` takes ``chunk`` new frames and returns the matching output frames (see EaBNetStream.step).
-        Needs the configuration in which the network really is causal -- ``norm_type="BN"`` in eval mode
-        (running statistics) and ``is_causal=True`` -- and raises NotImplementedError otherwise."""
+        Needs a configuration in which the network really is causal -- ``norm_type="BN"`` in eval mode (running
+        statistics) or ``norm_type="cLN"`` (cumulative statistics), and ``is_causal=True`` -- and raises
+        NotImplementedError otherwise."""
         if self.training:
             raise RuntimeError("stream_begin: call .eval() first (BatchNorm must use its running statistics)")
         _lib.load()

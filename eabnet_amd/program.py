@@ -32,6 +32,7 @@ from .spec import GagConfig, NetConfig, gag_param_specs, param_specs, unet_decod
 XF_NONE, XF_NORM_PRELU, XF_PRELU_NORM = 0, 1, 2
 EPI_LINEAR, EPI_GLU, EPI_RELU, EPI_MULSIG, EPI_ADD, EPI_DUALGATE = 0, 1, 2, 3, 4, 5
 OP_CONV, OP_IN_FINALIZE, OP_NORM_ACT, OP_LSTM64, OP_BFW_FS, OP_MEMSET0, OP_GAG_PACK, OP_GAG_CRM = 1, 2, 3, 4, 5, 6, 7, 8
+OP_CLN_STATS, OP_CLN_APPLY, OP_GATE_ROWS = 33, 34, 35
 ACT_SIGMOID, ACT_TANH, ACT_RELU = 0, 1, 2
 GAG_PRE_LD = 324   # floats per (b, t) row of the interleaved previous estimate: 2*161 rounded up to a float4
 GAG_LIN_LD = 192   # 161 linear outputs padded to three 64-column tiles
@@ -251,6 +252,56 @@ class GagCrmOp:
     kind: int = OP_GAG_CRM
 
 
+@dataclass
+class ClnStatsOp:
+    """cumulative-LayerNorm statistics (eab_cln_stats_f32): mr[b][t] = (cum_mean, rstd) of x or prelu(x, slope)"""
+    x: Ref
+    slope: Optional[Ref]
+    sums: Ref
+    state: Optional[Ref]
+    mr: Ref
+    B: int
+    T: int
+    P: int
+    C: int
+    eps: float
+    win: bool = False
+    name: str = ""
+    kind: int = OP_CLN_STATS
+
+
+@dataclass
+class ClnApplyOp:
+    x: Ref
+    mr: Ref
+    gain: Ref
+    bias: Ref
+    slope: Ref
+    add: Optional[Ref]
+    out: Ref
+    B: int
+    T: int
+    P: int
+    C: int
+    mode: int
+    win: bool = False
+    name: str = ""
+    kind: int = OP_CLN_APPLY
+
+
+@dataclass
+class GateRowsOp:
+    a: Ref
+    r: Ref
+    z: Ref
+    B: int
+    T: int
+    row: int
+    win: bool = False
+    name: str = ""
+    kind: int = OP_GATE_ROWS
+
+
 def conv_tiles(T: int, No: int, bm: int) -> int:
     return (T * No + bm - 1) // bm
 
@@ -362,8 +413,8 @@ class Lowering:
         if chunk:
             # streaming = the same program restricted to a moving window of `chunk` frames (eab_time_window):
             # needs every op to be causal with data-independent statistics
-            if cfg.norm_type != "BN" or not cfg.is_causal:
-                raise NotImplementedError("streaming needs norm_type='BN' (eval) and is_causal=True: InstanceNorm "
+            if cfg.norm_type not in ("BN", "cLN") or not cfg.is_causal:
+                raise NotImplementedError("streaming needs norm_type='BN' (eval) or 'cLN' and is_causal=True: InstanceNorm "
                                           "statistics and centred S-TCM taps look at the whole utterance")
             if precision == "f16x3":
                 raise NotImplementedError("streaming runs in 'f32' or 'bf16' (BASELINE config 5); 'f16x3' is an offline mode")
@@ -387,6 +438,7 @@ class Lowering:
         self.flops = 0
         self.dump_bfw = dump_bfw
         self.bn = cfg.norm_type == "BN"
+        self.cln = cfg.norm_type == "cLN"
         self.add = cfg.intra_connect == "add"
         self.zero_init: List[Tuple[Ref, int]] = []              # arena regions that must be zero before the first replay
         # InstanceNorm finalisation inside the producing convolution (last-arriving tile): implemented and parity-green, but
@@ -442,6 +494,26 @@ class Lowering:
         if norm is None:
             return self.static_xf(f"identity{C}", np.ones(C), np.zeros(C))
         return self.bn_xf(norm) if self.bn else None
+
+    def cln_norm(self, name: str, raw: Ref, F: int, C: int, norm: str, slope_key: str, mode: int,
+                 add: Optional[Act] = None) -> Act:
+        """Cumulative LayerNorm + PReLU (reference CumulativeLayerNorm1d/2d, EaBNet.py:696-769) as a statistics op and a
+        materialising apply op; the running sums are the streaming state."""
+        B, T = self.B, self.T
+        Pn = F * C
+        sums = self.alloc(B * T * 4)                                  # [B][T][2] doubles
+        state = self.alloc(B * 4) if self.chunk else None             # [B][2] doubles
+        mr = self.alloc(B * T * 2)
+        gain = self.W.add(f"{norm}.norm.gain#c", self.P[f"{norm}.norm.gain"].reshape(C))
+        bias = self.W.add(f"{norm}.norm.bias#c", self.P[f"{norm}.norm.bias"].reshape(C))
+        slope = self.vec(slope_key)
+        win = bool(self.chunk)
+        self.ops.append(ClnStatsOp(x=raw, slope=slope if mode == XF_PRELU_NORM else None, sums=sums, state=state, mr=mr, B=B, T=T,
+                                   P=Pn, C=C, eps=EPS_IN, win=win, name=name + ".cln_stats"))
+        out = self.alloc_act(F, C)
+        self.ops.append(ClnApplyOp(x=raw, mr=mr, gain=gain, bias=bias, slope=slope, add=add.ref if add is not None else None,
+                                   out=out, B=B, T=T, P=Pn, C=C, mode=mode, win=win, name=name + ".cln"))
+        return Act(out, F, C)
 
     # -- generic conv emission -----------------------------------------------------
     def pick_bm(self, No: int) -> int:
@@ -547,7 +619,7 @@ class Lowering:
 
     # -- 2-D units -------------------------------------------------------------------
     def conv2d_fwd(self, name: str, srcs: Sequence[Act], wkey: str, glu: bool, norm: Optional[str], act: str,
-                   in_perm: Optional[np.ndarray] = None) -> Act:
+                   in_perm: Optional[np.ndarray] = None, add: Optional[Act] = None) -> Act:
         """Strided causal Conv2d [(kt,kf), stride (1,2)] (+GLU) -> raw output with
         norm+PReLU pending (norm=None: PReLU only).  Reference GateConv2d EaBNet.py:434-460 /
         Conv2dunit :391-407."""
@@ -566,12 +638,15 @@ class Lowering:
         dst = self.alloc_act(Fout, Cout)
         bm = self.pick_bm(Fout)
         tiles = conv_tiles(self.T, Fout, bm)
-        xf = self.fixed_norm(norm, Cout)
-        stats = self.alloc(self.B * tiles * Cout * 4) if xf is None else None
+        cln = self.cln and norm is not None
+        xf = None if cln else self.fixed_norm(norm, Cout)
+        stats = self.alloc(self.B * tiles * Cout * 4) if (xf is None and not cln) else None
         op = self.emit_conv(name, srcs, wref, bref, N, wp.shape[1], Fout, Fout, 1, 0, 2,
                             [a - (kt - 1) for a, _ in taps], [c for _, c in taps],
                             EPI_GLU if glu else EPI_LINEAR, dst, stats, 1 if stats else 0, (None, None),
                             tiles if stats else 0, 0, bm)
+        if cln:
+            return self.cln_norm(name, dst, Fout, Cout, norm, f"{act}.weight", XF_NORM_PRELU, add)
         if xf is None:
             if self.fuse_fin:
                 xf, = self.fuse_finalize([op], Cout, [norm])
@@ -580,7 +655,7 @@ class Lowering:
         return Act(dst, Fout, Cout, xf, self.vec(f"{act}.weight"), XF_NORM_PRELU)
 
     def conv2d_transposed(self, name: str, srcs: Sequence[Act], wkey: str, glu: bool, norm: str, act: str,
-                          summed: bool = False) -> Act:
+                          summed: bool = False, add: Optional[Act] = None) -> Act:
         """ConvTranspose2d [(kt,kf), stride (1,2)] + drop of the last kt-1 rows
         (+GLU) as two gather-form launches, one per output-column parity:
           out[t][2o+ph] = sum_{kt} sum_{kf = ph, ph+2, ..} W[kt][kf] . in[t-kt][o-(kf-ph)/2]
@@ -603,8 +678,9 @@ class Lowering:
         No = [(Fout + 1) // 2, Fout // 2]
         bm = self.pick_bm(No[0])
         tiles = [conv_tiles(self.T, n, bm) for n in No]
-        xf = self.fixed_norm(norm, Cout)
-        stats = self.alloc(self.B * sum(tiles) * Cout * 4) if xf is None else None
+        cln = self.cln
+        xf = None if cln else self.fixed_norm(norm, Cout)
+        stats = self.alloc(self.B * sum(tiles) * Cout * 4) if (xf is None and not cln) else None
         phase_ops = []
         for ph in (0, 1):
             taps = [(a, c) for a in range(kt) for c in range(ph, kf, 2)]
@@ -614,6 +690,8 @@ class Lowering:
                                             [-a for a, _ in taps], [-(c - ph) // 2 for _, c in taps],
                                             EPI_GLU if glu else EPI_LINEAR, dst, stats, 1 if stats else 0, (None, None),
                                             sum(tiles) if stats else 0, (0 if ph == 0 else tiles[0]) if stats else 0, bm))
+        if cln:
+            return self.cln_norm(name, dst, Fout, Cout, norm, f"{act}.weight", XF_NORM_PRELU, add)
         if xf is None:
             if self.fuse_fin:
                 xf, = self.fuse_finalize(phase_ops, Cout, [norm])
@@ -651,7 +729,11 @@ class Lowering:
         for j in range(scale):
             q = f"{pre}.deco.{j}.deconv"
             ins = [y] if j == 0 else [y, downs[-(j + 1)]]
-            y = self.conv2d_transposed(q, ins, f"{q}.0", False, f"{q}.1", f"{q}.2", summed=self.add and j > 0)
+            y = self.conv2d_transposed(q, ins, f"{q}.0", False, f"{q}.1", f"{q}.2", summed=self.add and j > 0,
+                                       add=g if (self.cln and j == scale - 1) else None)
+        if self.cln:                    # every activation is already materialised; the residual rode on the last apply
+            self.taps[pre] = y
+            return y
         return self.materialise(pre, g, y)
 
     # -- squeezed TCM --------------------------------------------------------------------
@@ -660,6 +742,8 @@ class Lowering:
         launches: in_conv (+ statistics of both branch PReLUs) -> left*sigmoid(right) in ONE
         dual-transform gated conv -> out_conv + residual.  T/64 tiles per utterance are few, so
         each consumer reduces the InstanceNorm partials itself (no finalize launches)."""
+        if self.cln:
+            return self.tcm_cln(pre, x, dilation, x_acc, perm)
         cfg, T, B = self.cfg, self.T, self.B
         D, cd, kd = cfg.d_feat, cfg.cd1, cfg.kd1
         bm = 64
@@ -698,6 +782,34 @@ class Lowering:
                        fin=None if bn else dict(stats=st2, tiles=tiles, nsets=1, count=T, norms=[nO]))
         return Act(xn, 1, D)
 
+    def tcm_cln(self, pre: str, x: Act, dilation: int, x_acc: Optional[Ref], perm: np.ndarray) -> Act:
+        """SqueezedTCM.forward (EaBNet.py:572-578) with cumulative LayerNorms: every normalised tensor is materialised
+        (the norm's statistics depend on the frame), the two branches are two convolutions and a gate op."""
+        cfg, T, B = self.cfg, self.T, self.B
+        D, cd, kd = cfg.d_feat, cfg.cd1, cfg.kd1
+        bm = 64
+        w_in = self.P[f"{pre}.in_conv.weight"][:, perm, :]
+        y = self.alloc_act(1, cd)
+        self.emit_conv(f"{pre}.in_conv", [x], self.W.add(f"{pre}.in_conv.weight#packed", pack_taps(w_in, [0])), None, cd, D, 1, 1,
+                       1, 0, 1, [0], [0], EPI_LINEAR, y, bm=bm)
+        yL = self.cln_norm(f"{pre}.left", y, 1, cd, f"{pre}.left_conv.1", f"{pre}.left_conv.0.weight", XF_PRELU_NORM)
+        yR = self.cln_norm(f"{pre}.right", y, 1, cd, f"{pre}.right_conv.1", f"{pre}.right_conv.0.weight", XF_PRELU_NORM)
+        span = (kd - 1) * dilation
+        dts = [j * dilation - span for j in range(kd)]              # causal (cLN is only built for is_causal=True)
+        Kp = kd * ((cd + 15) // 16) * 16
+        a, r = self.alloc_act(1, cd), self.alloc_act(1, cd)
+        for side, src, dst in (("left_conv", yL, a), ("right_conv", yR, r)):
+            wref = self.W.add(f"{pre}.{side}.3.weight#packed", pack_taps(self.P[f"{pre}.{side}.3.weight"], range(kd)))
+            self.emit_conv(f"{pre}.{side}", [src], wref, None, cd, Kp, 1, 1, 1, 0, 1, dts, [0] * kd, EPI_LINEAR, dst, bm=bm)
+        z = self.alloc_act(1, cd)
+        self.ops.append(GateRowsOp(a=a, r=r, z=z, B=B, T=T, row=cd, win=bool(self.chunk), name=f"{pre}.gate"))
+        zo = self.cln_norm(f"{pre}.out", z, 1, cd, f"{pre}.out_conv.1", f"{pre}.out_conv.0.weight", XF_PRELU_NORM)
+        w_out = self.P[f"{pre}.out_conv.2.weight"][perm]
+        xn = self.alloc_act(1, D)
+        self.emit_conv(f"{pre}.out_conv", [zo], self.W.add(f"{pre}.out_conv.2.weight#packed", pack_taps(w_out, [0])), None, D, cd, 1,
+                       1, 1, 0, 1, [0], [0], EPI_ADD, xn, bm=bm, aux=x.ref, dst_acc=x_acc)
+        return Act(xn, 1, D)
+
     # -- whole network ----------------------------------------------------------------------
     def build(self) -> Program:
         cfg, B, T, F = self.cfg, self.B, self.T, self.F
@@ -724,7 +836,11 @@ class Lowering:
                 if i < 4:
                     skips.append(g)
                     x = g
-        x = self.materialise("en.last_conv", g)       # the S-TCMs need the bottleneck itself in memory
+        if self.cln:
+            x = g
+            self.taps["en.last_conv"] = x
+        else:
+            x = self.materialise("en.last_conv", g)   # the S-TCMs need the bottleneck itself in memory
         skips.append(x)
         assert x.F * x.C == cfg.d_feat, "bottleneck width must equal d_feat"
 
@@ -753,7 +869,11 @@ class Lowering:
             for i in range(5):                        # UNet_Decoder (EaBNet.py:324-328)
                 q = f"de.unet_list.{i}"
                 x = g = self.conv2d_transposed(q, [x, skips[-(i + 1)]], f"{q}.0.conv.0", True, f"{q}.1", f"{q}.2")
-        e = self.materialise("de.last_conv", g)
+        if self.cln:
+            e = g
+            self.taps["de.last_conv"] = e
+        else:
+            e = self.materialise("de.last_conv", g)
         assert e.F == F and e.C == cfg.embed_dim == 64
 
         if not (cfg.topo_type == "mimo" and cfg.bf_type == "lstm"):

@@ -68,8 +68,10 @@ class NetConfig:
             bad.append(f"topo_type={self.topo_type!r}")
         if self.intra_connect not in ("cat", "add"):
             bad.append(f"intra_connect={self.intra_connect!r}")
-        if self.norm_type not in ("IN", "BN"):
+        if self.norm_type not in ("IN", "BN", "cLN"):
             bad.append(f"norm_type={self.norm_type!r}")
+        if self.norm_type == "cLN" and not (self.is_u2 and self.intra_connect == "cat" and self.is_causal):
+            bad.append("norm_type='cLN' is built for the default topology (U2, 'cat' skips, causal)")
         if not self.is_causal and (self.kd1 - 1) % 2:
             bad.append("is_causal=False with even kd1 (the reference's residual add fails on the shorter branch)")
         if tuple(self.k1) != (2, 3) or tuple(self.k2) != (1, 3):
@@ -98,8 +100,15 @@ class ParamSpec:
         return self.kind in ("bn_mean", "bn_var", "bn_count")
 
 
-def _norm(tab, prefix_norm: str, c: int, bn: bool) -> None:
-    """NormSwitch (EaBNet.py:662-694): affine InstanceNorm, or BatchNorm with its buffers."""
+def _norm(tab, prefix_norm: str, c: int, bn, dim: int = 2) -> None:
+    """NormSwitch (EaBNet.py:662-694): affine InstanceNorm, BatchNorm with its buffers (bn=True), or -- bn == "cLN" -- the
+    cumulative LayerNorm of EaBNet.py:696-769 with its (1,C,1[,1]) gain / bias (the reference's constructor passes the
+    string dim_size as num_features, :689,691, and cannot be built; this is the class with ``c`` passed instead)."""
+    if bn == "cLN":
+        shape = (1, c, 1, 1) if dim == 2 else (1, c, 1)
+        tab[f"{prefix_norm}.norm.gain"] = ParamSpec(shape, "norm_w", c)
+        tab[f"{prefix_norm}.norm.bias"] = ParamSpec(shape, "norm_b", c)
+        return
     tab[f"{prefix_norm}.norm.weight"] = ParamSpec((c,), "norm_w", c)
     tab[f"{prefix_norm}.norm.bias"] = ParamSpec((c,), "norm_b", c)
     if bn:
@@ -151,7 +160,7 @@ def param_specs(cfg: NetConfig) -> "OrderedDict[str, ParamSpec]":
     cfg.check_supported()
     tab: "OrderedDict[str, ParamSpec]" = OrderedDict()
     c, M = cfg.c, cfg.M
-    bn, add = cfg.norm_type == "BN", cfg.intra_connect == "add"
+    bn, add = {"BN": True, "IN": False, "cLN": "cLN"}[cfg.norm_type], cfg.intra_connect == "add"
 
     if cfg.is_u2:
         # encoder: scales 4,3,2,1 then a gated conv down to F=4
@@ -209,10 +218,10 @@ def param_specs(cfg: NetConfig) -> "OrderedDict[str, ParamSpec]":
             tab[f"{p}.in_conv.weight"] = ParamSpec((cd, D, 1), "conv_w", D)
             for side in ("left_conv", "right_conv"):
                 tab[f"{p}.{side}.0.weight"] = ParamSpec((cd,), "prelu", cd)
-                _norm(tab, f"{p}.{side}.1", cd, bn)
+                _norm(tab, f"{p}.{side}.1", cd, bn, dim=1)
                 tab[f"{p}.{side}.3.weight"] = ParamSpec((cd, cd, kd), "conv_w", cd * kd)
             tab[f"{p}.out_conv.0.weight"] = ParamSpec((cd,), "prelu", cd)
-            _norm(tab, f"{p}.out_conv.1", cd, bn)
+            _norm(tab, f"{p}.out_conv.1", cd, bn, dim=1)
             tab[f"{p}.out_conv.2.weight"] = ParamSpec((D, cd, 1), "conv_w", cd)
     return tab
 
@@ -271,8 +280,10 @@ class GagConfig:
             bad.append(f"acti_type={self.acti_type!r}")
         if self.intra_connect not in ("cat", "add"):
             bad.append(f"intra_connect={self.intra_connect!r}")
-        if self.norm_type not in ("IN", "BN"):
+        if self.norm_type not in ("IN", "BN", "cLN"):
             bad.append(f"norm_type={self.norm_type!r}")
+        if self.norm_type == "cLN" and not (self.is_u2 and self.intra_connect == "cat" and self.is_causal):
+            bad.append("norm_type='cLN' is built for the default topology (U2, 'cat' skips, causal)")
         if tuple(self.k1) != (2, 3) or tuple(self.k2) != (1, 3) or self.c != 64 or self.cd1 != 64:
             bad.append("k1/k2/c/cd1 away from (2,3)/(1,3)/64/64")
         if self.d_feat != self.c_end * 4 or self.fft_num != 320:

@@ -505,6 +505,32 @@ int eab_wgrad_f32(const eab_wgrad_desc* d, eab_stream_t stream);
 #define EAB_OP_LSTM_BWD    31
 #define EAB_OP_WGRAD       32
 
+/* --------------------------------------------------------------------------
+ * Cumulative LayerNorm: CumulativeLayerNorm1d / 2d, EaBNet.py:696-769, the causal norm
+ * NormSwitch(norm_type="cLN") is meant to build (its constructor passes the string dim_size as num_features,
+ * EaBNet.py:689,691; this is the class with the channel count passed).  x [B][T][P] with P = F*C values per frame,
+ * channel = index % C.
+ *   eab_cln_stats_f32: mr[b][t] = (cum_mean, 1/sqrt(cum_var + eps)) over all channels, bins and frames <= t, of x or --
+ *     slope != NULL -- of prelu(x, slope[c]) (S-TCM order).  sums: scratch [B][T][2] doubles; state: [B][2] doubles,
+ *     the running sums carried between streaming chunks (required with a window, optional otherwise).
+ *   eab_cln_apply_f32: y = prelu(gain_c (x-mean) rstd + bias_c, slope_c) [+ add]   (mode EAB_XF_NORM_PRELU)
+ *                      y = gain_c (prelu(x, slope_c) - mean) rstd + bias_c         (mode EAB_XF_PRELU_NORM)
+ *   eab_gate_rows_f32: z = a * sigmoid(r) (S-TCM gate, EaBNet.py:575) on [B][T][row_floats]
+ * ------------------------------------------------------------------------ */
+int eab_cln_stats_f32(const float* x, const float* slope, int B, int T, int P, int C, float eps, double* sums, double* state,
+                      float* mr, eab_time_window win, eab_stream_t stream);
+int eab_cln_apply_f32(const float* x, const float* mr, const float* gain, const float* bias, const float* slope,
+                      const float* add, float* y, int B, int T, int P, int C, int mode, eab_time_window win,
+                      eab_stream_t stream);
+int eab_gate_rows_f32(const float* a, const float* r, float* z, int B, int T, int row_floats, eab_time_window win,
+                      eab_stream_t stream);
+/* program ops:  CLN_STATS  p = {x, slope, sums, state, mr}              i = {B, T, P, C}        f = {eps}
+ *               CLN_APPLY  p = {x, mr, gain, bias, slope, add, y}       i = {B, T, P, C, mode}
+ *               GATE_ROWS  p = {a, r, z}                                i = {B, T, row_floats}       (all three windowed) */
+#define EAB_OP_CLN_STATS 33
+#define EAB_OP_CLN_APPLY 34
+#define EAB_OP_GATE_ROWS 35
+
 /* struct-layout handshake for foreign-function mirrors of the structs above */
 int eab_sizeof_conv_desc(void);
 int eab_sizeof_op(void);

@@ -113,9 +113,27 @@ def istft_oracle(esti: torch.Tensor, n_fft: int = 320, hop: int = 160) -> torch.
 # ----------------------------------------------------------------------------
 # network blocks
 # ----------------------------------------------------------------------------
-def _norm(x, P: Params, norm_prefix: str, bn: bool = False):
-    """NormSwitch (EaBNet.py:662-694): affine InstanceNorm, or BatchNorm in eval mode
-    (running statistics; nn.BatchNorm default eps 1e-5)."""
+def cumulative_layer_norm(x, gain, bias, eps: float = EPS_IN):
+    """CumulativeLayerNorm1d / 2d.forward (EaBNet.py:713-733, 752-769): statistics over all channels, all frequency bins
+    and all frames up to the current one.  x (B,C,T) or (B,C,T,F); gain / bias (1,C,1[,1])."""
+    dims = (1,) if x.ndim == 3 else (1, 3)
+    per_frame = x.shape[1] * (x.shape[3] if x.ndim == 4 else 1)
+    cum_sum = torch.cumsum(x.sum(dims), dim=1)                                 # (B,T)
+    cum_pow = torch.cumsum(x.pow(2).sum(dims), dim=1)
+    cnt = per_frame * torch.arange(1, x.shape[2] + 1, dtype=x.dtype, device=x.device).view(1, -1)
+    mean = cum_sum / cnt
+    var = (cum_pow - 2 * mean * cum_sum) / cnt + mean.pow(2)
+    std = (var + eps).sqrt()
+    shape = (x.shape[0], 1, x.shape[2]) + ((1,) if x.ndim == 4 else ())
+    return (x - mean.view(shape)) / std.view(shape) * gain + bias
+
+
+def _norm(x, P: Params, norm_prefix: str, bn=False):
+    """NormSwitch (EaBNet.py:662-694): affine InstanceNorm, BatchNorm in eval mode (running statistics; nn.BatchNorm
+    default eps 1e-5), or -- bn == "cLN" -- the cumulative LayerNorm the switch means to build (with ``c`` passed where the
+    reference passes the string dim_size, EaBNet.py:689,691)."""
+    if isinstance(bn, str) and bn == "cLN":
+        return cumulative_layer_norm(x, P[f"{norm_prefix}.norm.gain"], P[f"{norm_prefix}.norm.bias"])
     w, b = P[f"{norm_prefix}.norm.weight"], P[f"{norm_prefix}.norm.bias"]
     if bn:
         return F.batch_norm(x, P[f"{norm_prefix}.norm.running_mean"], P[f"{norm_prefix}.norm.running_var"], w, b,
@@ -265,8 +283,8 @@ def eabnet_forward(P: Params, inpt: torch.Tensor, p: int = 6, q: int = 3, kd: in
     if inpt.ndim == 4:
         inpt = inpt.unsqueeze(-2)
     B, T, Fq, M, _ = inpt.shape
-    bn, add = norm_type == "BN", intra_connect == "add"
-    assert norm_type in ("IN", "BN") and intra_connect in ("cat", "add")
+    assert norm_type in ("IN", "BN", "cLN") and intra_connect in ("cat", "add")
+    bn, add = {"BN": True, "IN": False, "cLN": "cLN"}[norm_type], intra_connect == "add"
     # (B,T,F,M,2) -> (B,2M,T,F), channel = ri*M + m   (EaBNet.py:96-97)
     x = inpt.transpose(-2, -1).contiguous().view(B, T, Fq, 2 * M).permute(0, 3, 1, 2)
 

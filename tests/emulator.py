@@ -224,6 +224,47 @@ class Emulator:
             out = self.v(xf, (op.B, op.C, 2))
             out[..., 0], out[..., 1] = scale, shift
 
+    def cln_stats(self, op):
+        x = self.v(op.x, (op.B, op.T, op.P)).astype(np.float64)
+        if op.slope is not None:
+            a = np.tile(self.v(op.slope, (op.C,)).astype(np.float64), op.P // op.C)
+            x = np.where(x > 0, x, a * x)
+        lo, hi = getattr(self, "_win", (0, op.T))
+        sums = self.v(op.sums, (op.B, op.T, 4)).view(np.float64).reshape(op.B, op.T, 2)
+        sums[:, lo:hi, 0], sums[:, lo:hi, 1] = x[:, lo:hi].sum(-1), (x[:, lo:hi] ** 2).sum(-1)
+        st = self.v(op.state, (op.B, 4)).view(np.float64).reshape(op.B, 2) if op.state is not None else None
+        cs = st[:, 0].copy() if (st is not None and lo > 0) else np.zeros(op.B)
+        cq = st[:, 1].copy() if (st is not None and lo > 0) else np.zeros(op.B)
+        mr = self.v(op.mr, (op.B, op.T, 2))
+        for t in range(lo, hi):
+            cs += sums[:, t, 0]
+            cq += sums[:, t, 1]
+            cnt = op.P * (t + 1.0)
+            mean = cs / cnt
+            var = (cq - 2.0 * mean * cs) / cnt + mean * mean
+            mr[:, t, 0], mr[:, t, 1] = mean, 1.0 / np.sqrt(var + op.eps)
+        if st is not None:
+            st[:, 0], st[:, 1] = cs, cq
+
+    def cln_apply(self, op):
+        lo, hi = getattr(self, "_win", (0, op.T))
+        x = self.v(op.x, (op.B, op.T, op.P // op.C, op.C))[:, lo:hi]
+        mr = self.v(op.mr, (op.B, op.T, 2))[:, lo:hi]
+        g, b, a = (self.v(r, (op.C,)) for r in (op.gain, op.bias, op.slope))
+        mean, rstd = mr[..., 0][:, :, None, None], mr[..., 1][:, :, None, None]
+        if op.mode == prg.XF_NORM_PRELU:
+            y = _prelu((x - mean) * rstd * g + b, a)
+        else:
+            y = (_prelu(x, a) - mean) * rstd * g + b
+        if op.add is not None:
+            y = y + self.v(op.add, (op.B, op.T, op.P // op.C, op.C))[:, lo:hi]
+        self.v(op.out, (op.B, op.T, op.P // op.C, op.C))[:, lo:hi] = y.astype(np.float32)
+
+    def gate_rows(self, op):
+        lo, hi = getattr(self, "_win", (0, op.T))
+        a, r = (self.v(q, (op.B, op.T, op.row))[:, lo:hi] for q in (op.a, op.r))
+        self.v(op.z, (op.B, op.T, op.row))[:, lo:hi] = (a * _sig(r)).astype(np.float32)
+
     def norm_act(self, op: prg.NormActOp):
         def f(ref, xf, sl):
             tab = self.v(xf, (op.B, op.C, 2))
@@ -310,6 +351,7 @@ class Emulator:
             {prg.OP_CONV: self.conv, prg.OP_IN_FINALIZE: self.finalize, prg.OP_NORM_ACT: self.norm_act,
              prg.OP_LSTM64: self.lstm, prg.OP_BFW_FS: self.bfw, prg.OP_GAG_PACK: self.gag_pack,
              prg.OP_GAG_CRM: self.gag_crm,
+             prg.OP_CLN_STATS: self.cln_stats, prg.OP_CLN_APPLY: self.cln_apply, prg.OP_GATE_ROWS: self.gate_rows,
              prg.OP_MEMSET0: lambda o: self.v(o.ptr, (o.nfloats,)).fill(0)}[op.kind](op)
 
     def _outputs(self, op):
@@ -327,6 +369,8 @@ class Emulator:
             return o + ([(op.bfw, (op.B, op.T, op.F * op.M * 2), 1)] if op.bfw is not None else [])
         if op.kind == prg.OP_MEMSET0:
             return [(op.ptr, (op.B, op.T, op.row), 1)]
+        if op.kind in (prg.OP_CLN_STATS, prg.OP_CLN_APPLY, prg.OP_GATE_ROWS):
+            return []                               # these emulate their window (and carried state) themselves: self._win
         if op.kind == prg.OP_GAG_PACK:
             return [(op.enc_in, (op.B, op.T, op.F * 4), 1), (op.pre, (op.B, op.T, prg.GAG_PRE_LD), 1)]
         if op.kind == prg.OP_GAG_CRM:
@@ -343,6 +387,7 @@ class Emulator:
         assert p.chunk > 0 and all(getattr(op, "win", False) for op in p.ops)
         for pos in range(0, p.T, p.chunk):
             hi = min(pos + p.chunk, p.T)
+            self._win = (pos, hi)
             for op in p.ops:
                 outs = self._outputs(op)
                 saved = [self.v(r, shp).copy() for r, shp, _ in outs]

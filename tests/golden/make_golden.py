@@ -44,10 +44,30 @@ VARIANTS = {          # constructor branches away from the default (SURVEY §8c 
     "noncausal": dict(is_causal=False),
     "unet_bn_cnn_noncausal": dict(is_u2=False, norm_type="BN", bf_type="cnn", is_causal=False),
     "add_bn_miso": dict(intra_connect="add", norm_type="BN", topo_type="miso"),
+    "cln": dict(norm_type="cLN"),       # needs the reference's NormSwitch constructor fixed: see _fixed_norm_switch()
 }
 
 
+def _fixed_norm_switch():
+    """The reference cannot construct norm_type="cLN": NormSwitch passes the STRING dim_size to
+    CumulativeLayerNorm{1,2}d as num_features (EaBNet.py:689,691).  For the cLN fixtures the two calls are given the
+    channel count ``c`` instead -- nothing else of the reference changes (its own CumulativeLayerNorm classes run)."""
+    import EaBNet as R
+
+    class FixedNormSwitch(R.NormSwitch):
+        def __init__(self, norm_type, dim_size, c):
+            if norm_type != "cLN":
+                super().__init__(norm_type, dim_size, c)
+                return
+            torch.nn.Module.__init__(self)
+            self.norm_type, self.dim_size, self.c = norm_type, dim_size, c
+            self.norm = (R.CumulativeLayerNorm1d if dim_size == "1D" else R.CumulativeLayerNorm2d)(c, affine=True)
+    R.NormSwitch = FixedNormSwitch
+
+
 def ref_model(M: int, seed: int, **kw):
+    if kw.get("norm_type") == "cLN":
+        _fixed_norm_switch()
     specs = param_specs(NetConfig(M=M, **kw))
     net = RefEaBNet(M=M, **kw).eval()
     sd = net.state_dict()
@@ -165,17 +185,20 @@ def main():
          target_l2=np.float64(torch.linalg.vector_norm(ts.double()).item()))
 
 
-def main_variants():
+def main_variants(only=None):
     """One small end-to-end fixture per non-default constructor branch (eval mode)."""
-    inventory = {}
+    path = os.path.join(HERE, "keys_variants.json")
+    inventory = json.load(open(path)) if (only and os.path.exists(path)) else {}
     for i, (name, kw) in enumerate(VARIANTS.items()):
+        if only and name != only:
+            continue
         M = 4
         net, specs = ref_model(M, seed=200 + i, **kw)
         inventory[name] = dict(kwargs=kw, M=M, keys=[[k, list(v.shape)] for k, v in net.state_dict().items()])
         x = torch.from_numpy(paramgen.make_spec_input(2, 20, 161, M, seed=300 + i))
         y = net(x)
         save(f"var_{name}.npz", out=y.numpy(), param_seed=200 + i, input_seed=300 + i, M=M)
-    with open(os.path.join(HERE, "keys_variants.json"), "w") as f:
+    with open(path, "w") as f:
         json.dump(inventory, f)
 
 
@@ -289,6 +312,23 @@ def main_blocks():
         json.dump(recipes, f)
 
 
+def main_cln():
+    """The reference's own CumulativeLayerNorm1d / 2d on random inputs with random gain / bias (pins the restatement of
+    the norm itself), and the cLN variant of the network (constructor fix above)."""
+    import EaBNet as R
+    rng = np.random.default_rng(91)
+    out = {}
+    for name, cls, shape in (("1d", R.CumulativeLayerNorm1d, (2, 64, 37)), ("2d", R.CumulativeLayerNorm2d, (2, 64, 11, 19))):
+        m = cls(shape[1], affine=True)
+        gshape = tuple(m.gain.shape)
+        g, b = (1.0 + 0.3 * rng.standard_normal(gshape)).astype(np.float32), (0.2 * rng.standard_normal(gshape)).astype(np.float32)
+        m.gain.data, m.bias.data = torch.from_numpy(g), torch.from_numpy(b)
+        x = (0.7 * rng.standard_normal(shape) + 0.2).astype(np.float32)
+        out[f"{name}/x"], out[f"{name}/gain"], out[f"{name}/bias"] = x, g, b
+        out[f"{name}/y"] = m(torch.from_numpy(x)).numpy()
+    save("cln_classes.npz", **out)
+
+
 def main_losses():
     """eabnet_with_postnet_loss (EaBNet.py:642-650, called at train_distributed.py:225) on the two-stage
     fixture's reference outputs."""
@@ -309,6 +349,9 @@ if __name__ == "__main__":
     with torch.no_grad():
         if sys.argv[1:] == ["losses"]:
             main_losses()
+        elif sys.argv[1:] == ["cln"]:
+            main_cln()
+            main_variants(only="cln")
         elif sys.argv[1:] == ["blocks"]:
             main_blocks()
         elif sys.argv[1:] == ["gagnet"]:

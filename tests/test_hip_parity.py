@@ -1301,3 +1301,60 @@ def test_config4_ddp_training_on_the_hip_programs(dev):
         assert l2 < 0.1
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------ cumulative LayerNorm (second half)
+def test_cln_every_op_matches_the_emulator_and_streams(dev):
+    """norm_type="cLN" (the reference's CumulativeLayerNorm classes behind the fixed NormSwitch constructor): every op of
+    the device program against the numpy interpreter, the output against the reference fixture (var_cln.npz), and the
+    property the norm exists for: streaming (running sums as the only norm state) equals the offline call bit for bit --
+    also at BASELINE configs[4] size (16 microphones, 8 s) in fp32 and bf16."""
+    from eabnet_amd import program as prg
+    from eabnet_amd.model import _Bound
+    from eabnet_amd.spec import NetConfig, param_specs
+    from emulator import Emulator
+    g = load("var_cln.npz")
+    cfg = NetConfig(M=4, norm_type="cLN")
+    P = paramgen.make_params(param_specs(cfg), int(g["param_seed"]))
+    x = paramgen.make_spec_input(2, 20, 161, 4, int(g["input_seed"]))
+    prog = prg.lower(cfg, P, 2, 20, 161)
+    emu = Emulator(prog, x)
+    bound = _Bound(prog, dev)
+    bound.acts.fill_(float("nan"))
+    xin = torch.from_numpy(x).to(dev)
+    out = torch.full((2, 2, 20, 161), float("nan"), device=dev)
+    bound.bind(xin.data_ptr(), out.data_ptr())
+    stream = torch.cuda.current_stream().cuda_stream
+    for k, op in enumerate(prog.ops):
+        bound.run(stream, k, 1)
+        torch.cuda.synchronize()
+        emu.step(op)
+        got, want = bound.acts.cpu().numpy(), emu.arena["a"]
+        if op.kind == prg.OP_CLN_STATS:        # fp64 scratch: compare as doubles where the emulator wrote them
+            gd, wd = got[op.sums.off:op.sums.off + 2 * 20 * 4].view(np.float64), want[op.sums.off:op.sums.off + 2 * 20 * 4].view(np.float64)
+            assert np.allclose(gd, wd, rtol=1e-5), f"op {k} {op.name}: frame sums"
+            want[op.sums.off:op.sums.off + 2 * 20 * 4] = got[op.sums.off:op.sums.off + 2 * 20 * 4]
+        assert np.array_equal(np.isnan(got), np.isnan(want)), f"op {k} {op.name}: wrote a different set of elements"
+        m = ~np.isnan(want)
+        err = np.abs(got[m] - want[m]).max() / max(np.abs(want[m]).max(), 1e-20)
+        assert err < 2e-4, f"op {k} {op.name} (kind {op.kind}): workspace deviates by {err:.3e}"
+        emu.arena["a"][:] = got
+    assert_close(out.cpu().numpy(), g["out"], TOL_HIP, "cLN vs reference fixture")
+    # streaming == offline, small and at config-5 size
+    for M, T, chunks, precs in ((4, 20, (1, 3), ("f32",)), (16, 801, (1, 16), ("f32", "bf16"))):
+        net = _model(M, int(g["param_seed"]) if M == 4 else 1240, dev, norm_type="cLN")
+        xs = torch.from_numpy(paramgen.make_spec_input(1, T, 161, M, 1241)).to(dev)
+        for prec in precs:
+            net.precision = prec
+            with torch.no_grad():
+                off = net(xs)
+            assert torch.isfinite(off).all()
+            for chunk in chunks:
+                st = net.stream_begin(1, T_max=T, chunk=chunk)
+                ys = torch.cat([st.step(xs[:, t:t + chunk]) for t in range(0, T, chunk)], dim=2)
+                assert torch.equal(ys, off), f"cLN streaming M={M} T={T} chunk={chunk} {prec}"
+    # causality: frames before t0 do not depend on the input from t0 on
+    x2 = xs.clone()
+    x2[:, 500:] = 0.0
+    with torch.no_grad():
+        assert torch.equal(net(x2)[:, :, :500], off[:, :, :500])

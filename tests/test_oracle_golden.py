@@ -293,3 +293,18 @@ def test_oracle_blocks_match_the_reference_classes():
             assert_close(orc.squeezed_tcm(x, {f"t.{k}": v for k, v in P.items()}, "t", d, 5).numpy(), y, TOL_ORACLE, name)
         x, y, P = _block("lstm_bf")
         assert_close(orc.lstm_bf(x, {f"bf_map.{k}": v for k, v in P.items()}, 8).numpy(), y, TOL_ORACLE, "lstm_bf")
+
+
+def test_cumulative_layer_norm_matches_the_reference_classes():
+    """oracle.cumulative_layer_norm against the outputs of the reference's own CumulativeLayerNorm1d / 2d
+    (EaBNet.py:696-769) -- the norm NormSwitch(norm_type="cLN") means to build (fixture: cln_classes.npz)."""
+    g = load("cln_classes.npz")
+    for name in ("1d", "2d"):
+        y = orc.cumulative_layer_norm(torch.from_numpy(g[f"{name}/x"]), torch.from_numpy(g[f"{name}/gain"]), torch.from_numpy(g[f"{name}/bias"]))
+        assert_close(y.numpy(), g[f"{name}/y"], TOL_ORACLE, name)
+    # causal: changing later frames never changes earlier outputs
+    x = torch.from_numpy(g["2d/x"]).clone()
+    y0 = orc.cumulative_layer_norm(x, torch.from_numpy(g["2d/gain"]), torch.from_numpy(g["2d/bias"]))
+    x[:, :, 7:] += 1.0
+    y1 = orc.cumulative_layer_norm(x, torch.from_numpy(g["2d/gain"]), torch.from_numpy(g["2d/bias"]))
+    assert torch.equal(y0[:, :, :7], y1[:, :, :7]) and not torch.equal(y0[:, :, 7:], y1[:, :, 7:])

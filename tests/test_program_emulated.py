@@ -78,10 +78,11 @@ def test_flop_count_close_to_survey_formula():
 
 
 def test_unsupported_topologies_raise():
-    """cLN cannot be constructed in the reference either (EaBNet.py:689-691); the layer geometry
-    (64 channels, (2,3)/(1,3) kernels) is fixed by the kernels."""
-    for kw in (dict(norm_type="cLN"), dict(bf_type="gru"), dict(topo_type="siso"), dict(intra_connect="mul"),
-               dict(c=32), dict(k1=(2, 5)), dict(is_causal=False, kd1=4)):
+    """The layer geometry (64 channels, (2,3)/(1,3) kernels) is fixed by the kernels; cLN (fixed constructor, round 2) is
+    built for the default topology only."""
+    for kw in (dict(norm_type="LN"), dict(bf_type="gru"), dict(topo_type="siso"), dict(intra_connect="mul"),
+               dict(c=32), dict(k1=(2, 5)), dict(is_causal=False, kd1=4), dict(norm_type="cLN", is_u2=False),
+               dict(norm_type="cLN", is_causal=False), dict(norm_type="cLN", intra_connect="add")):
         with pytest.raises(NotImplementedError):
             param_specs(NetConfig(M=8, **kw))
 
@@ -225,3 +226,17 @@ def test_bf16_lowering_stays_within_its_stated_bound():
     prg.lower(NetConfig(M=2, norm_type="BN", p=1, q=1), _params(2, 3, norm_type="BN", p=1, q=1), 1, 8, 161, precision="bf16", chunk=2)
     with pytest.raises(NotImplementedError):
         prg.lower(NetConfig(M=2, norm_type="BN", p=1, q=1), _params(2, 3, norm_type="BN", p=1, q=1), 1, 8, 161, precision="f16x3", chunk=2)
+
+
+@pytest.mark.parametrize("chunk", [1, 4])
+def test_emulated_cln_streaming_equals_offline(chunk):
+    """norm_type="cLN": the cumulative statistics are the only norm state, so the streaming program (windowed ops +
+    carried running sums) reproduces the offline program exactly, which matches the reference fixture (var_cln)."""
+    g = load("var_cln.npz")
+    cfg = NetConfig(M=4, norm_type="cLN")
+    P = _params(4, int(g["param_seed"]), norm_type="cLN")
+    x = paramgen.make_spec_input(2, 20, 161, 4, int(g["input_seed"]))
+    off = Emulator(prg.lower(cfg, P, 2, 20, 161), x).run()
+    assert_close(off, g["out"], TOL_EMU, "offline cLN vs reference")
+    st = Emulator(prg.lower(cfg, P, 2, 20, 161, chunk=chunk), x).run_stream()
+    assert np.array_equal(st, off)

@@ -42,5 +42,9 @@ for d in sorted(glob.glob(os.path.join(src, "pmc*"))):
                 out[k].setdefault("duration_us", {})[os.path.basename(d)] = v
 for k in out:
     out[k]["counters"] = dict(out[k]["counters"])
+# fingerprint of the kernel sources the profile was taken on: bench.py reports `traffic` only when it matches the tree
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bench import kernel_source_sha  # noqa: E402
+out["_meta"] = {"kernel_source_sha16": kernel_source_sha()}
 json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
 print(f"{dst}: {len(out)} kernels summarised")
