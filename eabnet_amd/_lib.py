@@ -51,7 +51,7 @@ class ConvDesc(C.Structure):
 
 class WgradDesc(C.Structure):
     _fields_ = [
-        ("dz", C.c_void_p), ("src0", C.c_void_p), ("src1", C.c_void_p), ("dw", C.c_void_p),
+        ("dz", C.c_void_p), ("src0", C.c_void_p), ("src1", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p),
         ("N", C.c_int32), ("C0", C.c_int32), ("C1", C.c_int32), ("Kpad", C.c_int32),
         ("B", C.c_int32), ("T", C.c_int32), ("Fin", C.c_int32), ("Fz", C.c_int32), ("No", C.c_int32),
         ("ostride", C.c_int32), ("ophase", C.c_int32), ("istride", C.c_int32),

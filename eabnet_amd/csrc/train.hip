@@ -151,38 +151,46 @@ extern "C" int eab_train_norm_act_f32(const float* x, const float* xf, const flo
 // pass 2 (apply):  dx (= or +=), PRELU_NORM slope sum into sums[..][2].
 // pass 3 (params): dgamma[c] += sum_b Q, dbeta[c] += sum_b A, dslope[c] += sum_b S.
 // ---------------------------------------------------------------------------------------------------
-#define NB_ROWS 4       // position lanes per block: block = 64 channels x 4
+#define NB_ROWS 16      // position lanes per block: block = 16 float4 channel groups (64 channels) x 16 positions
 
 __global__ __launch_bounds__(TR_THREADS) void tr_zero_kernel(float* __restrict__ p, long long n4) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n4) reinterpret_cast<f32x4*>(p)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
+// thread -> 4 channels (float4) x every 16th position of the block's chunk: a wave reads 4 positions x 256 B = 1 KB
 __global__ __launch_bounds__(TR_THREADS) void norm_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                      const float* __restrict__ mr, const float* __restrict__ gamma,
                                                                      const float* __restrict__ beta, const float* __restrict__ slope,
                                                                      float* __restrict__ sums, int P, int C, int mode, int chunk) {
-    __shared__ float red[3][NB_ROWS][64];
-    const int b = blockIdx.z, cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int c = blockIdx.y * 64 + cl;
-    float A = 0.f, Q = 0.f, S = 0.f;
+    __shared__ f32x4 red[3][NB_ROWS][16];
+    const int b = blockIdx.z, cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + cl * 4;
+    f32x4 A = {0.f, 0.f, 0.f, 0.f}, Q = A, S = A;
     if (c < C) {
-        const float2 m = *reinterpret_cast<const float2*>(&mr[((size_t)b * C + c) * 2]);
-        const float g = gamma[c], be = beta[c], a = slope[c];
+        const float* mp = &mr[((size_t)b * C + c) * 2];
+        const f32x4 m01 = *reinterpret_cast<const f32x4*>(mp), m23 = *reinterpret_cast<const f32x4*>(mp + 4);
+        const float mean[4] = {m01[0], m01[2], m23[0], m23[2]}, rstd[4] = {m01[1], m01[3], m23[1], m23[3]};
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c),
+                    a = *reinterpret_cast<const f32x4*>(slope + c);
         const int p0 = blockIdx.x * chunk, p1 = p0 + chunk < P ? p0 + chunk : P;
         const size_t base = (size_t)b * P * C + c;
         for (int i = p0 + pl; i < p1; i += NB_ROWS) {
-            const float xv = x[base + (size_t)i * C], d = dy[base + (size_t)i * C];
-            if (mode == EAB_XF_NORM_PRELU) {
-                const float xh = (xv - m.x) * m.y, u = fmaf(g, xh, be);
-                const float du = u > 0.f ? d : a * d;
-                A += du;
-                Q = fmaf(du, xh, Q);
-                S += u > 0.f ? 0.f : d * u;
-            } else {
-                const float xh = (eab_prelu(xv, a) - m.x) * m.y;
-                A += d;
-                Q = fmaf(d, xh, Q);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(&x[base + (size_t)i * C]);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(&dy[base + (size_t)i * C]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (mode == EAB_XF_NORM_PRELU) {
+                    const float xh = (xv[j] - mean[j]) * rstd[j], u = fmaf(g[j], xh, be[j]);
+                    const float du = u > 0.f ? d[j] : a[j] * d[j];
+                    A[j] += du;
+                    Q[j] = fmaf(du, xh, Q[j]);
+                    S[j] += u > 0.f ? 0.f : d[j] * u;
+                } else {
+                    const float xh = (eab_prelu(xv[j], a[j]) - mean[j]) * rstd[j];
+                    A[j] += d[j];
+                    Q[j] = fmaf(d[j], xh, Q[j]);
+                }
             }
         }
     }
@@ -190,11 +198,13 @@ __global__ __launch_bounds__(TR_THREADS) void norm_bwd_reduce_kernel(const float
     red[1][pl][cl] = Q;
     red[2][pl][cl] = S;
     __syncthreads();
-    if (pl == 0 && c < C) {
-        float* o = &sums[((size_t)b * C + c) * 4];
-        atomicAdd(o + 0, red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
-        atomicAdd(o + 1, red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]);
-        if (mode == EAB_XF_NORM_PRELU) atomicAdd(o + 2, red[2][0][cl] + red[2][1][cl] + red[2][2][cl] + red[2][3][cl]);
+    if (pl < 3 && c < C) {       // pl = which of (A, Q, S); fixed-order sum over the 16 position lanes, then one atomic per value
+        if (pl == 2 && mode != EAB_XF_NORM_PRELU) return;
+        f32x4 t = red[pl][0][cl];
+#pragma unroll
+        for (int k = 1; k < NB_ROWS; ++k) t += red[pl][k][cl];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(&sums[((size_t)b * C + c + j) * 4 + pl], t[j]);
     }
 }
 
@@ -203,39 +213,57 @@ __global__ __launch_bounds__(TR_THREADS) void norm_bwd_apply_kernel(const float*
                                                                     const float* __restrict__ beta, const float* __restrict__ slope,
                                                                     float* __restrict__ sums, const float* __restrict__ acc_in,
                                                                     float* __restrict__ dx, int P, int C, int mode, int chunk) {
-    __shared__ float red[NB_ROWS][64];
-    const int b = blockIdx.z, cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int c = blockIdx.y * 64 + cl;
-    float S = 0.f;
+    __shared__ f32x4 red[NB_ROWS][16];
+    const int b = blockIdx.z, cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + cl * 4;
+    f32x4 S = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
-        const float2 m = *reinterpret_cast<const float2*>(&mr[((size_t)b * C + c) * 2]);
-        const float g = gamma[c], be = beta[c], a = slope[c];
+        const float* mp = &mr[((size_t)b * C + c) * 2];
+        const f32x4 m01 = *reinterpret_cast<const f32x4*>(mp), m23 = *reinterpret_cast<const f32x4*>(mp + 4);
+        const float mean[4] = {m01[0], m01[2], m23[0], m23[2]}, rstd[4] = {m01[1], m01[3], m23[1], m23[3]};
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c),
+                    a = *reinterpret_cast<const f32x4*>(slope + c);
         const float inv_p = 1.0f / (float)P;
-        const float A = sums[((size_t)b * C + c) * 4] * inv_p, Q = sums[((size_t)b * C + c) * 4 + 1] * inv_p;
-        const float k = m.y * g;
+        float Am[4], Qm[4], k[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Am[j] = sums[((size_t)b * C + c + j) * 4] * inv_p;
+            Qm[j] = sums[((size_t)b * C + c + j) * 4 + 1] * inv_p;
+            k[j] = rstd[j] * g[j];
+        }
         const int p0 = blockIdx.x * chunk, p1 = p0 + chunk < P ? p0 + chunk : P;
         const size_t base = (size_t)b * P * C + c;
         for (int i = p0 + pl; i < p1; i += NB_ROWS) {
             const size_t e = base + (size_t)i * C;
-            const float xv = x[e], d = dy[e];
-            float r;
-            if (mode == EAB_XF_NORM_PRELU) {
-                const float xh = (xv - m.x) * m.y, u = fmaf(g, xh, be);
-                const float du = u > 0.f ? d : a * d;
-                r = k * (du - A - xh * Q);
-            } else {
-                const float xh = (eab_prelu(xv, a) - m.x) * m.y;
-                const float dp = k * (d - A - xh * Q);
-                r = xv > 0.f ? dp : a * dp;
-                S += xv > 0.f ? 0.f : dp * xv;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(&x[e]), d = *reinterpret_cast<const f32x4*>(&dy[e]);
+            f32x4 r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (mode == EAB_XF_NORM_PRELU) {
+                    const float xh = (xv[j] - mean[j]) * rstd[j], u = fmaf(g[j], xh, be[j]);
+                    const float du = u > 0.f ? d[j] : a[j] * d[j];
+                    r[j] = k[j] * (du - Am[j] - xh * Qm[j]);
+                } else {
+                    const float xh = (eab_prelu(xv[j], a[j]) - mean[j]) * rstd[j];
+                    const float dp = k[j] * (d[j] - Am[j] - xh * Qm[j]);
+                    r[j] = xv[j] > 0.f ? dp : a[j] * dp;
+                    S[j] += xv[j] > 0.f ? 0.f : dp * xv[j];
+                }
             }
-            dx[e] = acc_in ? r + acc_in[e] : r;
+            if (acc_in) r += *reinterpret_cast<const f32x4*>(&acc_in[e]);
+            *reinterpret_cast<f32x4*>(&dx[e]) = r;
         }
     }
     if (mode == EAB_XF_PRELU_NORM) {
         red[pl][cl] = S;
         __syncthreads();
-        if (pl == 0 && c < C) atomicAdd(&sums[((size_t)b * C + c) * 4 + 2], red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+        if (pl == 0 && c < C) {
+            f32x4 t = red[0][cl];
+#pragma unroll
+            for (int kk = 1; kk < NB_ROWS; ++kk) t += red[kk][cl];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(&sums[((size_t)b * C + c + j) * 4 + 2], t[j]);
+        }
     }
 }
 
@@ -269,7 +297,7 @@ extern "C" int eab_train_norm_bwd_f32(const float* dy, const float* x, const flo
                                       const float* slope, float* sums, const float* acc_in, float* dx, float* dgamma,
                                       float* dbeta, float* dslope, int B, int P, int C, int mode, eab_stream_t stream) {
     EAB_CHECK_ARG(dy && x && mr && gamma && beta && slope && sums && dx && dgamma && dbeta && dslope);
-    EAB_CHECK_ARG(B > 0 && P > 0 && C > 0 && B <= 65535 && (mode == EAB_XF_NORM_PRELU || mode == EAB_XF_PRELU_NORM));
+    EAB_CHECK_ARG(B > 0 && P > 0 && C > 0 && (C % 4) == 0 && B <= 65535 && (mode == EAB_XF_NORM_PRELU || mode == EAB_XF_PRELU_NORM));
     const int chunk = nb_chunk(P, B, C);
     dim3 grid((P + chunk - 1) / chunk, (C + 63) / 64, B);
     hipStream_t s = eab_stream(stream);

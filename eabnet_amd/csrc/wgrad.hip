@@ -4,112 +4,142 @@
 // reduction runs over the rows.  (What autograd computes for Conv2d / ConvTranspose2d / Conv1d / Linear / the LSTM
 // input and recurrent matrices in train_distributed.py:228; reference layers as listed for eab_conv_f32.)
 //
-// GEMM view: M = N output channels (tile TN = 64 or 128), N = Kpad weight columns (tile 64 = 4 units of 16
+// GEMM view: M = N output channels (tile TN = 64 or 128), N = Kpad weight columns (tile TC = 64 or 128 = 4 or 8 units of 16
 // channels), K = rows.  dz rows and gathered x rows are staged [16 rows][cols] in LDS by coalesced 16-byte loads
 // (a unit of one row is 64 contiguous bytes, zero where the tap leaves the tensor), and both MFMA operands are
 // read K-major straight from there: lane (i, h) takes  As[2s+h][n0+i]  and  Bs[2s+h][c0+i]  -- 32 consecutive
 // floats per half wave, row stride = 32 mod 64 floats, so the two halves use disjoint banks.
-// Split-K over the rows: grid.x row groups accumulate into dW with fp32 atomics (dW zeroed by the caller).
+// Split-K over the rows: grid.x row groups accumulate into dW with fp32 atomics (dW zeroed by the caller).  The
+// column sums of dz (the bias gradient) ride along in the workgroups of column block 0 (dbias, optional).
 // Roofline "mfma" (fp32 dense, 157.3 TFLOP/s); algorithmic bytes = rows * (N + ntaps*C) * 4 per launch.
 #include "common.h"
 
 #define WG_THREADS 256
 #define WG_ROWS 16           // rows per pipeline stage
-#define WG_TC 64             // weight columns per workgroup
-#define WG_OOB 0x80000000u
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-template <int TN>
+template <int TN, int TC>
 struct WgSmem {
-    static constexpr int LDA = TN + 32, LDB = WG_TC + 32;
+    static constexpr int LDA = TN + 32, LDB = TC + 32;
     float a[2][WG_ROWS * LDA];
     float b[2][WG_ROWS * LDB];
 };
 
-template <int TN>
+// (b, t, o) of a flattened row index, advanced by a constant number of rows per stage without divisions
+struct WgRow {
+    int b, t, o;
+    __device__ __forceinline__ void init(long long r, int T, int No) {
+        const long long rows_b = (long long)T * No;
+        b = (int)(r / rows_b);
+        const int q = (int)(r - (long long)b * rows_b);
+        t = q / No;
+        o = q - t * No;
+    }
+    __device__ __forceinline__ void advance(int n, int T, int No) {
+        o += n;
+        while (o >= No) {
+            o -= No;
+            if (++t == T) {
+                t = 0;
+                ++b;
+            }
+        }
+    }
+};
+
+template <int TN, int TC>
 __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const eab_wgrad_desc d) {
-    using Smem = WgSmem<TN>;
-    constexpr int LDA = Smem::LDA, LDB = Smem::LDB, MI = TN / 64;
+    using Smem = WgSmem<TN, TC>;
+    constexpr int LDA = Smem::LDA, LDB = Smem::LDB, MI = TN / 64, NJ = TC / 64;
+    constexpr int AP = TN / 64;                                  // float4 loads of dz per thread per stage
+    constexpr int BP = TC / 64;                                  // float4 loads of x per thread per stage
     __shared__ __attribute__((aligned(16))) Smem sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
 
-    const long long rows_b = (long long)d.T * d.No;              // rows per batch element
-    const long long R = rows_b * d.B;
+    const long long R = (long long)d.T * d.No * d.B;
     const long long r_begin = (long long)blockIdx.x * d.rows_per_wg;
     const long long r_end = r_begin + d.rows_per_wg < R ? r_begin + d.rows_per_wg : R;
-    const int col0 = blockIdx.y * WG_TC, n0 = blockIdx.z * TN;
+    const int col0 = blockIdx.y * TC, n0 = blockIdx.z * TN;
     const int Ctot = d.C0 + d.C1, UPT = (Ctot + 15) >> 4, NU = d.ntaps * UPT;
 
-    // ---- staging roles ------------------------------------------------------------------------------
-    // A (dz): TN = 128: thread -> rows (tid>>5) and (tid>>5)+8, float4 column tid&31;  TN = 64: row tid>>4, float4 tid&15
-    constexpr int AP = TN / 64;                                  // float4 loads of A per thread per stage
+    // ---- staging roles --------------------------------------------------------------------------------
+    // A (dz): thread -> row (tid>>5) + 8p (TN = 128) / tid>>4 (TN = 64), float4 column
     const int a_row = TN == 128 ? tid >> 5 : tid >> 4, a_c4 = TN == 128 ? tid & 31 : tid & 15;
-    // B (gathered x): thread -> row tid>>4, unit (tid>>2)&3 of this column block, float4 tid&3 of the unit
-    const int b_row = tid >> 4, b_unit = (tid >> 2) & 3, b_q = tid & 3;
-    const int u = (col0 >> 4) + b_unit;                          // unit index in [tap][chunk] order
-    const bool u_ok = u < NU;
-    const int tap = u_ok ? u / UPT : 0;
-    const int c0 = (u_ok ? u - tap * UPT : 0) << 4;
-    const bool second = d.C1 > 0 && c0 >= d.C0;
-    const int Cs = second ? d.C1 : d.C0;
-    const int cc = (second ? c0 - d.C0 : c0) + b_q * 4;
-    const bool c_ok = u_ok && cc < Cs;
-    const int dt = d.dt[0] * 0 + (tap == 0 ? d.dt[0] : 0), io_dummy = 0;   // (overwritten below: constant-index reads only)
-    int tdt = 0, tio = 0;
+    // B (gathered x): thread -> row tid>>4, float4 (tid&15) + 16j of the TC-wide block: unit = (tid&15)/4 + 4j
+    const int b_row = tid >> 4, b_q = tid & 3;
+    int tdt[BP], tio[BP], b_cc[BP], b_Cs[BP];
+    const float* b_src[BP];
+    bool b_ok[BP];
 #pragma unroll
-    for (int j = 0; j < EAB_MAX_TAPS; ++j)
-        if (j == tap) {
-            tdt = d.dt[j];
-            tio = d.ioff[j];
-        }
-    (void)dt;
-    (void)io_dummy;
-    const float* srcp = second ? d.src1 : d.src0;
+    for (int j = 0; j < BP; ++j) {
+        const int u = (col0 >> 4) + ((tid & 15) >> 2) + 4 * j;
+        const bool u_ok = u < NU;
+        const int tap = u_ok ? u / UPT : 0;
+        const int c0 = (u_ok ? u - tap * UPT : 0) << 4;
+        const bool second = d.C1 > 0 && c0 >= d.C0;
+        b_Cs[j] = second ? d.C1 : d.C0;
+        b_cc[j] = (second ? c0 - d.C0 : c0) + b_q * 4;
+        b_ok[j] = u_ok && b_cc[j] < b_Cs[j];
+        b_src[j] = second ? d.src1 : d.src0;
+        tdt[j] = tio[j] = 0;
+#pragma unroll
+        for (int k = 0; k < EAB_MAX_TAPS; ++k)
+            if (k == tap) {
+                tdt[j] = d.dt[k];
+                tio[j] = d.ioff[k];
+            }
+    }
+    WgRow ra_[AP], rb_;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) ra_[p].init(r_begin + a_row + 8 * p, d.T, d.No);
+    rb_.init(r_begin + b_row, d.T, d.No);
 
-    f32x4 ra[AP], rb;
+    f32x4 ra[AP], rb[BP];
+    f32x4 bsum[AP];                                              // bias gradient: column sums of dz (column block 0 only)
+#pragma unroll
+    for (int p = 0; p < AP; ++p) bsum[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = d.dbias != nullptr && blockIdx.y == 0;
     auto fetch = [&](long long r0) {
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
-            const long long r = r0 + a_row + 8 * p * (TN == 128 ? 1 : 0);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < r_end) {
-                const long long b = r / rows_b, q = r - b * rows_b;
-                const int t = (int)(q / d.No), o = (int)(q - (long long)t * d.No);
+            if (r0 + a_row + 8 * p < r_end)
                 v = *reinterpret_cast<const f32x4*>(
-                    &d.dz[(((size_t)b * d.T + t) * d.Fz + (size_t)o * d.ostride + d.ophase) * d.N + n0 + a_c4 * 4]);
-            }
+                    &d.dz[(((size_t)ra_[p].b * d.T + ra_[p].t) * d.Fz + (size_t)ra_[p].o * d.ostride + d.ophase) * d.N + n0 + a_c4 * 4]);
             ra[p] = v;
+            ra_[p].advance(WG_ROWS, d.T, d.No);
         }
-        {
-            const long long r = r0 + b_row;
+        const bool rok = r0 + b_row < r_end;
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < r_end && c_ok) {
-                const long long b = r / rows_b, q = r - b * rows_b;
-                const int t = (int)(q / d.No), o = (int)(q - (long long)t * d.No);
-                const int tt = t + tdt, fi = o * d.istride + tio;
-                if (tt >= 0 && tt < d.T && fi >= 0 && fi < d.Fin)
-                    v = *reinterpret_cast<const f32x4*>(&srcp[(((size_t)b * d.T + tt) * d.Fin + fi) * Cs + cc]);
-            }
-            rb = v;
+            const int tt = rb_.t + tdt[j], fi = rb_.o * d.istride + tio[j];
+            if (rok && b_ok[j] && tt >= 0 && tt < d.T && fi >= 0 && fi < d.Fin)
+                v = *reinterpret_cast<const f32x4*>(&b_src[j][(((size_t)rb_.b * d.T + tt) * d.Fin + fi) * b_Cs[j] + b_cc[j]]);
+            rb[j] = v;
         }
+        rb_.advance(WG_ROWS, d.T, d.No);
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < AP; ++p)
+        for (int p = 0; p < AP; ++p) {
             *reinterpret_cast<f32x4*>(&sm.a[buf][(a_row + 8 * p) * LDA + a_c4 * 4]) = ra[p];
-        *reinterpret_cast<f32x4*>(&sm.b[buf][b_row * LDB + b_unit * 16 + b_q * 4]) = rb;
+            if (do_bias) bsum[p] += ra[p];
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) *reinterpret_cast<f32x4*>(&sm.b[buf][b_row * LDB + (tid & 15) * 4 + 64 * j]) = rb[j];
     };
 
-    f32x16 acc[MI];
+    f32x16 acc[MI][NJ];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.0f;
+        for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.0f;
 
     auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    const int a_off = wm * (TN / 2) + li, b_off = wn * 32 + li;
+    const int a_off = wm * (TN / 2) + li, b_off = wn * (TC / 2) + li;
 
     if (r_begin < r_end) {
         fetch(r_begin);
@@ -121,12 +151,16 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const eab_wgrad_desc 
             if (more) fetch(r0 + WG_ROWS);
 #pragma unroll
             for (int s = 0; s < WG_ROWS / 2; ++s) {
-                const float bv = sm.b[cur][(2 * s + lh) * LDB + b_off];
+                float av[MI], bv[NJ];
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const float av = sm.a[cur][(2 * s + lh) * LDA + a_off + mi * 32];
-                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi], 0, 0, 0);
-                }
+                for (int mi = 0; mi < MI; ++mi) av[mi] = sm.a[cur][(2 * s + lh) * LDA + a_off + mi * 32];
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj) bv[nj] = sm.b[cur][(2 * s + lh) * LDB + b_off + nj * 32];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int nj = 0; nj < NJ; ++nj)
+                        acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[nj], acc[mi][nj], 0, 0, 0);
             }
             if (more) stash(cur ^ 1);
             lds_barrier();
@@ -135,15 +169,24 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const eab_wgrad_desc 
     }
 
     // ---- accumulate the tile into dW[n][col]: C/D map of the 32x32 MFMA: column = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
-    const int col = col0 + wn * 32 + li;
-    if (col < d.Kpad) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+    for (int nj = 0; nj < NJ; ++nj) {
+        const int col = col0 + wn * (TC / 2) + nj * 32 + li;
+        if (col < d.Kpad) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wm * (TN / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                atomicAdd(&d.dw[(size_t)n * d.Kpad + col], acc[mi][r]);
-            }
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + wm * (TN / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    atomicAdd(&d.dw[(size_t)n * d.Kpad + col], acc[mi][nj][r]);
+                }
+        }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int p = 0; p < AP; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(&d.dbias[n0 + a_c4 * 4 + j], bsum[p][j]);
     }
 }
 
@@ -158,7 +201,8 @@ extern "C" int eab_wgrad_f32(const eab_wgrad_desc* d, eab_stream_t stream) {
     EAB_CHECK_ARG(d->Kpad == d->ntaps * upt * 16);
     const long long R = (long long)d->B * d->T * d->No;
     const int tn = (d->N % 128 == 0) ? 128 : 64;
-    const int cb = (d->Kpad + WG_TC - 1) / WG_TC, nb = d->N / tn;
+    const int tc = (d->Kpad % 128 == 0) ? 128 : 64;
+    const int cb = (d->Kpad + tc - 1) / tc, nb = d->N / tn;
     // row groups: about four workgroups per CU over the whole grid, at least 256 rows each
     long long groups = (1024 + (long long)cb * nb - 1) / ((long long)cb * nb);
     long long rpw = (R + groups - 1) / groups;
@@ -167,9 +211,10 @@ extern "C" int eab_wgrad_f32(const eab_wgrad_desc* d, eab_stream_t stream) {
     eab_wgrad_desc dd = *d;
     dd.rows_per_wg = (int)rpw;
     dim3 grid((unsigned)((R + rpw - 1) / rpw), (unsigned)cb, (unsigned)nb);
-    if (tn == 128)
-        hipLaunchKernelGGL(wgrad_kernel<128>, grid, dim3(WG_THREADS), 0, eab_stream(stream), dd);
-    else
-        hipLaunchKernelGGL(wgrad_kernel<64>, grid, dim3(WG_THREADS), 0, eab_stream(stream), dd);
+    hipStream_t s = eab_stream(stream);
+    if (tn == 128 && tc == 128) hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(WG_THREADS), 0, s, dd);
+    else if (tn == 128) hipLaunchKernelGGL((wgrad_kernel<128, 64>), grid, dim3(WG_THREADS), 0, s, dd);
+    else if (tc == 128) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(WG_THREADS), 0, s, dd);
+    else hipLaunchKernelGGL((wgrad_kernel<64, 64>), grid, dim3(WG_THREADS), 0, s, dd);
     EAB_RETURN_LAUNCH_STATUS();
 }

@@ -80,6 +80,7 @@ class WgradOp:
     ioff: List[int]
     name: str = ""
     kind: int = OP_WGRAD
+    dbias: Optional[Ref] = None          # bias gradient (column sums of dz over this launch's rows) rides along
 
 
 class Slot:
@@ -247,14 +248,15 @@ class TrainLowering:
             self.flops_bwd += fl
         return op
 
-    def wgrad_op(self, name, dz: Ref, N: int, Fz: int, srcs: Sequence[TVar], No, ostride, ophase, istride, dt, ioff, gimg) -> None:
+    def wgrad_op(self, name, dz: Ref, N: int, Fz: int, srcs: Sequence[TVar], No, ostride, ophase, istride, dt, ioff, gimg,
+                 dbias: Optional[Ref] = None) -> None:
         s0, s1 = srcs[0], (srcs[1] if len(srcs) > 1 else None)
         Ctot = s0.C + (s1.C if s1 else 0)
         Kpad = len(dt) * ((Ctot + 15) // 16) * 16
         assert tuple(gimg.shape) == (N, Kpad), (gimg.shape, N, Kpad)
         self.bwd.append(WgradOp(dz=dz, src0=s0.ref, src1=s1.ref if s1 else None, dw=self.gadd([gimg]), N=N, C0=s0.C,
                                 C1=s1.C if s1 else 0, Kpad=Kpad, B=self.B, T=self.T, Fin=s0.F, Fz=Fz, No=No, ostride=ostride,
-                                ophase=ophase, istride=istride, dt=list(dt), ioff=list(ioff), name=name))
+                                ophase=ophase, istride=istride, dt=list(dt), ioff=list(ioff), name=name, dbias=dbias))
         self.flops_bwd += 2 * self.B * self.T * No * N * len(dt) * Ctot
 
     def colsum(self, name, x: Ref, rows: int, N: int, imgs: Sequence[np.ndarray]) -> None:
@@ -336,8 +338,7 @@ class TrainLowering:
                 self.bwd.append(GenOp(OP_GLU_BWD, [dr, dump, dz], list(_split64(rows)) + [N], name=name + ".glu_bwd"))
             else:
                 dz = dr
-            self.colsum(name + ".db", dz, rows, N, [bimg])
-            self.wgrad_op(name + ".wgrad", dz, N, Fout, srcs, Fout, 1, 0, 2, dts, ios, wimg)
+            self.wgrad_op(name + ".wgrad", dz, N, Fout, srcs, Fout, 1, 0, 2, dts, ios, wimg, dbias=self.gadd([bimg]))
             # dgrad: per source, per input-column parity p:  dx[t'][2o'+p] = sum_{a, c = p, p+2, ..} W[:, ci, a, c]^T dz[t'+(kt-1)-a][o' - (c-p)/2]
             c_lo = 0
             for s in srcs:
@@ -395,9 +396,9 @@ class TrainLowering:
                 self.bwd.append(GenOp(OP_GLU_BWD, [dr, dump, dz], list(_split64(rows)) + [N], name=name + ".glu_bwd"))
             else:
                 dz = dr
-            self.colsum(name + ".db", dz, rows, N, [bimg])
+            gb = self.gadd([bimg])               # both phases add their rows' column sums
             for ph, dts, ios, wimg in phases:
-                self.wgrad_op(f"{name}.wgrad{ph}", dz, N, Fout, srcs, Nos[ph], 2, ph, 1, dts, ios, wimg)
+                self.wgrad_op(f"{name}.wgrad{ph}", dz, N, Fout, srcs, Nos[ph], 2, ph, 1, dts, ios, wimg, dbias=gb)
             # dgrad: a strided convolution over dz:  dx[t'][f] = sum_{a, c} W[ci, :, a, c] dz[t'+a][2f + c]
             taps = [(a, c) for a in range(kt) for c in range(kf)]
             c_lo = 0
@@ -442,9 +443,8 @@ class TrainLowering:
         rows = self.B * self.T
 
         def back(dz: Ref):
-            if bimg is not None:
-                self.colsum(name + ".db", dz, rows, N, [bimg])
-            self.wgrad_op(name + ".wgrad", dz, N, 1, [src], 1, 1, 0, 1, list(dts), [0] * K, wimg)
+            self.wgrad_op(name + ".wgrad", dz, N, 1, [src], 1, 1, 0, 1, list(dts), [0] * K, wimg,
+                          dbias=self.gadd([bimg]) if bimg is not None else None)
             img = self.pack_taps_idx(np.ascontiguousarray(wimg_nck.transpose(1, 0, 2)), range(K))      # (Cc, N, K)
             self.dgrad(name + ".dgrad", src, dz, N, 1, [(self.wadd(wname + ".wd", img), 1, 1, 0, 1, [-d for d in dts], [0] * K)])
         return out, back
@@ -582,8 +582,7 @@ class TrainLowering:
             dbw = self.alloc(rows * MLP_LD)
             bw.slot.ref = dbw
             self.bwd.append(GenOp(OP_FS_BWD, [Ref("dout"), Ref("in"), dbw], [B, T, F, M, MLP_LD], name="filter_sum.bwd"))
-            self.colsum("w_dnn.2.db", dbw, rows, MLP_LD, [b2img])
-            self.wgrad_op("w_dnn.2.wgrad", dbw, MLP_LD, F, [y1], F, 1, 0, 1, [0], [0], w2img)
+            self.wgrad_op("w_dnn.2.wgrad", dbw, MLP_LD, F, [y1], F, 1, 0, 1, [0], [0], w2img, dbias=self.gadd([b2img]))
             dy1 = self.alloc(rows * 64)
             src = TVar(dbw, F, MLP_LD)
             self.emit = self.bwd
@@ -593,16 +592,15 @@ class TrainLowering:
             self.emit = self.fwd
             dpre = self.alloc(rows * 64)
             self.bwd.append(GenOp(OP_RELU_BWD, [dy1, y1.ref, dpre], list(_split64(rows * 64)), name="w_dnn.relu_bwd"))
-            self.colsum("w_dnn.0.db", dpre, rows, 64, [b1img])
-            self.wgrad_op("w_dnn.0.wgrad", dpre, 64, F, [h2], F, 1, 0, 1, [0], [0], w1img)
+            self.wgrad_op("w_dnn.0.wgrad", dpre, 64, F, [h2], F, 1, 0, 1, [0], [0], w1img, dbias=self.gadd([b1img]))
             w1d = self.pack_taps_idx(np.ascontiguousarray(w1.transpose(1, 0, 2)), [0])
             self.dgrad("w_dnn.0.dgrad", h2, dpre, 64, F, [(self.wadd("w_dnn.0.wd", w1d), F, 1, 0, 1, [0], [0])])
             for p, hin, h, gates, wcat in reversed(layers):
                 dg = self.alloc(rows * 256)
                 self.bwd.append(GenOp(OP_LSTM_BWD, [gates, self.grad_of(h), wcat, dg], [B, T, F], name=p + ".bwd"))
                 self.flops_bwd += 2 * rows * 256 * 64
-                self.colsum(p + ".db", dg, rows, 256, [self.idx(f"{p}.bias_ih_l0"), self.idx(f"{p}.bias_hh_l0")])
-                self.wgrad_op(p + ".wgrad_ih", dg, 256, F, [hin], F, 1, 0, 1, [0], [0], self.idx(f"{p}.weight_ih_l0"))
+                self.wgrad_op(p + ".wgrad_ih", dg, 256, F, [hin], F, 1, 0, 1, [0], [0], self.idx(f"{p}.weight_ih_l0"),
+                              dbias=self.gadd([self.idx(f"{p}.bias_ih_l0"), self.idx(f"{p}.bias_hh_l0")]))
                 self.wgrad_op(p + ".wgrad_hh", dg, 256, F, [h], F, 1, 0, 1, [-1], [0], self.idx(f"{p}.weight_hh_l0"))
                 wih_d = self.pack_taps_idx(np.ascontiguousarray(self.idx(f"{p}.weight_ih_l0").T)[:, :, None], [0])   # (64, 256)
                 self.dgrad(p + ".dgrad", hin, dg, 256, F, [(self.wadd(p + ".wd", wih_d), F, 1, 0, 1, [0], [0])])
@@ -720,7 +718,7 @@ class TrainBound:
                     o.p[0] = A(op.ptr)
                 elif op.kind == OP_WGRAD:
                     d = o.wgrad
-                    d.dz, d.src0, d.src1, d.dw = A(op.dz), A(op.src0), A(op.src1), A(op.dw)
+                    d.dz, d.src0, d.src1, d.dw, d.dbias = A(op.dz), A(op.src0), A(op.src1), A(op.dw), A(op.dbias)
                     for f in ("N", "C0", "C1", "Kpad", "B", "T", "Fin", "Fz", "No", "ostride", "ophase", "istride"):
                         setattr(d, f, int(getattr(op, f)))
                     d.ntaps = len(op.dt)

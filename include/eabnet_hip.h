@@ -351,6 +351,7 @@ typedef struct eab_wgrad_desc {
     const float* src0;      /* [B][T][Fin][C0] */
     const float* src1;      /* [B][T][Fin][C1] or NULL */
     float* dw;              /* [N][Kpad] */
+    float* dbias;           /* optional [N]: += column sums of dz over the rows of this launch (bias gradient) */
     int32_t N, C0, C1, Kpad;
     int32_t B, T, Fin, Fz, No, ostride, ophase, istride;
     int32_t ntaps;

@@ -35,11 +35,12 @@ def _ck(code, what=""):
     _lib.check(code, what)
 
 
-def _wgrad(lib, dz, src0, src1, N, Kpad, B, T, Fin, Fz, No, ostride, ophase, istride, dt, ioff):
+def _wgrad(lib, dz, src0, src1, N, Kpad, B, T, Fin, Fz, No, ostride, ophase, istride, dt, ioff, dbias=None):
     from eabnet_amd import _lib
     d = _lib.WgradDesc()
     dw = torch.zeros(N, Kpad, device="cuda:0")
     d.dz, d.src0, d.src1, d.dw = dz.data_ptr(), src0.data_ptr(), (src1.data_ptr() if src1 is not None else None), dw.data_ptr()
+    d.dbias = dbias.data_ptr() if dbias is not None else None
     d.N, d.C0, d.C1, d.Kpad = N, src0.shape[-1], (src1.shape[-1] if src1 is not None else 0), Kpad
     d.B, d.T, d.Fin, d.Fz, d.No, d.ostride, d.ophase, d.istride = B, T, Fin, Fz, No, ostride, ophase, istride
     d.ntaps = len(dt)
@@ -64,11 +65,13 @@ def test_wgrad_of_a_strided_convolution(lib, N, C0, C1, kt, kf, B, T, Fin):
     (y * dz).sum().backward()
     taps = [(a, c) for a in range(kt) for c in range(kf)]
     upt = (C0 + 15) // 16
+    db = torch.zeros(N, device="cuda:0")
     got = _wgrad(lib, _dev(dz.permute(0, 2, 3, 1)), _dev(x.permute(0, 2, 3, 1)), None, N, len(taps) * upt * 16, B, T, Fin, Fout, Fout, 1, 0,
-                 stride, [a - (kt - 1) for a, _ in taps], [c for _, c in taps])
+                 stride, [a - (kt - 1) for a, _ in taps], [c for _, c in taps], dbias=db)
     got = got.view(N, len(taps), upt * 16)[:, :, :C0]                       # [n][tap][c]
     want = w.grad.reshape(N, C0, kt * kf).permute(0, 2, 1)
     assert_close(got.numpy(), want.numpy(), TOL, "dW")
+    assert_close(db.cpu().numpy(), dz.sum((0, 2, 3)).numpy(), TOL, "dbias riding on the weight gradient")
 
 
 @pytest.mark.parametrize("N,C0,C1,kt,kf,B,T,Fin", [(128, 64, 64, 2, 3, 2, 8, 9), (64, 64, 64, 1, 3, 2, 6, 19), (128, 64, 64, 2, 5, 1, 4, 79)])
