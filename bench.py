@@ -236,6 +236,15 @@ def main_train(a, rank, world, dev, is_dist):
                           tr.OP_GLU_BWD: "glu_bwd", prg.OP_IN_FINALIZE: "in_finalize"}.get(o.kind, "other")
                     by[nm] = by.get(nm, 0.0) + float(ms[k])
                 res[which] = {"ms_total": float(ms.sum()), "ms_by_kernel": {k: round(v, 3) for k, v in sorted(by.items(), key=lambda kv: -kv[1])}}
+                if a.per_op:
+                    with open(a.per_op + "." + which, "w") as f:
+                        f.write("idx kind ms gflop tflops name geometry\n")
+                        for k, o in enumerate(ops):
+                            gf, geo = 0.0, ""
+                            if o.kind in (prg.OP_CONV, tr.OP_WGRAD):
+                                gf = 2e-9 * o.B * o.T * o.No * o.N * len(o.dt) * (o.C0 + o.C1)
+                                geo = f"N={o.N} C={o.C0}+{o.C1} taps={len(o.dt)} Fin={o.Fin} No={o.No}"
+                            f.write(f"{k} {o.kind} {ms[k]:.4f} {gf:.3f} {gf / max(ms[k], 1e-9):.2f} {o.name} {geo}\n")
                 if which == "bwd":
                     wg = [k for k, o in enumerate(ops) if o.kind == tr.OP_WGRAD]
                     wg_fl = sum(2.0 * o.B * o.T * o.No * o.N * len(o.dt) * (o.C0 + o.C1) for o in ops if o.kind == tr.OP_WGRAD)

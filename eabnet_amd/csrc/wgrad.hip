@@ -182,11 +182,19 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const eab_wgrad_desc 
                 }
         }
     }
-    if (do_bias) {
+    if (d.dbias != nullptr && blockIdx.y == 0) {     // (workgroup-uniform)
+        // the 16 row lanes of a column are summed through LDS first: ONE atomic per column and workgroup (per-thread
+        // atomics on the same 128 addresses from every row group serialised in L2: 9 -> 34 ms per step when tried)
+        __syncthreads();
 #pragma unroll
-        for (int p = 0; p < AP; ++p)
+        for (int p = 0; p < AP; ++p) *reinterpret_cast<f32x4*>(&sm.a[0][(a_row + 8 * p) * LDA + a_c4 * 4]) = bsum[p];
+        __syncthreads();
+        if (tid < TN) {
+            float t = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) atomicAdd(&d.dbias[n0 + a_c4 * 4 + j], bsum[p][j]);
+            for (int r = 0; r < WG_ROWS; ++r) t += sm.a[0][r * LDA + tid];
+            atomicAdd(&d.dbias[n0 + tid], t);
+        }
     }
 }
 
@@ -203,10 +211,12 @@ extern "C" int eab_wgrad_f32(const eab_wgrad_desc* d, eab_stream_t stream) {
     const int tn = (d->N % 128 == 0) ? 128 : 64;
     const int tc = (d->Kpad % 128 == 0) ? 128 : 64;
     const int cb = (d->Kpad + tc - 1) / tc, nb = d->N / tn;
-    // row groups: about four workgroups per CU over the whole grid, at least 256 rows each
+    // row groups: about four workgroups per CU over the whole grid, at least 64 rows (four pipeline stages) each -- a
+    // stage is a global-load -> LDS -> barrier round trip of ~2 us that only other resident workgroups can hide, so the
+    // small layers (a few thousand rows) want many short workgroups rather than a few long ones
     long long groups = (1024 + (long long)cb * nb - 1) / ((long long)cb * nb);
     long long rpw = (R + groups - 1) / groups;
-    if (rpw < 256) rpw = 256;
+    if (rpw < 64) rpw = 64;
     rpw = (rpw + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
     eab_wgrad_desc dd = *d;
     dd.rows_per_wg = (int)rpw;
