@@ -675,6 +675,29 @@ def main():
                 st = None
             nxt["streaming"] = stream_rows
             sn = None
+            # the same shape with the causal norm the reference means to offer (norm_type="cLN", fixed constructor): running
+            # sums are the only norm state; statistics and normalisation are separate ops here, hence more launches per step
+            torch.manual_seed(3)
+            sc = eabnet_amd.EaBNet(M=16, norm_type="cLN").to(dev).eval()
+            cln_rows = {"config": "B=1, M=16, T_max=801 (8 s), norm_type=cLN; fp32 and (suffix _bf16) bf16 products", "hop_ms": 10.0}
+            for chunk, sprec in ((1, "f32"), (16, "f32"), (1, "bf16")):
+                sc.precision = sprec
+                st = sc.stream_begin(1, T_max=801, chunk=chunk)
+                xs = 0.3 * torch.randn(1, chunk, 161, 16, 2, device=dev)
+                for _ in range(3):
+                    st.step(xs)
+                torch.cuda.synchronize()
+                nstep = min(40, (801 - 3 * chunk) // chunk)
+                t0 = time.perf_counter()
+                for _ in range(nstep):
+                    ys = st.step(xs)
+                torch.cuda.synchronize()
+                dts = (time.perf_counter() - t0) / nstep
+                assert bool(torch.isfinite(ys).all())
+                cln_rows[f"chunk{chunk}" + ("" if sprec == "f32" else "_bf16")] = {"ms_per_step": 1e3 * dts, "rtf": dts / (chunk * 0.010)}
+                st = None
+            nxt["streaming_cln"] = cln_rows
+            sc = None
             # the same, wave in -> wave out through the two-stage model (StreamingEnhancer: STFT windows, streamed
             # beam-former + post-filter, ISTFT windows), one 10-ms hop of 16-microphone samples per push
             pb = argparse.Namespace(**{**vars(pa), "M": 16, "norm_type": "BN", "gagnet_norm_type": "BN"})

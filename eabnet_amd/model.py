@@ -974,8 +974,8 @@ def prepare_data(x: torch.Tensor, target: torch.Tensor, device, args):
     win_size = int(args.win_size * sr)
     win_shift = int(args.win_shift * sr)
     fft_num = args.fft_num
-    if win_size != fft_num:
-        raise NotImplementedError("the HIP front end implements win_size == fft_num (the reference's 320/320)")
+    if win_size > fft_num:
+        raise RuntimeError(f"win_size ({win_size} samples) must not exceed fft_num ({fft_num}), as in torch.stft")
     batch_size = x.shape[0]
     device = torch.device(device)
     if device.type == "cuda" and device.index is None:
@@ -986,6 +986,9 @@ def prepare_data(x: torch.Tensor, target: torch.Tensor, device, args):
         noisy_wav = xd.contiguous().view(batch_size, args.mics, -1)
         target_wav = td.reshape(batch_size, 1, -1)
         window = torch.hann_window(win_size)
+        if win_size < fft_num:                        # torch.stft(win_length < n_fft): zero-padded on both sides, centred
+            left = (fft_num - win_size) // 2
+            window = torch.nn.functional.pad(window, (left, fft_num - win_size - left))
         noisy_stft = stft_compress(noisy_wav, fft_num, win_shift, window, 0)
         target_stft = stft_compress(target_wav, fft_num, win_shift, window, 1)
         for ev in (ev_x, ev_t):

@@ -60,9 +60,18 @@ def hann_periodic(n: int, dtype=torch.float32) -> torch.Tensor:
     return torch.hann_window(n, dtype=dtype)
 
 
-def stft_oracle(wav: torch.Tensor, n_fft: int, hop: int) -> torch.Tensor:
-    """(N, L) -> (N, F, T, 2); frames * periodic Hann -> one-sided rfft."""
-    fr = stft_frames(wav, n_fft, hop) * hann_periodic(n_fft, wav.dtype)
+def padded_window(n_fft: int, win: int, dtype=torch.float32) -> torch.Tensor:
+    """torch.stft(win_length=win < n_fft): the window is zero-padded on both sides to n_fft, centred"""
+    w = hann_periodic(win, dtype)
+    if win == n_fft:
+        return w
+    left = (n_fft - win) // 2
+    return torch.nn.functional.pad(w, (left, n_fft - win - left))
+
+
+def stft_oracle(wav: torch.Tensor, n_fft: int, hop: int, win: Optional[int] = None) -> torch.Tensor:
+    """(N, L) -> (N, F, T, 2); frames * periodic Hann (zero-padded to n_fft when shorter) -> one-sided rfft."""
+    fr = stft_frames(wav, n_fft, hop) * padded_window(n_fft, win or n_fft, wav.dtype)
     X = torch.fft.rfft(fr, n=n_fft, dim=-1)             # (N, T, F)
     return torch.view_as_real(X).permute(0, 2, 1, 3).contiguous()
 
@@ -80,14 +89,14 @@ def prepare_data_oracle(x: torch.Tensor, target: Optional[torch.Tensor], n_fft: 
                         hop: int = 160, win: int = 320
                         ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """x (B,M,L), target (B,1,L) -> noisy (B,T,F,M,2), target (B,2,T,F)."""
-    assert win == n_fft, "the reference always uses win_size == fft_num (320)"
+    assert win <= n_fft, "torch.stft needs win_length <= n_fft"
     B, M, L = x.shape
-    X = stft_oracle(x.reshape(B * M, L), n_fft, hop)               # (B*M, F, T, 2)
+    X = stft_oracle(x.reshape(B * M, L), n_fft, hop, win)          # (B*M, F, T, 2)
     X = X.view(B, M, X.shape[1], X.shape[2], 2).permute(0, 3, 2, 1, 4)   # (B,T,F,M,2)
     noisy = compress_oracle(X, -1).contiguous()
     tgt = None
     if target is not None:
-        Y = stft_oracle(target.reshape(B, L), n_fft, hop).permute(0, 3, 2, 1)   # (B,2,T,F)
+        Y = stft_oracle(target.reshape(B, L), n_fft, hop, win).permute(0, 3, 2, 1)   # (B,2,T,F)
         tgt = compress_oracle(Y, 1).contiguous()
     return noisy, tgt
 

@@ -1361,3 +1361,17 @@ def test_cln_every_op_matches_the_emulator_and_streams(dev):
     x2[:, 500:] = 0.0
     with torch.no_grad():
         assert torch.equal(net(x2)[:, :, :500], off[:, :, :500])
+
+
+def test_prepare_data_with_a_window_shorter_than_the_fft(dev):
+    """prepare_data with win_size != fft_num (the reference accepts any win_length <= n_fft, train_distributed.py:83)."""
+    import eabnet_amd
+    from oracle import eabnet_oracle as orc
+    x = torch.from_numpy(paramgen.make_wave(2, 4, 3200, 43))
+    args = type("A", (), dict(mics=4, sr=16000, wav_len=0.2, win_size=0.0125, win_shift=0.010, fft_num=320))   # 200-sample window
+    noisy, tgt = eabnet_amd.prepare_data(x, x[:, :1], dev, args)
+    want_n, want_t = orc.prepare_data_oracle(x, x[:, :1], 320, 160, 200)
+    assert_compressed_close(noisy.cpu().numpy(), want_n.numpy(), TOL_HIP, "noisy")
+    assert_compressed_close(np.moveaxis(tgt.cpu().numpy(), 1, -1), np.moveaxis(want_t.numpy(), 1, -1), TOL_HIP, "target")
+    with pytest.raises(RuntimeError):
+        eabnet_amd.prepare_data(x, x[:, :1], dev, type("A", (), dict(mics=4, sr=16000, wav_len=0.2, win_size=0.03, win_shift=0.010, fft_num=320)))

@@ -308,3 +308,13 @@ def test_cumulative_layer_norm_matches_the_reference_classes():
     x[:, :, 7:] += 1.0
     y1 = orc.cumulative_layer_norm(x, torch.from_numpy(g["2d/gain"]), torch.from_numpy(g["2d/bias"]))
     assert torch.equal(y0[:, :, :7], y1[:, :, :7]) and not torch.equal(y0[:, :, 7:], y1[:, :, 7:])
+
+
+def test_prepare_data_oracle_with_a_short_window_equals_torch_stft():
+    """win_size < fft_num (prepare_data passes both to torch.stft, train_distributed.py:83): the oracle's zero-padded
+    centred window reproduces torch.stft(n_fft=320, win_length=200) bit for bit."""
+    x = torch.from_numpy(paramgen.make_wave(1, 2, 2400, 17))
+    win = torch.hann_window(200)
+    ref = torch.stft(x.view(2, -1), 320, 160, 200, win, return_complex=False)          # (N, F, T, 2)
+    got = orc.stft_oracle(x.view(2, -1), 320, 160, 200)
+    assert torch.equal(got, ref) or float((got - ref).abs().max()) < 1e-6 * float(ref.abs().max())
