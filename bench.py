@@ -371,7 +371,8 @@ def main():
                 ok = ok and bool(torch.equal(yy, want))
         torch.cuda.synchronize()
         return ok
-    assert pipelined_results_all_equal(y_seq), "a pipelined result differs from the direct call (f32)"
+    if a.pipeline > 1:             # (--pipeline 1 = the profiling recipe: one batch in flight, nothing pipelined anywhere)
+        assert pipelined_results_all_equal(y_seq), "a pipelined result differs from the direct call (f32)"
 
     frames = world * B_PER_GPU * T * a.steps
     out = {
@@ -405,7 +406,7 @@ def main():
         el2_seq = timed_steps(1, 2, a.steps)[0] if depth > 1 else el2
         with torch.no_grad():
             y_seq2, _ = step()                  # the same batch through a direct (unpipelined) call
-        same = bool(torch.equal(y_seq2, y)) and pipelined_results_all_equal(y_seq2)
+        same = bool(torch.equal(y_seq2, y)) and (a.pipeline <= 1 or pipelined_results_all_equal(y_seq2))
         dev_rel = float((y - y32).abs().max() / y32.abs().max())
         if same and dev_rel < 1e-4:
             out["alt_precision"] = {

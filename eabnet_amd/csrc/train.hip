@@ -53,43 +53,60 @@ __global__ __launch_bounds__(TR_THREADS) void in_stats_kernel(const float* __res
                                                               int P, int C, float eps, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* __restrict__ xf,
                                                               float* __restrict__ mr) {
-    __shared__ double red[2][4][64];
-    const int b = blockIdx.x, cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int c = blockIdx.y * 64 + cl;
-    double s = 0.0, q = 0.0;
+    // thread -> 4 channels (float4) x every 16th position; shifted sums (shift = the channel's first value, so a
+    // nearly constant channel loses nothing to cancellation) in fp64, combined through LDS in a fixed order
+    __shared__ double red[2][16][64];
+    const int b = blockIdx.x, cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + cl * 4;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    f32x4 k = {0.f, 0.f, 0.f, 0.f}, a = {1.f, 1.f, 1.f, 1.f};
     if (c < C) {
-        const float a = slope ? slope[c] : 1.0f;
+        if (slope) a = *reinterpret_cast<const f32x4*>(slope + c);
         const float* p = x + (size_t)b * P * C + c;
-        // shifted sums (shift = the first value): no cancellation for nearly constant channels
-        const float k = eab_prelu(p[0], a);
-        for (int i = pl; i < P; i += 4) {
-            const double v = (double)(eab_prelu(p[(size_t)i * C], a) - k);
-            s += v;
-            q += v * v;
+        k = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) k[j] = eab_prelu(k[j], a[j]);
+        for (int i = pl; i < P; i += 16) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + (size_t)i * C);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double d = (double)(eab_prelu(v[j], a[j]) - k[j]);
+                s[j] += d;
+                q[j] += d * d;
+            }
         }
-        red[0][pl][cl] = s;
-        red[1][pl][cl] = q;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[0][pl][cl * 4 + j] = s[j];
+        red[1][pl][cl * 4 + j] = q[j];
     }
     __syncthreads();
-    if (pl == 0 && c < C) {
-        const float a = slope ? slope[c] : 1.0f;
-        const float k = eab_prelu(x[(size_t)b * P * C + c], a);
-        s = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-        q = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
-        const double mean_s = s / P;
-        double var = q / P - mean_s * mean_s;
-        if (var < 0.0) var = 0.0;
-        const double mean = mean_s + (double)k;
-        const double rstd = 1.0 / sqrt(var + (double)eps);
-        const double scale = (double)gamma[c] * rstd;
-        *reinterpret_cast<float2*>(&xf[((size_t)b * C + c) * 2]) = make_float2((float)scale, (float)((double)beta[c] - mean * scale));
-        *reinterpret_cast<float2*>(&mr[((size_t)b * C + c) * 2]) = make_float2((float)mean, (float)rstd);
+    if (threadIdx.x < 64) {
+        const int cc = blockIdx.y * 64 + threadIdx.x;
+        if (cc < C) {
+            double ss = 0.0, qq = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                ss += red[0][r][threadIdx.x];
+                qq += red[1][r][threadIdx.x];
+            }
+            const float kk = eab_prelu(x[(size_t)b * P * C + cc], slope ? slope[cc] : 1.0f);
+            const double mean_s = ss / P;
+            double var = qq / P - mean_s * mean_s;
+            if (var < 0.0) var = 0.0;
+            const double mean = mean_s + (double)kk;
+            const double rstd = 1.0 / sqrt(var + (double)eps);
+            const double scale = (double)gamma[cc] * rstd;
+            *reinterpret_cast<float2*>(&xf[((size_t)b * C + cc) * 2]) = make_float2((float)scale, (float)((double)beta[cc] - mean * scale));
+            *reinterpret_cast<float2*>(&mr[((size_t)b * C + cc) * 2]) = make_float2((float)mean, (float)rstd);
+        }
     }
 }
 
 extern "C" int eab_train_in_stats_f32(const float* x, const float* slope, int B, int P, int C, float eps, const float* gamma,
                                       const float* beta, float* xf, float* mr, eab_stream_t stream) {
-    EAB_CHECK_ARG(x && gamma && beta && xf && mr && B > 0 && P > 0 && C > 0 && B <= 65535);
+    EAB_CHECK_ARG(x && gamma && beta && xf && mr && B > 0 && P > 0 && C > 0 && (C % 4) == 0 && B <= 65535);
     hipLaunchKernelGGL(in_stats_kernel, dim3(B, (C + 63) / 64), dim3(TR_THREADS), 0, eab_stream(stream), x, slope, P, C, eps,
                        gamma, beta, xf, mr);
     EAB_RETURN_LAUNCH_STATUS();
