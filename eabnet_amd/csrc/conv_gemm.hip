@@ -116,7 +116,7 @@ __device__ __forceinline__ void cg_split2(float x0, float x1, unsigned& hi, unsi
 }
 
 template <int MI, int NI, int KU, int MODE, int XF, bool VEC, int PREC, bool PATCH>
-__global__ __launch_bounds__(CG_THREADS) void conv_gemm_kernel(const eab_conv_desc d) {
+__global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE == CG_GLU) ? 3 : 1) void conv_gemm_kernel(const eab_conv_desc d) {
     static_assert(!PATCH || (KU == 1 && MODE != CG_DUAL && VEC), "patch mode: one unit per stage, single transform");
     constexpr bool H3 = PREC == EAB_PREC_F16X3;
     constexpr bool BF = PREC == EAB_PREC_BF16;       // fp32 in memory, operands rounded to bf16 on their way into LDS, ONE bf16 MFMA
