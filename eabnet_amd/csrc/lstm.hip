@@ -278,13 +278,13 @@ __global__ __launch_bounds__(256) void lstm64_kernel(const float* __restrict__ x
 //   The four gates of a unit sit in one quad: quad_perm DPP broadcasts hand every lane i, f, g, o and
 //   the quad updates the cell redundantly (lanes are free; lane j stores sequence j).
 // Same x prefetch, LayerNorm, streaming window and state hand-off as lstm64_kernel.
-template <bool LN, int G>
+template <bool LN, int G, bool DUMP = false>
 __global__ __launch_bounds__(256) void lstm64_q_kernel(const float* __restrict__ x, const float* __restrict__ ln_g,
                                                        const float* __restrict__ ln_b, float ln_eps,
                                                        const float* __restrict__ wcat, const float* __restrict__ bias,
                                                        float* __restrict__ h_out, int T, int F, int S,
                                                        const int* __restrict__ t_pos, int t_count,
-                                                       float* __restrict__ c_state) {
+                                                       float* __restrict__ c_state, float* __restrict__ gates = nullptr) {
     constexpr int NSEQ = 4 * G;
     constexpr int NCH = G == 1 ? 8 : (G == 2 ? 4 : 2);       // accumulation chains per group (>= 6 in flight overall)
     __shared__ __attribute__((aligned(16))) float xs[2][NSEQ * LS_LD];
@@ -405,6 +405,16 @@ __global__ __launch_bounds__(256) void lstm64_q_kernel(const float* __restrict__
                 cst[q][s] = fmaf(gf, cst[q][s], gi * gg);
                 const float hv = go * ls_tanh(cst[q][s]);
                 if (s == gate) hs[nxt][(4 * q + s) * LS_LD + u] = hv;
+                if (DUMP) {
+                    // training: gates[seq][t][5][64] = i, f, g, o, c (the layout csrc/lstm_bwd.hip reads): every lane its own
+                    // activated gate, lane s of the quad the cell state of sequence s
+                    const int sq = s0 + 4 * q + s;
+                    if (sq < S) {
+                        float* gp = gates + (((size_t)sq * T + t) * 5) * LS_H + u;
+                        gp[gate * LS_H] = a;
+                        if (s == gate) gp[4 * LS_H] = cst[q][s];
+                    }
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -490,6 +500,11 @@ extern "C" int eab_lstm64_train_fwd_f32(const float* x, const float* wcat, const
     EAB_CHECK_ARG(x && wcat && bias && h_out && gates && B > 0 && T > 0 && F > 0);
     const long long S = (long long)B * F;
     EAB_CHECK_ARG(S * T * LS_H * 4 < (1ll << 31));
+    if (S <= 2048) {        // same split as the inference dispatcher: 4-sequence workgroups while they fit the chip in two rounds
+        hipLaunchKernelGGL((lstm64_q_kernel<false, 1, true>), dim3((unsigned)((S + 3) / 4)), dim3(256), 0, eab_stream(stream), x,
+                           nullptr, nullptr, 0.0f, wcat, bias, h_out, T, F, (int)S, nullptr, 0, nullptr, gates);
+        EAB_RETURN_LAUNCH_STATUS();
+    }
     const int grid = (int)((S + LS_SEQ - 1) / LS_SEQ);
     hipLaunchKernelGGL((lstm64_kernel<false, true>), dim3(grid), dim3(256), 0, eab_stream(stream), x, nullptr, nullptr, 0.0f, wcat,
                        bias, h_out, T, F, (int)S, nullptr, 0, nullptr, gates);

@@ -13,6 +13,7 @@
 // column sums of dz (the bias gradient) ride along in the workgroups of column block 0 (dbias, optional).
 // Roofline "mfma" (fp32 dense, 157.3 TFLOP/s); algorithmic bytes = rows * (N + ntaps*C) * 4 per launch.
 #include "common.h"
+#include <math.h>
 
 #define WG_THREADS 256
 #define WG_ROWS 16           // rows per pipeline stage
@@ -211,10 +212,20 @@ extern "C" int eab_wgrad_f32(const eab_wgrad_desc* d, eab_stream_t stream) {
     const int tn = (d->N % 128 == 0) ? 128 : 64;
     const int tc = (d->Kpad % 128 == 0) ? 128 : 64;
     const int cb = (d->Kpad + tc - 1) / tc, nb = d->N / tn;
-    // row groups: about four workgroups per CU over the whole grid, at least 64 rows (four pipeline stages) each -- a
-    // stage is a global-load -> LDS -> barrier round trip of ~2 us that only other resident workgroups can hide, so the
-    // small layers (a few thousand rows) want many short workgroups rather than a few long ones
-    long long groups = (1024 + (long long)cb * nb - 1) / ((long long)cb * nb);
+    // Row groups G (split-K).  Two costs pull in opposite directions, both measured on MI355X:
+    //   * every group adds its whole tile to dW with device-scope atomics, and those retire at ~1.2e11 per second chip-wide
+    //     (en.3.in_conv: 338 groups x 128 x 384 atomics = 127 us, whatever the matrix work) -> t_atomic = G * cb*nb*tn*tc / 1.2e11;
+    //   * a group is a serial chain of 16-row stages (global load -> LDS -> barrier -> MFMA, ~0.5-1 us each with
+    //     neighbours hiding the latency) -> t_chain = R / (16 G) * t_stage.
+    // G* = sqrt(R * t_stage / 16 / (atomics per group / 1.2e11)) minimises the sum; never more than ~four workgroups per CU
+    // over the grid, never fewer than fill the chip once (when R allows it at >= 64 rows per group).
+    const double t_stage = (tn == 128 && tc == 128) ? 1.0e-6 : (tn == 128 || tc == 128) ? 0.7e-6 : 0.5e-6;
+    const double per_group = (double)cb * nb * tn * tc / 1.2e11;
+    long long groups = (long long)(sqrt((double)R * t_stage / 16.0 / per_group) + 0.5);
+    const long long g_max = (1024 + (long long)cb * nb - 1) / ((long long)cb * nb);
+    const long long g_min = (256 + (long long)cb * nb - 1) / ((long long)cb * nb);
+    if (groups > g_max) groups = g_max;
+    if (groups < g_min) groups = g_min;
     long long rpw = (R + groups - 1) / groups;
     if (rpw < 64) rpw = 64;
     rpw = (rpw + WG_ROWS - 1) / WG_ROWS * WG_ROWS;

@@ -29,6 +29,8 @@ import ctypes as C
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -677,6 +679,59 @@ class TrainBound:
         self.fwd = (_lib.Op * len(prog.fwd))()
         self.bwd = (_lib.Op * len(prog.bwd))()
         self._bound = None
+        self.serial = 0                     # forward passes run so far: a backward must belong to the latest one
+        self.use_graph = True
+        self.graphs = None                  # (forward hipGraph, backward hipGraph) on the static boundary buffers
+        self.graph_failed = False
+        self.static_x = self.static_out = self.static_dout = None
+        # Backward lanes: a weight gradient is a leaf of the backward graph -- nothing reads dW before the step ends, its
+        # operands (the finished gradient of a convolution output, a forward activation) are never written again
+        # (TrainLowering never recycles a buffer) -- so every block of wgrad launches forks onto a side stream right after
+        # its producer and joins at the end.  The dgrad / norm-backward chain of the small layers and the 161-workgroup LSTM
+        # backward leave most of the chip idle; the wgrads fill it.  Captured into the hipGraph these are parallel branches.
+        self.wgrad_lanes = int(os.environ.get("EAB_WGRAD_LANES", "0"))     # measured: 30.5 (2 lanes) / 30.7 (1) / 30.2 ms (off) per step -- co-running kernels slow each other (a dgrad next to a wgrad: 239 -> 623 us), so off by default
+        self.segments = []                  # (lane, first op, count) of the backward program; lane 0 = the caller's stream
+        k, nb, blk = 0, len(prog.bwd), 0
+        while k < nb:
+            j, is_w = k + 1, prog.bwd[k].kind == OP_WGRAD
+            while j < nb and (prog.bwd[j].kind == OP_WGRAD) == is_w:
+                j += 1
+            if is_w:
+                blk += 1
+            self.segments.append((1 + blk % 2 if is_w else 0, k, j - k))
+            k = j
+        self._side = None
+
+    def capture(self, x_shape) -> bool:
+        """Both programs as hipGraphs on static boundary buffers (input, output, output gradient): a step is two graph
+        launches instead of ~840 host-side kernel launches.  False (direct launches) if the runtime refuses."""
+        if self.graphs is not None or self.graph_failed or not self.use_graph:
+            return self.graphs is not None
+        prog = self.prog
+        try:
+            self.static_x = torch.zeros(x_shape, dtype=torch.float32, device=self.device)
+            self.static_out = torch.zeros((prog.B, 2, prog.T, prog.F), dtype=torch.float32, device=self.device)
+            self.static_dout = torch.zeros_like(self.static_out)
+            self.bind(self.static_x.data_ptr(), self.static_out.data_ptr(), self.static_dout.data_ptr())
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                 # warm-up outside the capture (weights are packed already)
+                self.g.zero_()
+                self.run("fwd", side.cuda_stream)
+                self.run("bwd", side.cuda_stream)
+            torch.cuda.current_stream().wait_stream(side)
+            graphs = []
+            for which in ("fwd", "bwd"):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.run(which, torch.cuda.current_stream().cuda_stream)
+                graphs.append(g)
+            self.graphs = tuple(graphs)
+        except Exception as e:                            # noqa: BLE001 - any capture failure -> direct launches
+            import warnings
+            warnings.warn(f"eabnet_amd: hipGraph capture of the training programs failed ({e!r}); using direct launches")
+            self.graphs, self.graph_failed, self._bound = None, True, None
+        return self.graphs is not None
 
     def bind(self, in_ptr: int, out_ptr: int, dout_ptr: int) -> None:
         if self._bound == (in_ptr, out_ptr, dout_ptr):
@@ -736,6 +791,24 @@ class TrainBound:
 
     def run(self, which: str, stream: int, first: int = 0, count: Optional[int] = None) -> None:
         arr = self.fwd if which == "fwd" else self.bwd
+        if which == "bwd" and self.wgrad_lanes and first == 0 and count is None:
+            main = torch.cuda.current_stream()
+            assert main.cuda_stream == stream, "the backward program forks from torch's current stream"
+            if self._side is None:
+                self._side = [torch.cuda.Stream(device=self.device) for _ in range(2)]
+            used = set()
+            for lane, k, n in self.segments:
+                if lane == 0:
+                    self.run(which, stream, k, n)
+                    continue
+                sd = self._side[(lane - 1) % self.wgrad_lanes]
+                sd.wait_stream(main)
+                used.add(sd)
+                with torch.cuda.stream(sd):
+                    self.run(which, sd.cuda_stream, k, n)
+            for sd in used:
+                main.wait_stream(sd)
+            return
         n = len(arr) - first if count is None else count
         ops = C.cast(C.byref(arr, first * C.sizeof(_lib.Op)), C.POINTER(_lib.Op))
         _lib.check(_lib.load().eab_run_program(ops, n, C.c_void_p(stream)), f"eab_run_program({which})")
@@ -758,12 +831,20 @@ class _EaBNetTrainFn(torch.autograd.Function):
         ctx.sync_group = sync_group
         st = torch.cuda.current_stream().cuda_stream
         flat = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in params])
-        out = torch.empty((prog.B, 2, prog.T, prog.F), dtype=torch.float32, device=x.device)
-        dout = torch.empty_like(out)
-        bound.bind(x.data_ptr(), out.data_ptr(), dout.data_ptr())
         bound.pack(flat, st)
-        bound.run("fwd", st)
-        ctx.bound, ctx.x, ctx.dout, ctx.out = bound, x, dout, out
+        bound.serial += 1
+        ctx.serial = bound.serial
+        if bound.capture(tuple(x.shape)):
+            bound.static_x.copy_(x)
+            bound.graphs[0].replay()
+            out = bound.static_out.clone()
+            ctx.bound, ctx.x, ctx.dout, ctx.out = bound, None, None, None
+        else:
+            out = torch.empty((prog.B, 2, prog.T, prog.F), dtype=torch.float32, device=x.device)
+            dout = torch.empty_like(out)
+            bound.bind(x.data_ptr(), out.data_ptr(), dout.data_ptr())
+            bound.run("fwd", st)
+            ctx.bound, ctx.x, ctx.dout, ctx.out = bound, x, dout, out
         ctx.shapes = [p.shape for p in params]
         ctx.dtypes = [p.dtype for p in params]
         return out
@@ -772,11 +853,18 @@ class _EaBNetTrainFn(torch.autograd.Function):
     def backward(ctx, grad_out: torch.Tensor):
         bound, prog = ctx.bound, ctx.bound.prog
         st = torch.cuda.current_stream().cuda_stream
-        ctx.dout.copy_(grad_out.to(torch.float32))
-        bound.bind(ctx.x.data_ptr(), ctx.out.data_ptr(), ctx.dout.data_ptr())
+        if ctx.serial != bound.serial:
+            raise RuntimeError("eabnet_amd: backward of a forward pass whose saved activations were overwritten by a later "
+                               "forward of the same module (one training program holds one set of activations)")
         bound.g.zero_()
-        bound.run("bwd", st)
-        gflat = torch.empty(prog.n_params, dtype=torch.float32, device=ctx.x.device)     # fresh per call: .grad may keep views of it
+        if ctx.x is None:
+            bound.static_dout.copy_(grad_out)
+            bound.graphs[1].replay()
+        else:
+            ctx.dout.copy_(grad_out.to(torch.float32))
+            bound.bind(ctx.x.data_ptr(), ctx.out.data_ptr(), ctx.dout.data_ptr())
+            bound.run("bwd", st)
+        gflat = torch.empty(prog.n_params, dtype=torch.float32, device=bound.device)     # fresh per call: .grad may keep views of it
         bound.unpack_grads(gflat, st)
         if ctx.sync_group is not None:
             # data-parallel training: the whole gradient is ONE contiguous buffer, so the reference's DDP bucket
@@ -807,6 +895,7 @@ def forward_train(module, inpt: torch.Tensor) -> torch.Tensor:
         cache.clear()
         with torch.cuda.device(x.device):
             bound = cache[key] = TrainBound(lower_train(module.cfg, B, T, F, prec), x.device)
+    bound.use_graph = bool(getattr(module, "use_graph", True)) and not torch.cuda.is_current_stream_capturing()
     sd = dict(module.named_parameters())
     params = [sd[k] for k in bound.prog.keys]
     sync = module.__dict__.get("grad_allreduce", None)          # None | True (default group) | a process group

@@ -217,7 +217,7 @@ def test_elementwise_backward_kernels(lib):
     assert_close(dbl.cpu().numpy(), bl.grad.numpy(), TOL, "layernorm dbeta")
 
 
-@pytest.mark.parametrize("B,T,Fq", [(1, 9, 21), (2, 40, 161)])
+@pytest.mark.parametrize("B,T,Fq", [(1, 9, 21), (2, 40, 161), (13, 5, 161)])      # the last: > 2048 sequences, the 16-sequence kernel
 def test_lstm_training_forward_and_reverse_time_kernel(lib, B, T, Fq):
     """nn.LSTM(64, 64) over time for B*F sequences (EaBNet.py:610-611): the training forward (gates kept) equals the
     layer, and the reverse-time kernel's dgates reproduce autograd's dW_ih, dW_hh, db and dx."""
