@@ -687,6 +687,63 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
 
     const unsigned row_bytes = (unsigned)(d.Fout * Cout) * 4u, step_bytes = (unsigned)(d.ostride * Cout) * 4u;
     const unsigned phase_bytes = (unsigned)(d.ophase * Cout) * 4u;
+    // Fast path (workgroup-uniform): a full tile with the plain / gated epilogue and at most one statistics set -- every
+    // 2-D convolution of the inference program except the last tile of a batch element.  Straight-line code: no per-row
+    // masks, no per-element dispatch on the epilogue kind.  Values are computed by the same expressions as below (a row's
+    // result does not depend on the path its tile took); the statistics use the same shifted single pass.
+    const bool fast_epi = !DUAL && q0 + BM <= Q && d.dst_acc == nullptr && d.glu_dump == nullptr && !two_sets &&
+                          (GLU ? true : d.epi == EAB_EPI_LINEAR);
+    if (fast_epi) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int qg = q0 + (wm * MI + mi) * 32 + 8 * r4 + 4 * lh;
+                const int t = cg_div(qg, d.No, inv_no);
+                int o = qg - t * d.No;
+                unsigned row_start = (unsigned)t * row_bytes + phase_bytes;
+                unsigned cur = row_start + (unsigned)o * step_bytes;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * r4 + j;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        float v;
+                        if (GLU) v = (acc[mi][0][r] + bias_v[0]) * cg_sigmoid(acc[mi][1][r] + bias_v[1]);
+                        else v = acc[mi][c][r] + bias_v[c];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_dst, cur + 4u * ch[c], 0, 0);
+                        acc[mi][c][r] = v;
+                    }
+                    cur += step_bytes;
+                    if (++o == d.No) {
+                        o = 0;
+                        row_start += row_bytes;
+                        cur = row_start;
+                    }
+                }
+            }
+        }
+        if (d.stats) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float a = st_slope[0][c];
+                const float k0 = eab_prelu(acc[0][c][0], a);
+                float su = 0.0f, sq = 0.0f;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float e = eab_prelu(acc[mi][c][r], a) - k0;
+                        su += e;
+                        sq = fmaf(e, e, sq);
+                    }
+                skk[0][c] = k0;
+                ssum[0][c] = su;
+                ssq[0][c] = sq;
+            }
+            scount = (float)(16 * MI);
+        }
+    } else
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         unsigned off[16];

@@ -125,8 +125,10 @@ extern "C" int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream
                 rc = eab_gather_f32(EAB_P(0), (const int32_t*)o.p[1], (const int32_t*)o.p[2], EAB_W(3), EAB_N64(0), stream);
                 break;
             case EAB_OP_IN_STATS:
-                rc = eab_train_in_stats_f32(EAB_P(0), EAB_P(1), o.i[0], o.i[1], o.i[2], o.f[0], EAB_P(2), EAB_P(3), EAB_W(4),
-                                            EAB_W(5), stream);
+                rc = o.p[6] ? eab_train_in1d_f32(EAB_P(0), EAB_P(1), o.i[0], o.i[1], o.i[2], o.f[0], EAB_P(2), EAB_P(3), EAB_W(4),
+                                                 EAB_W(5), EAB_W(6), stream)
+                            : eab_train_in_stats_f32(EAB_P(0), EAB_P(1), o.i[0], o.i[1], o.i[2], o.f[0], EAB_P(2), EAB_P(3),
+                                                     EAB_W(4), EAB_W(5), stream);
                 break;
             case EAB_OP_TR_NORM_ACT:
                 rc = eab_train_norm_act_f32(EAB_P(0), EAB_P(1), EAB_P(2), EAB_P(3), EAB_W(4), o.i[0], o.i[1], o.i[2], o.i[3],

@@ -49,13 +49,15 @@ extern "C" int eab_gather_f32(const float* flat, const int32_t* ia, const int32_
 //   xf[b][c] = (gamma*rstd, beta - mean*gamma*rstd),  mr[b][c] = (mean, rstd).
 // grid (B, C/64), block 256 = 64 channels x 4 position lanes.
 // ---------------------------------------------------------------------------------------------------
+template <bool APPLY>
 __global__ __launch_bounds__(TR_THREADS) void in_stats_kernel(const float* __restrict__ x, const float* __restrict__ slope,
                                                               int P, int C, float eps, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* __restrict__ xf,
-                                                              float* __restrict__ mr) {
+                                                              float* __restrict__ mr, float* __restrict__ y) {
     // thread -> 4 channels (float4) x every 16th position; shifted sums (shift = the channel's first value, so a
     // nearly constant channel loses nothing to cancellation) in fp64, combined through LDS in a fixed order
     __shared__ double red[2][16][64];
+    __shared__ float scsh[2][64];
     const int b = blockIdx.x, cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int c = blockIdx.y * 64 + cl * 4;
     double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
@@ -66,13 +68,25 @@ __global__ __launch_bounds__(TR_THREADS) void in_stats_kernel(const float* __res
         k = *reinterpret_cast<const f32x4*>(p);
 #pragma unroll
         for (int j = 0; j < 4; ++j) k[j] = eab_prelu(k[j], a[j]);
-        for (int i = pl; i < P; i += 16) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(p + (size_t)i * C);
+        // four rows in flight per thread: a workgroup owns its slab alone, so its own loads are all the memory-level
+        // parallelism there is (one row per iteration ran at one memory latency per 16 rows)
+        for (int i0 = pl; i0 < P; i0 += 64) {
+            f32x4 v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const double d = (double)(eab_prelu(v[j], a[j]) - k[j]);
-                s[j] += d;
-                q[j] += d * d;
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 16 * u;
+                v[u] = i < P ? *reinterpret_cast<const f32x4*>(p + (size_t)i * C) : k;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + 16 * u < P) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const double d = (double)(eab_prelu(v[u][j], a[j]) - k[j]);
+                        s[j] += d;
+                        q[j] += d * d;
+                    }
+                }
             }
         }
     }
@@ -100,6 +114,43 @@ __global__ __launch_bounds__(TR_THREADS) void in_stats_kernel(const float* __res
             const double scale = (double)gamma[cc] * rstd;
             *reinterpret_cast<float2*>(&xf[((size_t)b * C + cc) * 2]) = make_float2((float)scale, (float)((double)beta[cc] - mean * scale));
             *reinterpret_cast<float2*>(&mr[((size_t)b * C + cc) * 2]) = make_float2((float)mean, (float)rstd);
+            if (APPLY) {
+                scsh[0][threadIdx.x] = (float)scale;
+                scsh[1][threadIdx.x] = (float)((double)beta[cc] - mean * scale);
+            }
+        }
+    }
+    if (APPLY) {
+        // the whole 1-D unit in this launch: y = prelu(x) * scale + shift for the slab this workgroup just reduced (second
+        // pass from L2); the same expression and the same rounded (scale, shift) as tr_norm_act_kernel, EAB_XF_PRELU_NORM
+        __syncthreads();
+        if (c < C) {
+            float sc4[4], sh4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sc4[j] = scsh[0][cl * 4 + j];
+                sh4[j] = scsh[1][cl * 4 + j];
+            }
+            const float* p = x + (size_t)b * P * C + c;
+            float* yp = y + (size_t)b * P * C + c;
+            for (int i0 = pl; i0 < P; i0 += 64) {
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + 16 * u;
+                    v[u] = i < P ? *reinterpret_cast<const f32x4*>(p + (size_t)i * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + 16 * u;
+                    if (i < P) {
+                        f32x4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = fmaf(eab_prelu(v[u][j], a[j]), sc4[j], sh4[j]);
+                        *reinterpret_cast<f32x4*>(yp + (size_t)i * C) = o;
+                    }
+                }
+            }
         }
     }
 }
@@ -107,8 +158,18 @@ __global__ __launch_bounds__(TR_THREADS) void in_stats_kernel(const float* __res
 extern "C" int eab_train_in_stats_f32(const float* x, const float* slope, int B, int P, int C, float eps, const float* gamma,
                                       const float* beta, float* xf, float* mr, eab_stream_t stream) {
     EAB_CHECK_ARG(x && gamma && beta && xf && mr && B > 0 && P > 0 && C > 0 && (C % 4) == 0 && B <= 65535);
-    hipLaunchKernelGGL(in_stats_kernel, dim3(B, (C + 63) / 64), dim3(TR_THREADS), 0, eab_stream(stream), x, slope, P, C, eps,
-                       gamma, beta, xf, mr);
+    hipLaunchKernelGGL(in_stats_kernel<false>, dim3(B, (C + 63) / 64), dim3(TR_THREADS), 0, eab_stream(stream), x, slope, P, C, eps,
+                       gamma, beta, xf, mr, nullptr);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
+// The whole 1-D unit y = InstanceNorm1d(prelu(x)) of an S-TCM (EaBNet.py:545-547) in one launch: statistics, (xf, mr) for the
+// backward pass, and the normalised output.  One workgroup per (b, 64 channels) walks its P positions twice.
+extern "C" int eab_train_in1d_f32(const float* x, const float* slope, int B, int P, int C, float eps, const float* gamma,
+                                  const float* beta, float* xf, float* mr, float* y, eab_stream_t stream) {
+    EAB_CHECK_ARG(x && slope && gamma && beta && xf && mr && y && B > 0 && P > 0 && C > 0 && (C % 4) == 0 && B <= 65535);
+    hipLaunchKernelGGL(in_stats_kernel<true>, dim3(B, (C + 63) / 64), dim3(TR_THREADS), 0, eab_stream(stream), x, slope, P, C, eps,
+                       gamma, beta, xf, mr, y);
     EAB_RETURN_LAUNCH_STATUS();
 }
 
@@ -229,11 +290,24 @@ __global__ __launch_bounds__(TR_THREADS) void norm_bwd_apply_kernel(const float*
                                                                     const float* __restrict__ mr, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, const float* __restrict__ slope,
                                                                     float* __restrict__ sums, const float* __restrict__ acc_in,
-                                                                    float* __restrict__ dx, int P, int C, int mode, int chunk) {
+                                                                    float* __restrict__ dx, float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta, float* __restrict__ dslope, int P, int C,
+                                                                    int mode, int chunk) {
     __shared__ f32x4 red[NB_ROWS][16];
     const int b = blockIdx.z, cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int c = blockIdx.y * 64 + cl * 4;
     f32x4 S = {0.f, 0.f, 0.f, 0.f};
+    if (dgamma && blockIdx.x == 0 && pl == 0 && c < C) {
+        // the sums A, Q (and S for NORM_PRELU) of (b, c) are final after the reduce pass -> the parameter gradients ride
+        // along here (one workgroup per (b, channel group); B atomics per address)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&sums[((size_t)b * C + c + j) * 4]);
+            atomicAdd(&dbeta[c + j], v[0]);
+            atomicAdd(&dgamma[c + j], v[1]);
+            if (mode == EAB_XF_NORM_PRELU) atomicAdd(&dslope[c + j], v[2]);
+        }
+    }
     if (c < C) {
         const float* mp = &mr[((size_t)b * C + c) * 2];
         const f32x4 m01 = *reinterpret_cast<const f32x4*>(mp), m23 = *reinterpret_cast<const f32x4*>(mp + 4);
@@ -278,8 +352,10 @@ __global__ __launch_bounds__(TR_THREADS) void norm_bwd_apply_kernel(const float*
             f32x4 t = red[0][cl];
 #pragma unroll
             for (int kk = 1; kk < NB_ROWS; ++kk) t += red[kk][cl];
+            // PRELU_NORM: the slope sum only exists after this pass.  merged (dgamma != NULL): straight into dslope (the host
+            // picks that when a slope address sees few workgroups), else into sums for the params kernel
 #pragma unroll
-            for (int j = 0; j < 4; ++j) atomicAdd(&sums[((size_t)b * C + c + j) * 4 + 2], t[j]);
+            for (int j = 0; j < 4; ++j) atomicAdd(dgamma ? &dslope[c + j] : &sums[((size_t)b * C + c + j) * 4 + 2], t[j]);
         }
     }
 }
@@ -314,16 +390,22 @@ extern "C" int eab_train_norm_bwd_f32(const float* dy, const float* x, const flo
                                       const float* slope, float* sums, const float* acc_in, float* dx, float* dgamma,
                                       float* dbeta, float* dslope, int B, int P, int C, int mode, eab_stream_t stream) {
     EAB_CHECK_ARG(dy && x && mr && gamma && beta && slope && sums && dx && dgamma && dbeta && dslope);
+    const bool zeroed = (mode & EAB_NB_SUMS_ZEROED) != 0;          // the caller guarantees sums == 0 on entry
+    mode &= ~EAB_NB_SUMS_ZEROED;
     EAB_CHECK_ARG(B > 0 && P > 0 && C > 0 && (C % 4) == 0 && B <= 65535 && (mode == EAB_XF_NORM_PRELU || mode == EAB_XF_PRELU_NORM));
+    hipStream_t s = eab_stream(stream);
     const int chunk = nb_chunk(P, B, C);
     dim3 grid((P + chunk - 1) / chunk, (C + 63) / 64, B);
-    hipStream_t s = eab_stream(stream);
     // (a kernel, not hipMemsetAsync: memset nodes of a captured graph were not reliably ordered on this stack)
-    hipLaunchKernelGGL(tr_zero_kernel, dim3((B * C + TR_THREADS - 1) / TR_THREADS), dim3(TR_THREADS), 0, s, sums, (long long)B * C);
+    if (!zeroed)
+        hipLaunchKernelGGL(tr_zero_kernel, dim3((B * C + TR_THREADS - 1) / TR_THREADS), dim3(TR_THREADS), 0, s, sums, (long long)B * C);
     hipLaunchKernelGGL(norm_bwd_reduce_kernel, grid, dim3(TR_THREADS), 0, s, dy, x, mr, gamma, beta, slope, sums, P, C, mode, chunk);
-    hipLaunchKernelGGL(norm_bwd_apply_kernel, grid, dim3(TR_THREADS), 0, s, dy, x, mr, gamma, beta, slope, sums, acc_in, dx, P, C,
-                       mode, chunk);
-    hipLaunchKernelGGL(norm_bwd_params_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, B, C, dgamma, dbeta, dslope);
+    // parameter gradients inside the apply pass: always for NORM_PRELU (all three sums are final after the reduce pass); for
+    // PRELU_NORM when its slope sums can go straight into dslope (<= 256 workgroups per address: the S-TCN's slabs)
+    const bool merged = mode == EAB_XF_NORM_PRELU || (long long)grid.x * B <= 256;
+    hipLaunchKernelGGL(norm_bwd_apply_kernel, grid, dim3(TR_THREADS), 0, s, dy, x, mr, gamma, beta, slope, sums, acc_in, dx,
+                       merged ? dgamma : nullptr, dbeta, dslope, P, C, mode, chunk);
+    if (!merged) hipLaunchKernelGGL(norm_bwd_params_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, B, C, dgamma, dbeta, dslope);
     EAB_RETURN_LAUNCH_STATUS();
 }
 

@@ -42,6 +42,7 @@ from .spec import NetConfig, param_specs
 XF_NORM_PRELU, XF_PRELU_NORM = prg.XF_NORM_PRELU, prg.XF_PRELU_NORM
 (OP_GATHER, OP_IN_STATS, OP_TR_NORM_ACT, OP_NORM_BWD, OP_GLU_BWD, OP_GATE_FWD, OP_GATE_BWD, OP_ADD, OP_RELU_BWD, OP_COLSUM,
  OP_FILTER_SUM, OP_FS_BWD, OP_LN_FWD, OP_LN_BWD, OP_LSTM_TRAIN, OP_LSTM_BWD, OP_WGRAD) = range(16, 33)
+NB_SUMS_ZEROED = 0x100   # include/eabnet_hip.h EAB_NB_SUMS_ZEROED
 MLP_LD = 64          # the second Linear of w_dnn is run with its 2M rows padded to one 64-column tile
 
 
@@ -287,17 +288,24 @@ class TrainLowering:
         self.fwd.append(GenOp(OP_TR_NORM_ACT, [raw.ref, xf, slp, add.ref if add else None, out.ref], [self.B, P, raw.C, mode],
                               name=name))
 
+        self.tape.append(self._norm_back(name, raw, out, add, norm, act, mode, mr, gam, bet, slp, P))
+        return out
+
+    def _norm_back(self, name, raw: TVar, out: TVar, add: Optional[TVar], norm: str, act: str, mode: int, mr: Ref, gam: Ref,
+                   bet: Ref, slp: Ref, P: int) -> Callable[[], None]:
         def back():
             d = self.grad_of(out)
             if add is not None:
                 self.contribute(add, d)
             dst, aux = self.grad_target(raw)
-            sums = self.alloc(self.B * raw.C * 4)
+            # reduction scratch in the gradient arena: that arena is zero-filled once before every backward run, so the
+            # kernel needs no zero-fill launch of its own (EAB_NB_SUMS_ZEROED)
+            sums = Ref("g", self.g_size)
+            self.g_size += self.B * raw.C * 4 + ((-self.B * raw.C * 4) % ALIGN)
             self.bwd.append(GenOp(OP_NORM_BWD, [d, raw.ref, mr, gam, bet, slp, sums, aux, dst, self.gvec(f"{norm}.norm.weight"),
                                                 self.gvec(f"{norm}.norm.bias"), self.gvec(f"{act}.weight")],
-                                  [self.B, P, raw.C, mode], name=name + ".bwd"))
-        self.tape.append(back)
-        return out
+                                  [self.B, P, raw.C, mode | NB_SUMS_ZEROED], name=name + ".bwd"))
+        return back
 
     def finalize(self, name: str, stats: Ref, C: int, tiles: int, count: int, norm: str) -> Tuple[Ref, Ref]:
         xf, mr = self.alloc(self.B * C * 2), self.alloc(self.B * C * 2)
@@ -452,12 +460,15 @@ class TrainLowering:
         return out, back
 
     def in1d(self, name: str, raw: TVar, norm: str, act: str) -> TVar:
-        """prelu -> InstanceNorm1d (S-TCM order, EaBNet.py:545-547): statistics by a stand-alone kernel"""
+        """prelu -> InstanceNorm1d (S-TCM order, EaBNet.py:545-547) as ONE launch: statistics, (xf, mr) and the normalised
+        tensor (eab_train_in1d_f32); backward = the norm backward of the PRELU_NORM form"""
         xf, mr = self.alloc(self.B * raw.C * 2), self.alloc(self.B * raw.C * 2)
-        self.fwd.append(GenOp(OP_IN_STATS, [raw.ref, self.vec(f"{act}.weight"), self.vec(f"{norm}.norm.weight"),
-                                            self.vec(f"{norm}.norm.bias"), xf, mr], [self.B, self.T * raw.F, raw.C], [EPS_IN],
-                              name=name + ".stats"))
-        return self.norm_act(name, raw, norm, act, XF_PRELU_NORM, xf, mr)
+        out = self.act(raw.F, raw.C)
+        P = self.T * raw.F
+        gam, bet, slp = self.vec(f"{norm}.norm.weight"), self.vec(f"{norm}.norm.bias"), self.vec(f"{act}.weight")
+        self.fwd.append(GenOp(OP_IN_STATS, [raw.ref, slp, gam, bet, xf, mr, out.ref], [self.B, P, raw.C], [EPS_IN], name=name))
+        self.tape.append(self._norm_back(name, raw, out, None, norm, act, XF_PRELU_NORM, mr, gam, bet, slp, P))
+        return out
 
     def tcm(self, pre: str, x: TVar, dilation: int, x_acc: Optional[Ref], perm: np.ndarray) -> TVar:
         """SqueezedTCM.forward, EaBNet.py:572-578.  The closures go on the tape in forward order (they bind their

@@ -420,6 +420,10 @@ int eab_gather_f32(const float* flat, const int32_t* ia, const int32_t* ib, floa
  * EaBNet.py:545-547,559-560): xf[b][c] = (gamma*rstd, beta - mean*gamma*rstd), mr[b][c] = (mean, rstd). */
 int eab_train_in_stats_f32(const float* x, const float* slope, int B, int P, int C, float eps, const float* gamma,
                            const float* beta, float* xf, float* mr, eab_stream_t stream);
+/* The whole 1-D unit of an S-TCM in one launch: the statistics above (slope required) AND y = prelu(x)*scale + shift,
+ * y [B][P][C] (EaBNet.py:545-547: nn.PReLU -> NormSwitch 1-D).  One workgroup per (b, 64 channels), two passes. */
+int eab_train_in1d_f32(const float* x, const float* slope, int B, int P, int C, float eps, const float* gamma,
+                       const float* beta, float* xf, float* mr, float* y, eab_stream_t stream);
 /* eab_in_finalize_f32 that also emits mr0 / mr1 [B][C][2] = (mean, rstd) for the backward pass (NULL = skip) */
 int eab_in_finalize_mr_f32(const float* stats, int B, int C, int nsets, int stat_tiles, int count, float eps,
                            const float* gamma0, const float* beta0, float* xf0, const float* gamma1,
@@ -430,7 +434,9 @@ int eab_train_norm_act_f32(const float* x, const float* xf, const float* slope, 
                            int C, int mode, eab_stream_t stream);
 /* Backward of y = f(x) through the InstanceNorm statistics (per (b, c) over P) and the PReLU:
  *   dx = (acc_in ? acc_in : 0) + d loss / d x;   dgamma[c], dbeta[c], dslope[c] += their gradients.
- * sums: scratch [B][C][4].  Reference: autograd of EaBNet.py:684-686 + nn.PReLU. */
+ * sums: scratch [B][C][4]; OR-ing EAB_NB_SUMS_ZEROED into `mode` promises it is zero on entry (saves the zero-fill launch).
+ * Two launches (reduce, apply; the parameter gradients ride in the apply pass).  Reference: autograd of EaBNet.py:684-686 + nn.PReLU. */
+#define EAB_NB_SUMS_ZEROED 0x100
 int eab_train_norm_bwd_f32(const float* dy, const float* x, const float* mr, const float* gamma, const float* beta,
                            const float* slope, float* sums, const float* acc_in, float* dx, float* dgamma, float* dbeta,
                            float* dslope, int B, int P, int C, int mode, eab_stream_t stream);
@@ -474,7 +480,7 @@ int eab_wgrad_f32(const eab_wgrad_desc* d, eab_stream_t stream);
 
 /* op kinds of the training programs (eab_run_program); field use:
  *  GATHER       p = {flat, ia, ib, out}                 i = {n_lo, n_hi}
- *  IN_STATS     p = {x, slope, gamma, beta, xf, mr}     i = {B, P, C}          f = {eps}
+ *  IN_STATS     p = {x, slope, gamma, beta, xf, mr, y}  i = {B, P, C}          f = {eps}     (y != NULL: eab_train_in1d_f32)
  *  IN_FINALIZE  as before, plus p[7], p[8] = mr0, mr1
  *  TR_NORM_ACT  p = {x, xf, slope, add, y}              i = {B, P, C, mode}
  *  NORM_BWD     p = {dy, x, mr, gamma, beta, slope, sums, acc_in, dx, dgamma, dbeta, dslope}   i = {B, P, C, mode}

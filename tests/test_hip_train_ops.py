@@ -99,7 +99,7 @@ def test_wgrad_of_a_transposed_convolution_two_sources(lib, N, C0, C1, kt, kf, B
 
 
 @pytest.mark.parametrize("mode", [1, 2])
-@pytest.mark.parametrize("B,P,Cc", [(2, 57, 64), (3, 1300, 64), (1, 31, 256)])
+@pytest.mark.parametrize("B,P,Cc", [(2, 57, 64), (3, 1300, 64), (1, 31, 256), (2, 5409, 64), (2, 2561, 128)])   # <= 2560: one launch
 def test_instance_norm_prelu_forward_and_backward(lib, mode, B, P, Cc):
     """y = prelu(IN(x)) (2-D units) and y = IN(prelu(x)) (S-TCM): statistics kernel, apply kernel and the backward
     (dx, dgamma, dbeta, dslope, with and without an accumulate operand) against autograd."""
@@ -122,14 +122,23 @@ def test_instance_norm_prelu_forward_and_backward(lib, mode, B, P, Cc):
     yd = torch.empty_like(xd)
     _ck(lib.eab_train_norm_act_f32(xd.data_ptr(), xf.data_ptr(), sd.data_ptr(), None, yd.data_ptr(), B, P, Cc, mode, _st()))
     assert_close(yd.cpu().numpy(), y.detach().permute(0, 2, 1).numpy(), TOL, "forward")
-    sums = torch.empty(B, Cc, 4, device="cuda:0")
+    if mode == 2:       # the S-TCM unit as one launch: same statistics, bit-identical output
+        xf1, mr1, y1 = torch.empty_like(xf), torch.empty_like(mr), torch.empty_like(xd)
+        _ck(lib.eab_train_in1d_f32(xd.data_ptr(), sd.data_ptr(), B, P, Cc, 1e-5, gd.data_ptr(), bd.data_ptr(), xf1.data_ptr(),
+                                   mr1.data_ptr(), y1.data_ptr(), _st()))
+        assert torch.equal(xf1, xf) and torch.equal(mr1, mr) and torch.equal(y1, yd)
+    sums = torch.full((B, Cc, 4), 7.0, device="cuda:0")
     acc = torch.randn(B, P, Cc, device="cuda:0")
     for acc_in in (None, acc):
         dx = torch.empty_like(xd)
         dg, db, ds = (torch.zeros(Cc, device="cuda:0") for _ in range(3))
+        flag = 0
+        if acc_in is not None:              # second round: the caller zero-fills the scratch itself (EAB_NB_SUMS_ZEROED)
+            sums.zero_()
+            flag = 0x100
         _ck(lib.eab_train_norm_bwd_f32(dyd.data_ptr(), xd.data_ptr(), mr.data_ptr(), gd.data_ptr(), bd.data_ptr(), sd.data_ptr(),
                                        sums.data_ptr(), acc_in.data_ptr() if acc_in is not None else None, dx.data_ptr(), dg.data_ptr(),
-                                       db.data_ptr(), ds.data_ptr(), B, P, Cc, mode, _st()))
+                                       db.data_ptr(), ds.data_ptr(), B, P, Cc, mode | flag, _st()))
         want_dx = x.grad + (acc_in.cpu().double() if acc_in is not None else 0.0)
         assert_close(dx.cpu().numpy(), want_dx.numpy(), TOL, "dx")
         assert_close(dg.cpu().numpy(), gam.grad.numpy(), TOL, "dgamma")
