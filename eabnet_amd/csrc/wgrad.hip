@@ -100,6 +100,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const eab_wgrad_desc 
 #pragma unroll
     for (int p = 0; p < AP; ++p) bsum[p] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool do_bias = d.dbias != nullptr && blockIdx.y == 0;
+    const bool vec_ok = (d.C0 & 3) == 0;                           // (two sources require C0 % 16 == 0 and C1 % 4 == 0)
     auto fetch = [&](long long r0) {
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
@@ -115,8 +116,16 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const eab_wgrad_desc 
         for (int j = 0; j < BP; ++j) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             const int tt = rb_.t + tdt[j], fi = rb_.o * d.istride + tio[j];
-            if (rok && b_ok[j] && tt >= 0 && tt < d.T && fi >= 0 && fi < d.Fin)
-                v = *reinterpret_cast<const f32x4*>(&b_src[j][(((size_t)rb_.b * d.T + tt) * d.Fin + fi) * b_Cs[j] + b_cc[j]]);
+            if (rok && b_ok[j] && tt >= 0 && tt < d.T && fi >= 0 && fi < d.Fin) {
+                const float* sp = &b_src[j][(((size_t)rb_.b * d.T + tt) * d.Fin + fi) * b_Cs[j] + b_cc[j]];
+                if (vec_ok) {
+                    v = *reinterpret_cast<const f32x4*>(sp);
+                } else {            // channel count not a multiple of 4 (2M = 18 network inputs): element loads, row tail guarded
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (b_cc[j] + e < b_Cs[j]) v[e] = sp[e];
+                }
+            }
             rb[j] = v;
         }
         rb_.advance(WG_ROWS, d.T, d.No);
@@ -203,7 +212,7 @@ extern "C" int eab_wgrad_f32(const eab_wgrad_desc* d, eab_stream_t stream) {
     EAB_CHECK_ARG(d && d->dz && d->src0 && d->dw);
     EAB_CHECK_ARG(d->B > 0 && d->T > 0 && d->Fin > 0 && d->Fz > 0 && d->No > 0 && d->N > 0 && (d->N % 64) == 0);
     EAB_CHECK_ARG(d->C0 > 0 && d->C1 >= 0 && (d->C1 == 0) == (d->src1 == nullptr));
-    EAB_CHECK_ARG((d->C0 % 4) == 0 && (d->C1 % 4) == 0 && (d->C1 == 0 || (d->C0 % 16) == 0));
+    EAB_CHECK_ARG((d->C1 % 4) == 0 && (d->C1 == 0 || (d->C0 % 16) == 0));      // a single source may have any channel count
     EAB_CHECK_ARG(d->ntaps > 0 && d->ntaps <= EAB_MAX_TAPS && d->ostride >= 1 && d->istride >= 1);
     EAB_CHECK_ARG(d->ophase >= 0 && d->ophase < d->ostride && (d->No - 1) * d->ostride + d->ophase < d->Fz);
     const int upt = (d->C0 + d->C1 + 15) / 16;

@@ -48,7 +48,7 @@ MLP_LD = 64          # the second Linear of w_dnn is run with its 2M rows padded
 
 def supported(cfg: NetConfig) -> bool:
     return (cfg.is_u2 and cfg.bf_type == "lstm" and cfg.topo_type == "mimo" and cfg.intra_connect == "cat"
-            and cfg.norm_type == "IN" and (2 * cfg.M) % 4 == 0 and 2 * cfg.M <= MLP_LD)
+            and cfg.norm_type == "IN" and 2 * cfg.M <= MLP_LD)
 
 
 @dataclass

@@ -1113,7 +1113,7 @@ def _grad_errors(got: dict, ref: dict):
 
 
 @pytest.mark.parametrize("M,B,T,pq,smooth", [(4, 2, 30, (2, 2), True), (8, 1, 70, (6, 3), True), (4, 2, 30, (2, 2), False),
-                                             (8, 1, 70, (6, 3), False)])
+                                             (8, 1, 70, (6, 3), False), (9, 2, 24, (2, 2), True)])      # M = 9: the reference's default
 def test_hip_training_gradients_vs_oracle_autograd(dev, M, B, T, pq, smooth):
     """net(x) under autograd runs the two HIP training programs (eabnet_amd/train.py): the forward equals the
     inference program's output, and loss.backward() gives every parameter the gradient fp64 autograd through the
