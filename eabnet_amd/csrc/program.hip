@@ -175,9 +175,15 @@ extern "C" int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream
             case EAB_OP_LSTM_BWD:
                 rc = eab_lstm64_bwd_f32(EAB_P(0), EAB_P(1), EAB_P(2), EAB_W(3), o.i[0], o.i[1], o.i[2], stream);
                 break;
-            case EAB_OP_WGRAD:
-                rc = eab_wgrad_f32(&o.wgrad, stream);
+            case EAB_OP_WGRAD: {
+                // consecutive weight gradients of identical geometry share one launch (the lowering sorts them so)
+                int run = 1;
+                while (k + run < n_ops && ops[k + run].kind == EAB_OP_WGRAD) ++run;
+                const int nb = eab_wgrad_batchable(&o.wgrad, run, (int)sizeof(eab_op));
+                rc = eab_wgrad_batch_f32(&o.wgrad, nb, (int)sizeof(eab_op), stream);
+                k += nb - 1;
                 break;
+            }
             case EAB_OP_CLN_STATS:
                 rc = eab_cln_stats_f32(EAB_P(0), EAB_P(1), o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], (double*)const_cast<void*>(o.p[2]),
                                        (double*)const_cast<void*>(o.p[3]), EAB_W(4), o.win, stream);

@@ -47,9 +47,31 @@ struct WgRow {
     }
 };
 
+// One launch serves up to WG_MAXB weight gradients of IDENTICAL geometry (the 18 S-TCMs' in/left/right/out convolutions, the
+// repeated U-Net levels): the shared descriptor plus per-member pointers travel in the kernel arguments, blockIdx.x =
+// member * groups + row group.
+#define WG_MAXB 24
+struct WgBatch {
+    eab_wgrad_desc d;
+    int n, groups;
+    const float* dz[WG_MAXB];
+    const float* src0[WG_MAXB];
+    const float* src1[WG_MAXB];
+    float* dw[WG_MAXB];
+    float* dbias[WG_MAXB];
+};
+
 template <int TN, int TC>
-__global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const eab_wgrad_desc d) {
+__global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgBatch bt) {
     using Smem = WgSmem<TN, TC>;
+    const eab_wgrad_desc& d = bt.d;
+    const int member = bt.n > 1 ? (int)(blockIdx.x / (unsigned)bt.groups) : 0;
+    const int row_group = (int)blockIdx.x - member * bt.groups;
+    const float* const m_dz = bt.dz[member];
+    const float* const m_src0 = bt.src0[member];
+    const float* const m_src1 = bt.src1[member];
+    float* const m_dw = bt.dw[member];
+    float* const m_dbias = bt.dbias[member];
     constexpr int LDA = Smem::LDA, LDB = Smem::LDB, MI = TN / 64, NJ = TC / 64;
     constexpr int AP = TN / 64;                                  // float4 loads of dz per thread per stage
     constexpr int BP = TC / 64;                                  // float4 loads of x per thread per stage
@@ -58,7 +80,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const eab_wgrad_desc 
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
 
     const long long R = (long long)d.T * d.No * d.B;
-    const long long r_begin = (long long)blockIdx.x * d.rows_per_wg;
+    const long long r_begin = (long long)row_group * d.rows_per_wg;
     const long long r_end = r_begin + d.rows_per_wg < R ? r_begin + d.rows_per_wg : R;
     const int col0 = blockIdx.y * TC, n0 = blockIdx.z * TN;
     const int Ctot = d.C0 + d.C1, UPT = (Ctot + 15) >> 4, NU = d.ntaps * UPT;
@@ -81,7 +103,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const eab_wgrad_desc 
         b_Cs[j] = second ? d.C1 : d.C0;
         b_cc[j] = (second ? c0 - d.C0 : c0) + b_q * 4;
         b_ok[j] = u_ok && b_cc[j] < b_Cs[j];
-        b_src[j] = second ? d.src1 : d.src0;
+        b_src[j] = second ? m_src1 : m_src0;
         tdt[j] = tio[j] = 0;
 #pragma unroll
         for (int k = 0; k < EAB_MAX_TAPS; ++k)
@@ -99,7 +121,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const eab_wgrad_desc 
     f32x4 bsum[AP];                                              // bias gradient: column sums of dz (column block 0 only)
 #pragma unroll
     for (int p = 0; p < AP; ++p) bsum[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = d.dbias != nullptr && blockIdx.y == 0;
+    const bool do_bias = m_dbias != nullptr && blockIdx.y == 0;
     const bool vec_ok = (d.C0 & 3) == 0;                           // (two sources require C0 % 16 == 0 and C1 % 4 == 0)
     auto fetch = [&](long long r0) {
 #pragma unroll
@@ -107,7 +129,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const eab_wgrad_desc 
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (r0 + a_row + 8 * p < r_end)
                 v = *reinterpret_cast<const f32x4*>(
-                    &d.dz[(((size_t)ra_[p].b * d.T + ra_[p].t) * d.Fz + (size_t)ra_[p].o * d.ostride + d.ophase) * d.N + n0 + a_c4 * 4]);
+                    &m_dz[(((size_t)ra_[p].b * d.T + ra_[p].t) * d.Fz + (size_t)ra_[p].o * d.ostride + d.ophase) * d.N + n0 + a_c4 * 4]);
             ra[p] = v;
             ra_[p].advance(WG_ROWS, d.T, d.No);
         }
@@ -188,11 +210,11 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const eab_wgrad_desc 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int n = n0 + wm * (TN / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    atomicAdd(&d.dw[(size_t)n * d.Kpad + col], acc[mi][nj][r]);
+                    atomicAdd(&m_dw[(size_t)n * d.Kpad + col], acc[mi][nj][r]);
                 }
         }
     }
-    if (d.dbias != nullptr && blockIdx.y == 0) {     // (workgroup-uniform)
+    if (m_dbias != nullptr && blockIdx.y == 0) {     // (workgroup-uniform)
         // the 16 row lanes of a column are summed through LDS first: ONE atomic per column and workgroup (per-thread
         // atomics on the same 128 addresses from every row group serialised in L2: 9 -> 34 ms per step when tried)
         __syncthreads();
@@ -203,13 +225,39 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const eab_wgrad_desc 
             float t = 0.0f;
 #pragma unroll
             for (int r = 0; r < WG_ROWS; ++r) t += sm.a[0][r * LDA + tid];
-            atomicAdd(&d.dbias[n0 + tid], t);
+            atomicAdd(&m_dbias[n0 + tid], t);
         }
     }
 }
 
-extern "C" int eab_wgrad_f32(const eab_wgrad_desc* d, eab_stream_t stream) {
-    EAB_CHECK_ARG(d && d->dz && d->src0 && d->dw);
+static bool wg_same_geometry(const eab_wgrad_desc* a, const eab_wgrad_desc* b) {
+    if (a->N != b->N || a->C0 != b->C0 || a->C1 != b->C1 || a->Kpad != b->Kpad || a->B != b->B || a->T != b->T || a->Fin != b->Fin ||
+        a->Fz != b->Fz || a->No != b->No || a->ostride != b->ostride || a->ophase != b->ophase || a->istride != b->istride ||
+        a->ntaps != b->ntaps || (a->src1 == nullptr) != (b->src1 == nullptr) || (a->dbias == nullptr) != (b->dbias == nullptr))
+        return false;
+    for (int k = 0; k < a->ntaps; ++k)
+        if (a->dt[k] != b->dt[k] || a->ioff[k] != b->ioff[k]) return false;
+    return true;
+}
+
+// How many of descs[0..n) (at most WG_MAXB) can share one launch with descs[0]
+extern "C" int eab_wgrad_batchable(const eab_wgrad_desc* descs, int n, int stride_bytes) {
+    if (!descs || n <= 0) return 0;
+    int k = 1;
+    while (k < n && k < WG_MAXB &&
+           wg_same_geometry(descs, reinterpret_cast<const eab_wgrad_desc*>(reinterpret_cast<const char*>(descs) + (size_t)k * stride_bytes)))
+        ++k;
+    return k;
+}
+
+extern "C" int eab_wgrad_batch_f32(const eab_wgrad_desc* descs, int n, int stride_bytes, eab_stream_t stream) {
+    EAB_CHECK_ARG(descs && n >= 1 && n <= WG_MAXB && stride_bytes >= (int)sizeof(eab_wgrad_desc));
+    const eab_wgrad_desc* d = descs;
+    auto at = [&](int k) { return reinterpret_cast<const eab_wgrad_desc*>(reinterpret_cast<const char*>(descs) + (size_t)k * stride_bytes); };
+    for (int k = 0; k < n; ++k) {
+        EAB_CHECK_ARG(at(k)->dz && at(k)->src0 && at(k)->dw);
+        EAB_CHECK_ARG(k == 0 || wg_same_geometry(d, at(k)));
+    }
     EAB_CHECK_ARG(d->B > 0 && d->T > 0 && d->Fin > 0 && d->Fz > 0 && d->No > 0 && d->N > 0 && (d->N % 64) == 0);
     EAB_CHECK_ARG(d->C0 > 0 && d->C1 >= 0 && (d->C1 == 0) == (d->src1 == nullptr));
     EAB_CHECK_ARG((d->C1 % 4) == 0 && (d->C1 == 0 || (d->C0 % 16) == 0));      // a single source may have any channel count
@@ -231,20 +279,37 @@ extern "C" int eab_wgrad_f32(const eab_wgrad_desc* d, eab_stream_t stream) {
     const double t_stage = (tn == 128 && tc == 128) ? 1.0e-6 : (tn == 128 || tc == 128) ? 0.7e-6 : 0.5e-6;
     const double per_group = (double)cb * nb * tn * tc / 1.2e11;
     long long groups = (long long)(sqrt((double)R * t_stage / 16.0 / per_group) + 0.5);
-    const long long g_max = (1024 + (long long)cb * nb - 1) / ((long long)cb * nb);
-    const long long g_min = (256 + (long long)cb * nb - 1) / ((long long)cb * nb);
+    const long long per_rg = (long long)cb * nb * n;              // workgroups per row group over the whole launch
+    const long long g_max = (1024 + per_rg - 1) / per_rg;
+    const long long g_min = (256 + per_rg - 1) / per_rg;
     if (groups > g_max) groups = g_max;
     if (groups < g_min) groups = g_min;
     long long rpw = (R + groups - 1) / groups;
     if (rpw < 64) rpw = 64;
     rpw = (rpw + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
-    eab_wgrad_desc dd = *d;
-    dd.rows_per_wg = (int)rpw;
-    dim3 grid((unsigned)((R + rpw - 1) / rpw), (unsigned)cb, (unsigned)nb);
+    WgBatch bt;
+    bt.d = *d;
+    bt.d.rows_per_wg = (int)rpw;
+    bt.n = n;
+    bt.groups = (int)((R + rpw - 1) / rpw);
+    for (int k = 0; k < WG_MAXB; ++k) {
+        const eab_wgrad_desc* m = at(k < n ? k : 0);
+        bt.dz[k] = m->dz;
+        bt.src0[k] = m->src0;
+        bt.src1[k] = m->src1;
+        bt.dw[k] = m->dw;
+        bt.dbias[k] = m->dbias;
+    }
+    EAB_CHECK_ARG((long long)bt.groups * n < (1ll << 31));
+    dim3 grid((unsigned)(bt.groups * n), (unsigned)cb, (unsigned)nb);
     hipStream_t s = eab_stream(stream);
-    if (tn == 128 && tc == 128) hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(WG_THREADS), 0, s, dd);
-    else if (tn == 128) hipLaunchKernelGGL((wgrad_kernel<128, 64>), grid, dim3(WG_THREADS), 0, s, dd);
-    else if (tc == 128) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(WG_THREADS), 0, s, dd);
-    else hipLaunchKernelGGL((wgrad_kernel<64, 64>), grid, dim3(WG_THREADS), 0, s, dd);
+    if (tn == 128 && tc == 128) hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(WG_THREADS), 0, s, bt);
+    else if (tn == 128) hipLaunchKernelGGL((wgrad_kernel<128, 64>), grid, dim3(WG_THREADS), 0, s, bt);
+    else if (tc == 128) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(WG_THREADS), 0, s, bt);
+    else hipLaunchKernelGGL((wgrad_kernel<64, 64>), grid, dim3(WG_THREADS), 0, s, bt);
     EAB_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int eab_wgrad_f32(const eab_wgrad_desc* d, eab_stream_t stream) {
+    return eab_wgrad_batch_f32(d, 1, (int)sizeof(eab_wgrad_desc), stream);
 }

@@ -138,6 +138,7 @@ class TrainLowering:
         self.fwd: list = []
         self.bwd: list = []
         self.tape: List[Callable[[], None]] = []
+        self.deferred: List[WgradOp] = []                                     # weight gradients, appended to bwd by finish()
         self.flops_fwd = 0
         self.flops_bwd = 0
         self.emit = self.fwd                                                  # the list ops are appended to
@@ -257,9 +258,14 @@ class TrainLowering:
         Ctot = s0.C + (s1.C if s1 else 0)
         Kpad = len(dt) * ((Ctot + 15) // 16) * 16
         assert tuple(gimg.shape) == (N, Kpad), (gimg.shape, N, Kpad)
-        self.bwd.append(WgradOp(dz=dz, src0=s0.ref, src1=s1.ref if s1 else None, dw=self.gadd([gimg]), N=N, C0=s0.C,
-                                C1=s1.C if s1 else 0, Kpad=Kpad, B=self.B, T=self.T, Fin=s0.F, Fz=Fz, No=No, ostride=ostride,
-                                ophase=ophase, istride=istride, dt=list(dt), ioff=list(ioff), name=name, dbias=dbias))
+        # Weight gradients are leaves of the backward graph (nothing reads dW before the step ends; their operands -- the
+        # finished gradient of a convolution output and a forward activation -- are never written again, no buffer is
+        # recycled), so they are all emitted at the END of the backward program, sorted by geometry: eab_run_program
+        # then serves every run of identical geometry (the 18 S-TCMs, the repeated U-Net levels) with one launch.
+        self.deferred.append(WgradOp(dz=dz, src0=s0.ref, src1=s1.ref if s1 else None, dw=self.gadd([gimg]), N=N, C0=s0.C,
+                                     C1=s1.C if s1 else 0, Kpad=Kpad, B=self.B, T=self.T, Fin=s0.F, Fz=Fz, No=No,
+                                     ostride=ostride, ophase=ophase, istride=istride, dt=list(dt), ioff=list(ioff), name=name,
+                                     dbias=dbias))
         self.flops_bwd += 2 * self.B * self.T * No * N * len(dt) * Ctot
 
     def colsum(self, name, x: Ref, rows: int, N: int, imgs: Sequence[np.ndarray]) -> None:
@@ -640,6 +646,14 @@ class TrainLowering:
                 tgt = fl[m]
                 assert (inv[tgt] == -1).all(), "a parameter element received two gradient entries"
                 inv[tgt] = off + np.nonzero(m)[0]
+        def geometry(o: WgradOp):
+            return (o.N, o.C0, o.C1, o.Kpad, o.Fin, o.Fz, o.No, o.ostride, o.ophase, o.istride, tuple(o.dt), tuple(o.ioff),
+                    o.src1 is None, o.dbias is None)
+        order: Dict[tuple, int] = {}
+        for o in self.deferred:
+            order.setdefault(geometry(o), len(order))
+        self.bwd.extend(sorted(self.deferred, key=lambda o: order[geometry(o)]))      # stable: first-seen geometry first
+        self.deferred = []
         return TrainProgram(cfg=self.cfg, B=self.B, T=self.T, F=self.F, fwd=self.fwd, bwd=self.bwd, a_floats=self.a_size,
                             w_floats=self.w_size, g_floats=self.g_size, ia=ia, ib=ib, inv=inv.astype(np.int32),
                             n_params=self.n_params, keys=list(self.specs), shapes=[tuple(s.shape) for s in self.specs.values()],
@@ -700,12 +714,20 @@ class TrainBound:
         # (TrainLowering never recycles a buffer) -- so every block of wgrad launches forks onto a side stream right after
         # its producer and joins at the end.  The dgrad / norm-backward chain of the small layers and the 161-workgroup LSTM
         # backward leave most of the chip idle; the wgrads fill it.  Captured into the hipGraph these are parallel branches.
-        self.wgrad_lanes = int(os.environ.get("EAB_WGRAD_LANES", "0"))     # measured: 30.5 (2 lanes) / 30.7 (1) / 30.2 ms (off) per step -- co-running kernels slow each other (a dgrad next to a wgrad: 239 -> 623 us), so off by default
+        # EAB_WGRAD_LANES: 0 = off, 1 / 2 = side streams for every wgrad block, "small" = only the launches of the small
+        # layers (at most `small_rows` output rows: the S-TCN's) -- the big ones only contend with their neighbours
+        # (measured: 30.5 (2 lanes) / 30.7 (1) / 30.2 ms (off) per step; a dgrad next to a big wgrad: 239 -> 623 us)
+        mode = os.environ.get("EAB_WGRAD_LANES", "0")
+        small_rows = 1 << 15
+        self.wgrad_lanes = 1 if mode == "small" else int(mode)
         self.segments = []                  # (lane, first op, count) of the backward program; lane 0 = the caller's stream
+
+        def side(op) -> bool:
+            return op.kind == OP_WGRAD and (mode != "small" or op.B * op.T * op.No <= small_rows)
         k, nb, blk = 0, len(prog.bwd), 0
         while k < nb:
-            j, is_w = k + 1, prog.bwd[k].kind == OP_WGRAD
-            while j < nb and (prog.bwd[j].kind == OP_WGRAD) == is_w:
+            j, is_w = k + 1, side(prog.bwd[k])
+            while j < nb and side(prog.bwd[j]) == is_w:
                 j += 1
             if is_w:
                 blk += 1

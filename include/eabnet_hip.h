@@ -477,6 +477,11 @@ int eab_lstm64_bwd_f32(const float* gates, const float* dh_out, const float* wca
  * Kpad = ntaps*UPT*16, UPT = ceil((C0+C1)/16).  Accumulates with atomics: the caller zeroes dw. */
 /* (eab_wgrad_desc is declared next to eab_op above) */
 int eab_wgrad_f32(const eab_wgrad_desc* d, eab_stream_t stream);
+/* Up to 24 weight gradients of IDENTICAL geometry (every field but the five pointers) in one launch: descs[k] is found
+ * `stride_bytes` after descs[k-1] (so the descriptors may sit inside an eab_op array).  eab_wgrad_batchable tells how many
+ * of descs[0..n) can join descs[0].  eab_run_program batches consecutive EAB_OP_WGRAD ops this way. */
+int eab_wgrad_batchable(const eab_wgrad_desc* descs, int n, int stride_bytes);
+int eab_wgrad_batch_f32(const eab_wgrad_desc* descs, int n, int stride_bytes, eab_stream_t stream);
 
 /* op kinds of the training programs (eab_run_program); field use:
  *  GATHER       p = {flat, ia, ib, out}                 i = {n_lo, n_hi}
