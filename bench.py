@@ -269,6 +269,7 @@ def main_train(a, rank, world, dev, is_dist):
                         else:
                             launches, run = launches + 1, 1
                         prev = geo(o)
+                    res[which]["ms_total"] += wg_ms - float(ms[wg].sum())
                     res[which]["ms_by_kernel"]["wgrad"] = round(wg_ms, 3)
                     res[which]["ms_by_kernel"]["wgrad (one launch per descriptor)"] = round(float(ms[wg].sum()), 3)
                     out["roofline"] = {"kernel": "wgrad_kernel (fp32 MFMA 32x32x2, split-K, atomics)", "bound": "mfma",

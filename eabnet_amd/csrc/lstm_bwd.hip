@@ -129,11 +129,105 @@ __global__ __launch_bounds__(256) void lstm64_bwd_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small-batch variant (up to 2048 sequences; the training batch of BASELINE configs[3] is 6 x 161 = 966): 4 sequences
+// per workgroup on v_mfma_f32_4x4x1_16b_f32, the reverse-time twin of lstm64_q_kernel.  The 16-sequence kernel above is a
+// latency chain (elementwise -> LDS -> barrier -> 64 dependent-chain MFMAs of 32 cycles) on 61 of 256 CUs at that size;
+// here a step is 64 MFMAs of ~10 cycles per wave and four times as many workgroups run side by side.
+//   element role: thread (s = tid/64, u = tid%64) owns hidden unit u of sequence s: dh, dc carry, the four gate gradients;
+//   matrix role : dh_rec[s][u'] = sum_k dgates[s][k] W_hh[k][u'], K = 256 split over the 4 waves (wave w: k in [64w, 64w+64));
+//                 lane = output unit u' (its W_hh column slice stationary in 64 VGPRs), A operand = the 4 sequences
+//                 (broadcast from LDS), accumulator VGPR r = sequence r; the four K-slices meet in LDS.
+// ---------------------------------------------------------------------------------------------------------------
+#define LBQ_LD (4 * LB_H + 4)
+
+__global__ __launch_bounds__(256) void lstm64_bwd_q_kernel(const float* __restrict__ gates, const float* __restrict__ dh_out,
+                                                           const float* __restrict__ wcat, float* __restrict__ dgates, int T, int F,
+                                                           int S) {
+    __shared__ __attribute__((aligned(16))) float dg[2][4 * LBQ_LD];
+    __shared__ __attribute__((aligned(16))) float part[4][4][LB_H];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int es = tid >> 6, eu = tid & 63;                       // element role (es happens to equal the wave index)
+    const int sq = blockIdx.x * 4 + es;
+    const bool ok = sq < S;
+    const int b = ok ? sq / F : 0, f = ok ? sq - b * F : 0;
+    const size_t goff = ((size_t)(ok ? sq : 0) * T * 5) * LB_H + eu;
+    const size_t hoff = (((size_t)b * T) * F + f) * LB_H + eu;
+    const size_t g_t = (size_t)5 * LB_H, h_t = (size_t)F * LB_H;
+    const size_t dg_base = (((size_t)b * T) * F + f) * (4 * LB_H) + (size_t)eu * 4;      // writer: float4 eu of row es
+    const size_t dg_t = (size_t)F * 4 * LB_H;
+
+    float wh[64];                                                  // W_hh[64*wave + kk][lane]
+#pragma unroll
+    for (int kk = 0; kk < 64; ++kk) wh[kk] = wcat[(size_t)(64 * wave + kk) * 128 + 64 + lane];
+
+    float dhr = 0.f, dcc = 0.f;
+    float gi, gf, gg, go, ct, cp, du;
+    auto load = [&](int t, float& i_, float& f_, float& g_, float& o_, float& c_, float& p_, float& d_) {
+        const bool v = ok && t >= 0;
+        const float* gp = gates + goff + (size_t)(t >= 0 ? t : 0) * g_t;
+        i_ = v ? gp[0] : 0.f;
+        f_ = v ? gp[LB_H] : 0.f;
+        g_ = v ? gp[2 * LB_H] : 0.f;
+        o_ = v ? gp[3 * LB_H] : 0.f;
+        c_ = v ? gp[4 * LB_H] : 0.f;
+        p_ = (v && t > 0) ? *(gp - LB_H) : 0.f;                     // c_{t-1}
+        d_ = v ? dh_out[hoff + (size_t)(t >= 0 ? t : 0) * h_t] : 0.f;
+    };
+    load(T - 1, gi, gf, gg, go, ct, cp, du);
+
+    for (int t = T - 1; t >= 0; --t) {
+        const int buf = t & 1;
+        float ni, nf, ng, no, nc, np, nd;
+        load(t - 1, ni, nf, ng, no, nc, np, nd);
+        {   // same expressions as the 16-sequence kernel
+            const float dh = du + dhr;
+            const float tc = lb_tanh(ct);
+            const float d_o = dh * tc * go * (1.0f - go);
+            const float dc = dcc + dh * go * (1.0f - tc * tc);
+            const float d_i = dc * gg * gi * (1.0f - gi);
+            const float d_g = dc * gi * (1.0f - gg * gg);
+            const float d_f = dc * cp * gf * (1.0f - gf);
+            dcc = dc * gf;
+            float* row = &dg[buf][es * LBQ_LD + eu];
+            row[0] = d_i;
+            row[LB_H] = d_f;
+            row[2 * LB_H] = d_g;
+            row[3 * LB_H] = d_o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        f32x4 acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* arow = &dg[buf][(lane & 3) * LBQ_LD + 64 * wave];
+#pragma unroll
+        for (int k4 = 0; k4 < 16; ++k4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 4 * k4);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                acc[(4 * k4 + kk) & 7] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[kk], wh[4 * k4 + kk], acc[(4 * k4 + kk) & 7], 0, 0, 0);
+        }
+        const f32x4 p = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave][r][lane] = p[r];
+        if (ok)     // coalesced write-back of the dgates rows: 1 KB per sequence
+            *reinterpret_cast<f32x4*>(dgates + dg_base + (size_t)t * dg_t) = *reinterpret_cast<const f32x4*>(&dg[buf][es * LBQ_LD + eu * 4]);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        dhr = (part[0][es][eu] + part[1][es][eu]) + (part[2][es][eu] + part[3][es][eu]);
+        gi = ni; gf = nf; gg = ng; go = no; ct = nc; cp = np; du = nd;
+    }
+}
+
 extern "C" int eab_lstm64_bwd_f32(const float* gates, const float* dh_out, const float* wcat, float* dgates, int B, int T, int F,
                                   eab_stream_t stream) {
     EAB_CHECK_ARG(gates && dh_out && wcat && dgates && B > 0 && T > 0 && F > 0);
     const long long S = (long long)B * F;
     EAB_CHECK_ARG(S * T * 5 * LB_H < (1ll << 40));
+    if (S <= 2048) {
+        hipLaunchKernelGGL(lstm64_bwd_q_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, eab_stream(stream), gates, dh_out, wcat,
+                           dgates, T, F, (int)S);
+        EAB_RETURN_LAUNCH_STATUS();
+    }
     const int grid = (int)((S + LB_SEQ - 1) / LB_SEQ);
     hipLaunchKernelGGL(lstm64_bwd_kernel, dim3(grid), dim3(256), 0, eab_stream(stream), gates, dh_out, wcat, dgates, T, F, (int)S);
     EAB_RETURN_LAUNCH_STATUS();

@@ -92,10 +92,15 @@ __global__ __launch_bounds__(STFT_THREADS) void stft_dft_kernel(
     }
 }
 
+// NFFT_CT / HOP_CT != 0: the reference's front end (fft_num 320, hop 160) with every size a compile-time constant -- the
+// same passes and the same arithmetic as the run-time plan (bit-identical results), but the index divisions fold into
+// multiplies and shifts
+template <int NFFT_CT, int HOP_CT>
 __global__ __launch_bounds__(STFT_THREADS) void stft_fft_kernel(
     const float* __restrict__ wav, const float* __restrict__ window, const float* __restrict__ twiddle,
-    float* __restrict__ out, int M, int L, int n_fft, int hop, int T, int layout, FftPlan plan) {
+    float* __restrict__ out, int M, int L, int n_fft_rt, int hop_rt, int T, int layout, FftPlan plan) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n_fft = NFFT_CT ? NFFT_CT : n_fft_rt, hop = HOP_CT ? HOP_CT : hop_rt;
     const int NH = n_fft / 2, F = NH + 1;
     float2* tw = reinterpret_cast<float2*>(smem);                         // [n_fft]  exp(-2 pi i j / n_fft)
     float2* buf0 = tw + n_fft;                                            // [FFT_SIGS][NH]
@@ -117,7 +122,20 @@ __global__ __launch_bounds__(STFT_THREADS) void stft_fft_kernel(
             reinterpret_cast<float*>(buf0)[mm * n_fft + n] = v;           // float index 2*(n/2) + (n&1) = n
         }
         __syncthreads();
-        const float2* src = fft_run(buf0, buf1, tw, NH, n_fft, plan, tid, STFT_THREADS);
+        const float2* src;
+        if (NFFT_CT == 320) {                                 // 160 = 5 * 4 * 4 * 2 (what fft_plan gives), unrolled with constant sizes
+            fft_pass<5>(buf0, buf1, tw, 160, 320, 160, 1, tid, STFT_THREADS);
+            __syncthreads();
+            fft_pass<4>(buf1, buf0, tw, 160, 320, 32, 5, tid, STFT_THREADS);
+            __syncthreads();
+            fft_pass<4>(buf0, buf1, tw, 160, 320, 8, 20, tid, STFT_THREADS);
+            __syncthreads();
+            fft_pass<2>(buf1, buf0, tw, 160, 320, 2, 80, tid, STFT_THREADS);
+            __syncthreads();
+            src = buf0;
+        } else {
+            src = fft_run(buf0, buf1, tw, NH, n_fft, plan, tid, STFT_THREADS);
+        }
         // X[k] = E[k] + W_N^k O[k],  E = (Z[k] + conj Z[NH-k]) / 2,  O = (Z[k] - conj Z[NH-k]) / 2i;  k = 0..NH
         for (int e = tid; e < F * FFT_SIGS; e += STFT_THREADS) {
             const int f = e / FFT_SIGS, mm = e - f * FFT_SIGS;           // consecutive threads -> consecutive mics
@@ -162,8 +180,14 @@ extern "C" int eab_stft_compress_f32(const float* wav, const float* window, cons
     FftPlan plan;
     if (fft_plan(n_fft / 2, &plan)) {
         const size_t sh = (size_t)(2 * n_fft + 2 * FFT_SIGS * n_fft) * sizeof(float);
-        hipLaunchKernelGGL(stft_fft_kernel, dim3(B * T), dim3(STFT_THREADS), sh, eab_stream(stream), wav, window,
-                           twiddle, out, M, L, n_fft, hop, T, layout, plan);
+        const bool ref_plan = n_fft == 320 && hop == 160 && plan.npass == 4 && plan.radix[0] == 5 && plan.radix[1] == 4 &&
+                              plan.radix[2] == 4 && plan.radix[3] == 2;
+        if (ref_plan)
+            hipLaunchKernelGGL((stft_fft_kernel<320, 160>), dim3(B * T), dim3(STFT_THREADS), sh, eab_stream(stream), wav, window,
+                               twiddle, out, M, L, n_fft, hop, T, layout, plan);
+        else
+            hipLaunchKernelGGL((stft_fft_kernel<0, 0>), dim3(B * T), dim3(STFT_THREADS), sh, eab_stream(stream), wav, window,
+                               twiddle, out, M, L, n_fft, hop, T, layout, plan);
         EAB_RETURN_LAUNCH_STATUS();
     }
     size_t shmem = (size_t)(2 * n_fft + n_fft * STFT_MC) * sizeof(float);
