@@ -28,6 +28,7 @@
 // its SIMD for 64 cycles while needing one A and one B VGPR, so LDS and staging
 // traffic are far below their limits: roofline "mfma", fp32 dense 157.3 TFLOP/s.
 #include "common.h"
+#include <type_traits>
 
 #define CG_THREADS 256
 #define CG_OOB 0x80000000u   // > any legal byte offset inside one batch element (host checks < 2^31)
@@ -691,38 +692,69 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
     // 2-D convolution of the inference program except the last tile of a batch element.  Straight-line code: no per-row
     // masks, no per-element dispatch on the epilogue kind.  Values are computed by the same expressions as below (a row's
     // result does not depend on the path its tile took); the statistics use the same shifted single pass.
-    const bool fast_epi = !DUAL && q0 + BM <= Q && d.dst_acc == nullptr && d.glu_dump == nullptr && !two_sets &&
-                          (GLU ? true : d.epi == EAB_EPI_LINEAR);
+    const bool fast_epi = !DUAL && q0 + BM <= Q && d.dst_acc == nullptr && !two_sets &&
+                          (GLU ? true : (d.epi == EAB_EPI_LINEAR || d.epi == EAB_EPI_ADD));
     if (fast_epi) {
+        // the two training-side extras as compile-time variants of the same loop: the gated epilogue's factor dump (forward
+        // of the training program) and the accumulate-into operand (dgrad adding to an existing gradient, residual adds)
+        auto fast_loop = [&](auto dump_c, auto add_c) {
+            constexpr bool DUMPV = decltype(dump_c)::value, ADDV = decltype(add_c)::value;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
+            for (int mi = 0; mi < MI; ++mi) {
+                unsigned off[16];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int qg = q0 + (wm * MI + mi) * 32 + 8 * r4 + 4 * lh;
-                const int t = cg_div(qg, d.No, inv_no);
-                int o = qg - t * d.No;
-                unsigned row_start = (unsigned)t * row_bytes + phase_bytes;
-                unsigned cur = row_start + (unsigned)o * step_bytes;
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int qg = q0 + (wm * MI + mi) * 32 + 8 * r4 + 4 * lh;
+                    const int t = cg_div(qg, d.No, inv_no);
+                    int o = qg - t * d.No;
+                    unsigned row_start = (unsigned)t * row_bytes + phase_bytes;
+                    unsigned cur = row_start + (unsigned)o * step_bytes;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = 4 * r4 + j;
+                    for (int j = 0; j < 4; ++j) {
+                        off[4 * r4 + j] = cur;
+                        cur += step_bytes;
+                        if (++o == d.No) {
+                            o = 0;
+                            row_start += row_bytes;
+                            cur = row_start;
+                        }
+                    }
+                }
+                float auxv[16][NC];
+                if (ADDV) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+#pragma unroll
+                        for (int c = 0; c < NC; ++c)
+                            auxv[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_aux, off[r] + 4u * ch[c], 0, 0));
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
 #pragma unroll
                     for (int c = 0; c < NC; ++c) {
                         float v;
-                        if (GLU) v = (acc[mi][0][r] + bias_v[0]) * cg_sigmoid(acc[mi][1][r] + bias_v[1]);
-                        else v = acc[mi][c][r] + bias_v[c];
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_dst, cur + 4u * ch[c], 0, 0);
+                        if constexpr (GLU) {
+                            const float av = acc[mi][0][r] + bias_v[0], sv = cg_sigmoid(acc[mi][1][r] + bias_v[1]);
+                            v = av * sv;
+                            if (DUMPV) {
+                                float* dp = d.glu_dump + 2 * (out_b + (off[r] >> 2)) + n_blk + wn * 64 + li;
+                                dp[0] = av;
+                                dp[32] = sv;
+                            }
+                        } else {
+                            v = acc[mi][c][r] + bias_v[c];
+                        }
+                        if (ADDV) v = v + auxv[r][c];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_dst, off[r] + 4u * ch[c], 0, 0);
                         acc[mi][c][r] = v;
-                    }
-                    cur += step_bytes;
-                    if (++o == d.No) {
-                        o = 0;
-                        row_start += row_bytes;
-                        cur = row_start;
                     }
                 }
             }
-        }
+        };
+        const bool dump = GLU && d.glu_dump != nullptr, add = !GLU && d.epi == EAB_EPI_ADD;
+        if (dump) fast_loop(std::true_type{}, std::false_type{});
+        else if (add) fast_loop(std::false_type{}, std::true_type{});
+        else fast_loop(std::false_type{}, std::false_type{});
         if (d.stats) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
