@@ -199,7 +199,7 @@ def main_train(a, rank, world, dev, is_dist):
         "mode": "training step (BASELINE configs[3])",
         "value": frames / elapsed, "unit": "frames/s (trained)", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if net.precision == "f32" else "bf16 products (forward + dgrad convolutions), fp32 accumulate / wgrad / LSTM / norms / Adam",
+        "dtype": "f32" if net.precision == "f32" else "bf16 products (forward, dgrad and wgrad contractions), fp32 accumulate / LSTM / norms / gradients / Adam",
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[3] (train_distributed.py:214-230) for the beam-former stage: per-GPU batch 6 x 6 s x "
                                "8 mics; prepare_data (noisy + target STFT), EaBNet forward, com_mag_mse_loss, backward, "
@@ -272,12 +272,25 @@ def main_train(a, rank, world, dev, is_dist):
                     res[which]["ms_total"] += wg_ms - float(ms[wg].sum())
                     res[which]["ms_by_kernel"]["wgrad"] = round(wg_ms, 3)
                     res[which]["ms_by_kernel"]["wgrad (one launch per descriptor)"] = round(float(ms[wg].sum()), 3)
-                    out["roofline"] = {"kernel": "wgrad_kernel (fp32 MFMA 32x32x2, split-K, atomics)", "bound": "mfma",
-                                       "achieved": wg_fl / (wg_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                       "frac": wg_fl / (wg_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                                       "weight_gradients_per_step": len(wg), "launches_per_step": launches, "ms_per_step": wg_ms,
-                                       "note": "all weight gradients of the step: exact FLOPs / HIP-event time of the block as it "
-                                               "runs in production (descriptors of identical geometry share a launch)"}
+                    wg_by = sum(4.0 * o.B * o.T * o.No * (o.N + len(o.dt) * (o.C0 + o.C1)) for o in ops if o.kind == tr.OP_WGRAD)
+                    if net.precision == "bf16":
+                        # bf16 products: the matrix work is 1/16 of the fp32 form's, the kernel is bound by its operand traffic
+                        # (rows x (N + taps x C) x 4 B per descriptor: dz once, the gathered activations once per tap) and by the
+                        # split-K atomics
+                        out["roofline"] = {"kernel": "wgrad_bf_kernel (bf16 MFMA 32x32x16, fp32 accumulate, split-K, atomics)",
+                                           "bound": "hbm", "achieved": wg_by / (wg_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                           "frac": wg_by / (wg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                                           "achieved_tflops": wg_fl / (wg_ms * 1e-3) / 1e12,
+                                           "weight_gradients_per_step": len(wg), "launches_per_step": launches, "ms_per_step": wg_ms,
+                                           "note": "all weight gradients of the step: algorithmic operand bytes / HIP-event time of the "
+                                                   "block as it runs in production (descriptors of identical geometry share a launch)"}
+                    else:
+                        out["roofline"] = {"kernel": "wgrad_kernel (fp32 MFMA 32x32x2, split-K, atomics)", "bound": "mfma",
+                                           "achieved": wg_fl / (wg_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": wg_fl / (wg_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                                           "weight_gradients_per_step": len(wg), "launches_per_step": launches, "ms_per_step": wg_ms,
+                                           "note": "all weight gradients of the step: exact FLOPs / HIP-event time of the block as it "
+                                                   "runs in production (descriptors of identical geometry share a launch)"}
                     dg = [k for k, o in enumerate(ops) if o.kind == prg.OP_CONV]
                     dg_fl = sum(2.0 * o.B * o.T * o.No * o.N * len(o.dt) * (o.C0 + o.C1) for o in ops if o.kind == prg.OP_CONV)
                     out["dgrad"] = {"achieved_tflops": dg_fl / (float(ms[dg].sum()) * 1e-3) / 1e12, "ms_per_step": float(ms[dg].sum())}

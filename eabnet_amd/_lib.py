@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libeabnet_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_TAPS = 16
 _fp = C.POINTER(C.c_float)
 
@@ -56,7 +56,7 @@ class WgradDesc(C.Structure):
         ("B", C.c_int32), ("T", C.c_int32), ("Fin", C.c_int32), ("Fz", C.c_int32), ("No", C.c_int32),
         ("ostride", C.c_int32), ("ophase", C.c_int32), ("istride", C.c_int32),
         ("ntaps", C.c_int32), ("dt", C.c_int32 * MAX_TAPS), ("ioff", C.c_int32 * MAX_TAPS),
-        ("rows_per_wg", C.c_int32),
+        ("rows_per_wg", C.c_int32), ("precision", C.c_int32),
     ]
 
 

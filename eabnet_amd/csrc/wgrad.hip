@@ -230,10 +230,181 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgBatch bt) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 products (EAB_PREC_BF16; the training dtype of BASELINE configs[3]): the same split-K tiling, but the two operands are
+// rounded to bf16 on their way into LDS and multiplied on v_mfma_f32_32x32x16_bf16 (one instruction per 16-row stage instead
+// of eight fp32 ones); fp32 accumulation, fp32 atomics into dW, bias gradient from the unrounded dz.
+// LDS holds the operands TRANSPOSED, [column][row pair] with two bf16 (rows 2p, 2p+1) per dword and 9 dwords per column (odd
+// stride: the dword writes of a float4's four columns and the 4-dword fragment reads both spread over the banks): lane
+// (i, g) of the MFMA reads the dwords 4g..4g+3 of column i = its eight k values.  Thread -> row pair tid/32, float4 tid%32.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int wg_u32x4 __attribute__((ext_vector_type(4)));
+#define WGB_S 9
+
+__device__ __forceinline__ unsigned wg_bf2(float x0, float x1) {
+    const wg_bf16x2 v = {(__bf16)x0, (__bf16)x1};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+template <int TN, int TC>
+__global__ __launch_bounds__(WG_THREADS) void wgrad_bf_kernel(const WgBatch bt) {
+    constexpr int MI = TN / 64, NJ = TC / 64;
+    __shared__ unsigned a_t[2][TN * WGB_S];
+    __shared__ unsigned b_t[2][TC * WGB_S];
+    __shared__ float bias_red[8][TN];
+    const eab_wgrad_desc& d = bt.d;
+    const int member = bt.n > 1 ? (int)(blockIdx.x / (unsigned)bt.groups) : 0;
+    const int row_group = (int)blockIdx.x - member * bt.groups;
+    const float* const m_dz = bt.dz[member];
+    const float* const m_src0 = bt.src0[member];
+    const float* const m_src1 = bt.src1[member];
+    float* const m_dw = bt.dw[member];
+    float* const m_dbias = bt.dbias[member];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+
+    const long long R = (long long)d.T * d.No * d.B;
+    const long long r_begin = (long long)row_group * d.rows_per_wg;
+    const long long r_end = r_begin + d.rows_per_wg < R ? r_begin + d.rows_per_wg : R;
+    const int col0 = blockIdx.y * TC, n0 = blockIdx.z * TN;
+    const int Ctot = d.C0 + d.C1, UPT = (Ctot + 15) >> 4, NU = d.ntaps * UPT;
+
+    const int rp = tid >> 5, c4 = tid & 31;                        // row pair of the stage, float4 column
+    const bool a_live = c4 * 4 < TN, b_live = c4 * 4 < TC;
+    // gathered-x column block of this thread: unit u = one tap x 16 channels
+    const int u = (col0 >> 4) + (c4 >> 2);
+    const bool u_ok = b_live && u < NU;
+    const int tap = u_ok ? u / UPT : 0;
+    const int cu = (u_ok ? u - tap * UPT : 0) << 4;
+    const bool second = d.C1 > 0 && cu >= d.C0;
+    const int b_Cs = second ? d.C1 : d.C0;
+    const int b_cc = (second ? cu - d.C0 : cu) + (c4 & 3) * 4;
+    const bool b_ok = u_ok && b_cc < b_Cs;
+    const float* const b_src = second ? m_src1 : m_src0;
+    int tdt = 0, tio = 0;
+#pragma unroll
+    for (int k = 0; k < EAB_MAX_TAPS; ++k)
+        if (k == tap) {
+            tdt = d.dt[k];
+            tio = d.ioff[k];
+        }
+    const bool vec_ok = (d.C0 & 3) == 0;
+    WgRow rw;
+    rw.init(r_begin + 2 * rp, d.T, d.No);
+
+    f32x4 ra[2], rb[2];
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = m_dbias != nullptr && blockIdx.y == 0;
+    auto fetch = [&](long long r0) {
+        WgRow w = rw;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const bool rok = r0 + 2 * rp + e < r_end;
+            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            if (rok && a_live)
+                va = *reinterpret_cast<const f32x4*>(
+                    &m_dz[(((size_t)w.b * d.T + w.t) * d.Fz + (size_t)w.o * d.ostride + d.ophase) * d.N + n0 + c4 * 4]);
+            const int tt = w.t + tdt, fi = w.o * d.istride + tio;
+            if (rok && b_ok && tt >= 0 && tt < d.T && fi >= 0 && fi < d.Fin) {
+                const float* sp = &b_src[(((size_t)w.b * d.T + tt) * d.Fin + fi) * b_Cs + b_cc];
+                if (vec_ok) {
+                    vb = *reinterpret_cast<const f32x4*>(sp);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (b_cc + q < b_Cs) vb[q] = sp[q];
+                }
+            }
+            ra[e] = va;
+            rb[e] = vb;
+            if (e == 0) w.advance(1, d.T, d.No);
+        }
+        rw.advance(WG_ROWS, d.T, d.No);
+    };
+    auto stash = [&](int buf) {
+        if (a_live) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a_t[buf][(c4 * 4 + j) * WGB_S + rp] = wg_bf2(ra[0][j], ra[1][j]);
+            if (do_bias) bsum += ra[0] + ra[1];
+        }
+        if (b_live) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b_t[buf][(c4 * 4 + j) * WGB_S + rp] = wg_bf2(rb[0][j], rb[1][j]);
+        }
+    };
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.0f;
+
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    const int a_off = (wm * (TN / 2) + li) * WGB_S + 4 * lh, b_off = (wn * (TC / 2) + li) * WGB_S + 4 * lh;
+    auto frag = [](const unsigned* p) {
+        const wg_u32x4 v = {p[0], p[1], p[2], p[3]};
+        return __builtin_bit_cast(wg_bf16x8, v);
+    };
+
+    if (r_begin < r_end) {
+        fetch(r_begin);
+        stash(0);
+        lds_barrier();
+        int cur = 0;
+        for (long long r0 = r_begin; r0 < r_end; r0 += WG_ROWS) {
+            const bool more = r0 + WG_ROWS < r_end;
+            if (more) fetch(r0 + WG_ROWS);
+            wg_bf16x8 av[MI], bv[NJ];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) av[mi] = frag(&a_t[cur][a_off + mi * 32 * WGB_S]);
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj) bv[nj] = frag(&b_t[cur][b_off + nj * 32 * WGB_S]);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj)
+                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi], bv[nj], acc[mi][nj], 0, 0, 0);
+            if (more) stash(cur ^ 1);
+            lds_barrier();
+            cur ^= 1;
+        }
+    }
+
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+        const int col = col0 + wn * (TC / 2) + nj * 32 + li;
+        if (col < d.Kpad) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + wm * (TN / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    atomicAdd(&m_dw[(size_t)n * d.Kpad + col], acc[mi][nj][r]);
+                }
+        }
+    }
+    if (m_dbias != nullptr && blockIdx.y == 0) {     // (workgroup-uniform): the 8 row-pair lanes of a column meet in LDS
+        __syncthreads();
+        if (a_live) *reinterpret_cast<f32x4*>(&bias_red[rp][c4 * 4]) = bsum;
+        __syncthreads();
+        if (tid < TN) {
+            float t = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t += bias_red[r][tid];
+            atomicAdd(&m_dbias[n0 + tid], t);
+        }
+    }
+}
+
 static bool wg_same_geometry(const eab_wgrad_desc* a, const eab_wgrad_desc* b) {
     if (a->N != b->N || a->C0 != b->C0 || a->C1 != b->C1 || a->Kpad != b->Kpad || a->B != b->B || a->T != b->T || a->Fin != b->Fin ||
         a->Fz != b->Fz || a->No != b->No || a->ostride != b->ostride || a->ophase != b->ophase || a->istride != b->istride ||
-        a->ntaps != b->ntaps || (a->src1 == nullptr) != (b->src1 == nullptr) || (a->dbias == nullptr) != (b->dbias == nullptr))
+        a->ntaps != b->ntaps || a->precision != b->precision || (a->src1 == nullptr) != (b->src1 == nullptr) ||
+        (a->dbias == nullptr) != (b->dbias == nullptr))
         return false;
     for (int k = 0; k < a->ntaps; ++k)
         if (a->dt[k] != b->dt[k] || a->ioff[k] != b->ioff[k]) return false;
@@ -259,6 +430,7 @@ extern "C" int eab_wgrad_batch_f32(const eab_wgrad_desc* descs, int n, int strid
         EAB_CHECK_ARG(k == 0 || wg_same_geometry(d, at(k)));
     }
     EAB_CHECK_ARG(d->B > 0 && d->T > 0 && d->Fin > 0 && d->Fz > 0 && d->No > 0 && d->N > 0 && (d->N % 64) == 0);
+    EAB_CHECK_ARG(d->precision == EAB_PREC_F32 || d->precision == EAB_PREC_BF16);
     EAB_CHECK_ARG(d->C0 > 0 && d->C1 >= 0 && (d->C1 == 0) == (d->src1 == nullptr));
     EAB_CHECK_ARG((d->C1 % 4) == 0 && (d->C1 == 0 || (d->C0 % 16) == 0));      // a single source may have any channel count
     EAB_CHECK_ARG(d->ntaps > 0 && d->ntaps <= EAB_MAX_TAPS && d->ostride >= 1 && d->istride >= 1);
@@ -303,6 +475,13 @@ extern "C" int eab_wgrad_batch_f32(const eab_wgrad_desc* descs, int n, int strid
     EAB_CHECK_ARG((long long)bt.groups * n < (1ll << 31));
     dim3 grid((unsigned)(bt.groups * n), (unsigned)cb, (unsigned)nb);
     hipStream_t s = eab_stream(stream);
+    if (d->precision == EAB_PREC_BF16) {
+        if (tn == 128 && tc == 128) hipLaunchKernelGGL((wgrad_bf_kernel<128, 128>), grid, dim3(WG_THREADS), 0, s, bt);
+        else if (tn == 128) hipLaunchKernelGGL((wgrad_bf_kernel<128, 64>), grid, dim3(WG_THREADS), 0, s, bt);
+        else if (tc == 128) hipLaunchKernelGGL((wgrad_bf_kernel<64, 128>), grid, dim3(WG_THREADS), 0, s, bt);
+        else hipLaunchKernelGGL((wgrad_bf_kernel<64, 64>), grid, dim3(WG_THREADS), 0, s, bt);
+        EAB_RETURN_LAUNCH_STATUS();
+    }
     if (tn == 128 && tc == 128) hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(WG_THREADS), 0, s, bt);
     else if (tn == 128) hipLaunchKernelGGL((wgrad_kernel<128, 64>), grid, dim3(WG_THREADS), 0, s, bt);
     else if (tc == 128) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(WG_THREADS), 0, s, bt);

@@ -84,6 +84,7 @@ class WgradOp:
     name: str = ""
     kind: int = OP_WGRAD
     dbias: Optional[Ref] = None          # bias gradient (column sums of dz over this launch's rows) rides along
+    precision: int = 0                   # EAB_PREC_F32, or EAB_PREC_BF16 (operands rounded to bf16, fp32 accumulation)
 
 
 class Slot:
@@ -115,8 +116,8 @@ def _split64(n: int) -> Tuple[int, int]:
 class TrainLowering:
     def __init__(self, cfg: NetConfig, B: int, T: int, F: int = 161, precision: str = "f32"):
         if precision not in ("f32", "bf16"):
-            raise ValueError("training precision is 'f32' or 'bf16' (bf16: forward and dgrad contractions on the bf16 matrix "
-                             "cores; weight gradients, LSTM, norms and the optimiser state stay fp32)")
+            raise ValueError("training precision is 'f32' or 'bf16' (bf16: forward, dgrad and wgrad contractions on the bf16 "
+                             "matrix cores with fp32 accumulation; LSTM, norms, gradients and the optimiser state stay fp32)")
         self.prec = prg.PREC_CODE[precision]
         if not supported(cfg):
             raise NotImplementedError("the HIP training path covers the default topology with InstanceNorm")
@@ -265,7 +266,7 @@ class TrainLowering:
         self.deferred.append(WgradOp(dz=dz, src0=s0.ref, src1=s1.ref if s1 else None, dw=self.gadd([gimg]), N=N, C0=s0.C,
                                      C1=s1.C if s1 else 0, Kpad=Kpad, B=self.B, T=self.T, Fin=s0.F, Fz=Fz, No=No,
                                      ostride=ostride, ophase=ophase, istride=istride, dt=list(dt), ioff=list(ioff), name=name,
-                                     dbias=dbias))
+                                     dbias=dbias, precision=self.prec if self.prec == prg.PREC_BF16 else prg.PREC_F32))
         self.flops_bwd += 2 * self.B * self.T * No * N * len(dt) * Ctot
 
     def colsum(self, name, x: Ref, rows: int, N: int, imgs: Sequence[np.ndarray]) -> None:
@@ -648,7 +649,7 @@ class TrainLowering:
                 inv[tgt] = off + np.nonzero(m)[0]
         def geometry(o: WgradOp):
             return (o.N, o.C0, o.C1, o.Kpad, o.Fin, o.Fz, o.No, o.ostride, o.ophase, o.istride, tuple(o.dt), tuple(o.ioff),
-                    o.src1 is None, o.dbias is None)
+                    o.src1 is None, o.dbias is None, o.precision)
         order: Dict[tuple, int] = {}
         for o in self.deferred:
             order.setdefault(geometry(o), len(order))
@@ -810,6 +811,7 @@ class TrainBound:
                     for f in ("N", "C0", "C1", "Kpad", "B", "T", "Fin", "Fz", "No", "ostride", "ophase", "istride"):
                         setattr(d, f, int(getattr(op, f)))
                     d.ntaps = len(op.dt)
+                    d.precision = int(op.precision)
                     for j in range(_lib.MAX_TAPS):
                         d.dt[j] = op.dt[j] if j < len(op.dt) else 0
                         d.ioff[j] = op.ioff[j] if j < len(op.ioff) else 0

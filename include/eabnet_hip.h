@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EAB_ABI_VERSION 3
+#define EAB_ABI_VERSION 4
 
 #define EAB_OK          0
 #define EAB_EINVAL      1   /* bad argument (shape, alignment, limit) */
@@ -358,6 +358,7 @@ typedef struct eab_wgrad_desc {
     int32_t dt[EAB_MAX_TAPS];
     int32_t ioff[EAB_MAX_TAPS];
     int32_t rows_per_wg;    /* set by the library */
+    int32_t precision;      /* EAB_PREC_F32 (exact fp32 products) or EAB_PREC_BF16 (operands rounded to bf16, fp32 accumulation) */
 } eab_wgrad_desc;
 
 typedef struct eab_op {

@@ -35,7 +35,7 @@ def _ck(code, what=""):
     _lib.check(code, what)
 
 
-def _wgrad(lib, dz, src0, src1, N, Kpad, B, T, Fin, Fz, No, ostride, ophase, istride, dt, ioff, dbias=None):
+def _wgrad(lib, dz, src0, src1, N, Kpad, B, T, Fin, Fz, No, ostride, ophase, istride, dt, ioff, dbias=None, precision=0):
     from eabnet_amd import _lib
     d = _lib.WgradDesc()
     dw = torch.zeros(N, Kpad, device="cuda:0")
@@ -44,6 +44,7 @@ def _wgrad(lib, dz, src0, src1, N, Kpad, B, T, Fin, Fz, No, ostride, ophase, ist
     d.N, d.C0, d.C1, d.Kpad = N, src0.shape[-1], (src1.shape[-1] if src1 is not None else 0), Kpad
     d.B, d.T, d.Fin, d.Fz, d.No, d.ostride, d.ophase, d.istride = B, T, Fin, Fz, No, ostride, ophase, istride
     d.ntaps = len(dt)
+    d.precision = precision
     for j in range(len(dt)):
         d.dt[j], d.ioff[j] = dt[j], ioff[j]
     _ck(lib.eab_wgrad_f32(C.byref(d), _st()), "eab_wgrad_f32")
@@ -72,6 +73,19 @@ def test_wgrad_of_a_strided_convolution(lib, N, C0, C1, kt, kf, B, T, Fin):
     want = w.grad.reshape(N, C0, kt * kf).permute(0, 2, 1)
     assert_close(got.numpy(), want.numpy(), TOL, "dW")
     assert_close(db.cpu().numpy(), dz.sum((0, 2, 3)).numpy(), TOL, "dbias riding on the weight gradient")
+    # bf16 products (EAB_PREC_BF16): both operands rounded to bf16, fp32 accumulation -> compare with the same rounding applied
+    # to the fp64 operands (then only the accumulation order differs), and loosely with the unrounded gradient
+    db2 = torch.zeros(N, device="cuda:0")
+    got16 = _wgrad(lib, _dev(dz.permute(0, 2, 3, 1)), _dev(x.permute(0, 2, 3, 1)), None, N, len(taps) * upt * 16, B, T, Fin, Fout, Fout, 1,
+                   0, stride, [a - (kt - 1) for a, _ in taps], [c for _, c in taps], dbias=db2, precision=2)
+    got16 = got16.view(N, len(taps), upt * 16)[:, :, :C0]
+    xr = x.float().bfloat16().double()
+    dzr = dz.float().bfloat16().double()
+    wr = torch.zeros_like(w, requires_grad=True)
+    (F.conv2d(F.pad(xr, (0, 0, kt - 1, 0)), wr, stride=(1, stride)) * dzr).sum().backward()
+    assert_close(got16.numpy(), wr.grad.reshape(N, C0, kt * kf).permute(0, 2, 1).numpy(), TOL, "dW, bf16 products")
+    assert_close(got16.numpy(), want.numpy(), 2e-2, "dW, bf16 products vs exact")
+    assert_close(db2.cpu().numpy(), dz.sum((0, 2, 3)).numpy(), TOL, "dbias (from the unrounded dz)")
 
 
 @pytest.mark.parametrize("N,C0,C1,kt,kf,B,T,Fin", [(128, 64, 64, 2, 3, 2, 8, 9), (64, 64, 64, 1, 3, 2, 6, 19), (128, 64, 64, 2, 5, 1, 4, 79)])
