@@ -143,6 +143,24 @@ def main_train(a, rank, world, dev, is_dist):
     net.train()
     net.use_hip_training = not a.train_operator_path
     net.precision = "bf16" if a.precision == "bf16" else "f32"
+    two = None
+    if a.train_two_stage:
+        assert world == 1, "--train-two-stage is a single-GPU comparison line"
+        # the model train_distributed.py:181 actually builds: beam-former + GaGNet post-filter, both trained
+        # (eabnet_with_postnet_loss, :225).  The beam-former stage runs on the HIP training programs, the post-filter (fed
+        # esti0.detach(), EaBNet.py:142) on PyTorch-ROCm operators: its training lowering is not built yet.
+        pa = argparse.Namespace(
+            k1=(2, 3), k2=(1, 3), c=64, M=M, embed_dim=64, kd1=5, cd1=64, d_feat=256, p=6, q=3, is_causal=True, is_u2=True,
+            bf_type="lstm", topo_type="mimo", intra_connect="cat", norm_type="IN", ref_mic=0, freeze_eabnet=False,
+            gagnet_k1=(2, 3), gagnet_k2=(1, 3), gagnet_c=64, gagnet_kd1=3, gagnet_cd1=64, gagnet_d_feat=256, gagnet_p=2,
+            gagnet_q=3, gagnet_dilas=[1, 2, 5, 9], gagnet_fft_num=320, gagnet_is_u2=True, gagnet_is_causal=True,
+            gagnet_is_squeezed=False, gagnet_acti_type="sigmoid", gagnet_intra_connect="cat", gagnet_norm_type="IN")
+        torch.manual_seed(1)
+        two = eabnet_amd.make_eabnet_with_postnet(pa).to(dev).train()
+        two.eabnet.load_state_dict(net.state_dict(), strict=True)
+        two.eabnet.use_hip_training = net.use_hip_training
+        two.eabnet.precision = net.precision
+        net = two.eabnet
     pd_args = argparse.Namespace(mics=M, sr=SR, wav_len=seconds, win_size=0.020, win_shift=0.010, fft_num=N_FFT)
     wav = synth_waves(B, M, L, 1234 + rank).to(dev)
     tgt = synth_waves(B, 1, L, 4321 + rank).to(dev)
@@ -154,16 +172,19 @@ def main_train(a, rank, world, dev, is_dist):
                                                               gradient_as_bucket_view=True, static_graph=True)
         else:
             tr.enable_flat_allreduce(net)
-    opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+    trained = two if two is not None else net
+    opt = torch.optim.Adam(trained.parameters(), lr=5e-4)
     frames_list = [T] * B
 
     def step():
         opt.zero_grad(set_to_none=True)
         noisy, target = eabnet_amd.prepare_data(wav, tgt, dev, pd_args)
-        out = model(noisy)
-        loss = eabnet_amd.com_mag_mse_loss(out, target, frames_list)
+        if two is not None:
+            loss = eabnet_amd.eabnet_with_postnet_loss(two(noisy), target, frames_list)["final"]
+        else:
+            loss = eabnet_amd.com_mag_mse_loss(model(noisy), target, frames_list)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+        torch.nn.utils.clip_grad_norm_(trained.parameters(), 1.0)
         opt.step()
         return loss
 
@@ -183,6 +204,18 @@ def main_train(a, rank, world, dev, is_dist):
     elapsed = dist.max_over_ranks(el, dev)
     assert bool(torch.isfinite(loss)), "training diverged"
     frames = world * B * T * a.steps
+    if a.train_two_stage:
+        if rank == 0:
+            print(json.dumps({"mode": "training step of the two-stage model (train_distributed.py:181,225): beam-former on the HIP "
+                                      "training programs" + (" (operator path)" if a.train_operator_path else "") +
+                                      ", GaGNet post-filter on PyTorch-ROCm operators: comparison line",
+                              "value": frames / elapsed, "unit": "frames/s (trained)", "n_gpus": world, "steps": a.steps,
+                              "ms_per_step": 1e3 * elapsed / a.steps, "final_loss": float(loss.detach()),
+                              "params": eabnet_amd.numParams(two)}))
+        if is_dist:
+            dist.barrier()
+            torch.distributed.destroy_process_group()
+        return
     if a.train_operator_path:
         if rank == 0:
             print(json.dumps({"mode": "training step on PyTorch-ROCm operators (autograd_path.py): comparison line", "value": frames / elapsed,
@@ -323,6 +356,9 @@ def main():
     ap.add_argument("--train", action="store_true",
                     help="BASELINE configs[3]: training step (prepare_data, forward, loss, backward, clip, Adam) on the HIP "
                          "training programs, per-GPU batch 6 x 6 s x 8 mics, one flat RCCL gradient all-reduce per step")
+    ap.add_argument("--train-two-stage", action="store_true",
+                    help="with --train: the two-stage model of train_distributed.py (beam-former on the HIP training programs, "
+                         "post-filter on PyTorch-ROCm operators); a comparison line, not the training headline")
     ap.add_argument("--train-operator-path", action="store_true",
                     help="with --train: forward/backward on PyTorch-ROCm operators (autograd_path.py, MIOpen) -- the comparison line")
     ap.add_argument("--train-ddp", action="store_true", help="with --train: wrap in torch DistributedDataParallel (one 64 MB bucket, "
