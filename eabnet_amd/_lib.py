@@ -103,6 +103,8 @@ _SIGS = {
     "eab_gather_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong, C.c_void_p]),
     "eab_train_in_stats_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_float] + [C.c_void_p] * 4 + [C.c_void_p]),
     "eab_train_in1d_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_float] + [C.c_void_p] * 5 + [C.c_void_p]),
+    "eab_train_in1d_multi_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_float] + [C.c_void_p] * 5 + [C.c_void_p]),
+    "eab_train_norm_bwd_multi_f32": (C.c_int, [C.c_void_p] * 12 + [C.c_int] * 3 + [C.c_void_p]),
     "eab_in_finalize_mr_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_float] + [C.c_void_p] * 8 + [C.c_void_p]),
     "eab_train_norm_act_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "eab_train_norm_bwd_f32": (C.c_int, [C.c_void_p] * 12 + [C.c_int] * 4 + [C.c_void_p]),

@@ -125,7 +125,10 @@ extern "C" int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream
                 rc = eab_gather_f32(EAB_P(0), (const int32_t*)o.p[1], (const int32_t*)o.p[2], EAB_W(3), EAB_N64(0), stream);
                 break;
             case EAB_OP_IN_STATS:
-                rc = o.p[6] ? eab_train_in1d_f32(EAB_P(0), EAB_P(1), o.i[0], o.i[1], o.i[2], o.f[0], EAB_P(2), EAB_P(3), EAB_W(4),
+                rc = o.p[6] && o.i[3] > 0
+                         ? eab_train_in1d_multi_f32(EAB_P(0), EAB_P(1), o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], EAB_P(2), EAB_P(3),
+                                                    EAB_W(4), EAB_W(5), EAB_W(6), stream)
+                     : o.p[6] ? eab_train_in1d_f32(EAB_P(0), EAB_P(1), o.i[0], o.i[1], o.i[2], o.f[0], EAB_P(2), EAB_P(3), EAB_W(4),
                                                  EAB_W(5), EAB_W(6), stream)
                             : eab_train_in_stats_f32(EAB_P(0), EAB_P(1), o.i[0], o.i[1], o.i[2], o.f[0], EAB_P(2), EAB_P(3),
                                                      EAB_W(4), EAB_W(5), stream);
@@ -135,8 +138,12 @@ extern "C" int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream
                                             stream);
                 break;
             case EAB_OP_NORM_BWD:
-                rc = eab_train_norm_bwd_f32(EAB_P(0), EAB_P(1), EAB_P(2), EAB_P(3), EAB_P(4), EAB_P(5), EAB_W(6), EAB_P(7),
-                                            EAB_W(8), EAB_W(9), EAB_W(10), EAB_W(11), o.i[0], o.i[1], o.i[2], o.i[3], stream);
+                rc = o.i[4] > 0 ? eab_train_norm_bwd_multi_f32(EAB_P(0), EAB_P(4), EAB_P(1), EAB_P(2), EAB_P(3), EAB_P(5), EAB_W(6),
+                                                               EAB_P(7), EAB_W(8), EAB_W(9), EAB_W(10), EAB_W(11), o.i[0], o.i[1],
+                                                               o.i[4], stream)
+                                : eab_train_norm_bwd_f32(EAB_P(0), EAB_P(1), EAB_P(2), EAB_P(3), EAB_P(4), EAB_P(5), EAB_W(6), EAB_P(7),
+                                                         EAB_W(8), EAB_W(9), EAB_W(10), EAB_W(11), o.i[0], o.i[1], o.i[2], o.i[3],
+                                                         stream);
                 break;
             case EAB_OP_GLU_BWD:
                 rc = eab_glu_bwd_f32(EAB_P(0), EAB_P(1), EAB_W(2), EAB_N64(0), o.i[2], stream);

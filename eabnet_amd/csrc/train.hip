@@ -53,7 +53,7 @@ template <bool APPLY>
 __global__ __launch_bounds__(TR_THREADS) void in_stats_kernel(const float* __restrict__ x, const float* __restrict__ slope,
                                                               int P, int C, float eps, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* __restrict__ xf,
-                                                              float* __restrict__ mr, float* __restrict__ y) {
+                                                              float* __restrict__ mr, float* __restrict__ y, int xC) {
     // thread -> 4 channels (float4) x every 16th position; shifted sums (shift = the channel's first value, so a
     // nearly constant channel loses nothing to cancellation) in fp64, combined through LDS in a fixed order
     __shared__ double red[2][16][64];
@@ -64,7 +64,9 @@ __global__ __launch_bounds__(TR_THREADS) void in_stats_kernel(const float* __res
     f32x4 k = {0.f, 0.f, 0.f, 0.f}, a = {1.f, 1.f, 1.f, 1.f};
     if (c < C) {
         if (slope) a = *reinterpret_cast<const f32x4*>(slope + c);
-        const float* p = x + (size_t)b * P * C + c;
+        // xC < C: the output channels are several views of the same xC input channels (the two branch norms of an S-TCM
+        // see the same tensor through their own PReLU / gain / bias): channel c reads input channel c % xC
+        const float* p = x + (size_t)b * P * xC + (c % xC);
         k = *reinterpret_cast<const f32x4*>(p);
 #pragma unroll
         for (int j = 0; j < 4; ++j) k[j] = eab_prelu(k[j], a[j]);
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(TR_THREADS) void in_stats_kernel(const float* __res
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + 16 * u;
-                v[u] = i < P ? *reinterpret_cast<const f32x4*>(p + (size_t)i * C) : k;
+                v[u] = i < P ? *reinterpret_cast<const f32x4*>(p + (size_t)i * xC) : k;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(TR_THREADS) void in_stats_kernel(const float* __res
                 ss += red[0][r][threadIdx.x];
                 qq += red[1][r][threadIdx.x];
             }
-            const float kk = eab_prelu(x[(size_t)b * P * C + cc], slope ? slope[cc] : 1.0f);
+            const float kk = eab_prelu(x[(size_t)b * P * xC + (cc % xC)], slope ? slope[cc] : 1.0f);
             const double mean_s = ss / P;
             double var = qq / P - mean_s * mean_s;
             if (var < 0.0) var = 0.0;
@@ -131,14 +133,16 @@ __global__ __launch_bounds__(TR_THREADS) void in_stats_kernel(const float* __res
                 sc4[j] = scsh[0][cl * 4 + j];
                 sh4[j] = scsh[1][cl * 4 + j];
             }
-            const float* p = x + (size_t)b * P * C + c;
-            float* yp = y + (size_t)b * P * C + c;
+            const float* p = x + (size_t)b * P * xC + (c % xC);
+            // several views (xC < C): every view is its own contiguous [B][P][xC] tensor, one behind the other
+            const int yC = xC < C ? xC : C;
+            float* yp = y + (size_t)(c / yC) * gridDim.x * P * yC + (size_t)b * P * yC + (c % yC);
             for (int i0 = pl; i0 < P; i0 += 64) {
                 f32x4 v[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int i = i0 + 16 * u;
-                    v[u] = i < P ? *reinterpret_cast<const f32x4*>(p + (size_t)i * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    v[u] = i < P ? *reinterpret_cast<const f32x4*>(p + (size_t)i * xC) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(TR_THREADS) void in_stats_kernel(const float* __res
                         f32x4 o;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) o[j] = fmaf(eab_prelu(v[u][j], a[j]), sc4[j], sh4[j]);
-                        *reinterpret_cast<f32x4*>(yp + (size_t)i * C) = o;
+                        *reinterpret_cast<f32x4*>(yp + (size_t)i * yC) = o;
                     }
                 }
             }
@@ -159,7 +163,7 @@ extern "C" int eab_train_in_stats_f32(const float* x, const float* slope, int B,
                                       const float* beta, float* xf, float* mr, eab_stream_t stream) {
     EAB_CHECK_ARG(x && gamma && beta && xf && mr && B > 0 && P > 0 && C > 0 && (C % 4) == 0 && B <= 65535);
     hipLaunchKernelGGL(in_stats_kernel<false>, dim3(B, (C + 63) / 64), dim3(TR_THREADS), 0, eab_stream(stream), x, slope, P, C, eps,
-                       gamma, beta, xf, mr, nullptr);
+                       gamma, beta, xf, mr, nullptr, C);
     EAB_RETURN_LAUNCH_STATUS();
 }
 
@@ -169,7 +173,19 @@ extern "C" int eab_train_in1d_f32(const float* x, const float* slope, int B, int
                                   const float* beta, float* xf, float* mr, float* y, eab_stream_t stream) {
     EAB_CHECK_ARG(x && slope && gamma && beta && xf && mr && y && B > 0 && P > 0 && C > 0 && (C % 4) == 0 && B <= 65535);
     hipLaunchKernelGGL(in_stats_kernel<true>, dim3(B, (C + 63) / 64), dim3(TR_THREADS), 0, eab_stream(stream), x, slope, P, C, eps,
-                       gamma, beta, xf, mr, y);
+                       gamma, beta, xf, mr, y, C);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
+// Several 1-D units on ONE input: view v = c / xC of the C = k * xC parameter channels normalises prelu(x[b][p][c % xC], slope[c])
+// into its own contiguous tensor y + v * B*P*xC (the left and right branch norms of a SqueezedTCM, EaBNet.py:545-547 and
+// 559-560, in one launch).
+extern "C" int eab_train_in1d_multi_f32(const float* x, const float* slope, int B, int P, int C, int xC, float eps,
+                                        const float* gamma, const float* beta, float* xf, float* mr, float* y, eab_stream_t stream) {
+    EAB_CHECK_ARG(x && slope && gamma && beta && xf && mr && y && B > 0 && P > 0 && C > 0 && xC > 0 && (xC % 4) == 0 && (C % xC) == 0 &&
+                  B <= 65535);
+    hipLaunchKernelGGL(in_stats_kernel<true>, dim3(B, (C + 63) / 64), dim3(TR_THREADS), 0, eab_stream(stream), x, slope, P, C, eps,
+                       gamma, beta, xf, mr, y, xC);
     EAB_RETURN_LAUNCH_STATUS();
 }
 
@@ -240,7 +256,8 @@ __global__ __launch_bounds__(TR_THREADS) void tr_zero_kernel(float* __restrict__
 __global__ __launch_bounds__(TR_THREADS) void norm_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                      const float* __restrict__ mr, const float* __restrict__ gamma,
                                                                      const float* __restrict__ beta, const float* __restrict__ slope,
-                                                                     float* __restrict__ sums, int P, int C, int mode, int chunk) {
+                                                                     float* __restrict__ sums, int P, int C, int mode, int chunk,
+                                                                     int xC, const float* __restrict__ dy1) {
     __shared__ f32x4 red[3][NB_ROWS][16];
     const int b = blockIdx.z, cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int c = blockIdx.y * 64 + cl * 4;
@@ -252,10 +269,13 @@ __global__ __launch_bounds__(TR_THREADS) void norm_bwd_reduce_kernel(const float
         const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c),
                     a = *reinterpret_cast<const f32x4*>(slope + c);
         const int p0 = blockIdx.x * chunk, p1 = p0 + chunk < P ? p0 + chunk : P;
-        const size_t base = (size_t)b * P * C + c;
+        // xC < C: views (see in_stats_kernel): view v's output gradient is its own [B][P][xC] tensor (dy, dy1)
+        const size_t xbase = (size_t)b * P * xC + (c % xC);
+        const float* dyp = xC < C ? (c < xC ? dy : dy1) + xbase : dy + (size_t)b * P * C + c;
+        const int dC = xC < C ? xC : C;
         for (int i = p0 + pl; i < p1; i += NB_ROWS) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(&x[base + (size_t)i * C]);
-            const f32x4 d = *reinterpret_cast<const f32x4*>(&dy[base + (size_t)i * C]);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(&x[xbase + (size_t)i * xC]);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(&dyp[(size_t)i * dC]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (mode == EAB_XF_NORM_PRELU) {
@@ -360,6 +380,76 @@ __global__ __launch_bounds__(TR_THREADS) void norm_bwd_apply_kernel(const float*
     }
 }
 
+// Apply pass of the multi-view form (C = NV * xC: NV norms on views of the same xC-channel tensor, PRELU_NORM order): the
+// input gradient is the SUM over the views, written once:  dx[c] = (acc_in) + sum_v dx_v[c].  Parameter gradients always ride
+// along (this form is only used for the S-TCN's small slabs).  Thread -> 4 input channels x every 16th position.
+__global__ __launch_bounds__(TR_THREADS) void norm_bwd_apply_multi_kernel(const float* __restrict__ dy, const float* __restrict__ dy1,
+                                                                          const float* __restrict__ x,
+                                                                          const float* __restrict__ mr, const float* __restrict__ gamma,
+                                                                          const float* __restrict__ slope, const float* __restrict__ sums,
+                                                                          const float* __restrict__ acc_in, float* __restrict__ dx,
+                                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                          float* __restrict__ dslope, int P, int C, int xC, int chunk) {
+    __shared__ f32x4 red[2][NB_ROWS][16];
+    const int b = blockIdx.z, cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + cl * 4;                        // input channel
+    const int NV = C / xC;                                         // 2 (host-checked: <= 2)
+    f32x4 S[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (c < xC) {
+        float mean[2][4], k[2][4], Am[2][4], Qm[2][4];
+        f32x4 a[2];
+        const float inv_p = 1.0f / (float)P;
+        for (int v = 0; v < NV; ++v) {
+            const int cv = c + v * xC;
+            const float* mp = &mr[((size_t)b * C + cv) * 2];
+            const f32x4 m01 = *reinterpret_cast<const f32x4*>(mp), m23 = *reinterpret_cast<const f32x4*>(mp + 4);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + cv);
+            a[v] = *reinterpret_cast<const f32x4*>(slope + cv);
+            const float mn[4] = {m01[0], m01[2], m23[0], m23[2]}, rs[4] = {m01[1], m01[3], m23[1], m23[3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 sv = *reinterpret_cast<const f32x4*>(&sums[((size_t)b * C + cv + j) * 4]);
+                mean[v][j] = mn[j];
+                k[v][j] = rs[j] * g[j];
+                Am[v][j] = sv[0] * inv_p;
+                Qm[v][j] = sv[1] * inv_p * rs[j];                // xh = (p - mean) * rstd folded: xh * Qm = (p - mean) * (Qm * rstd)
+                if (blockIdx.x == 0 && pl == 0) {
+                    atomicAdd(&dbeta[cv + j], sv[0]);
+                    atomicAdd(&dgamma[cv + j], sv[1]);
+                }
+            }
+        }
+        const int p0 = blockIdx.x * chunk, p1 = p0 + chunk < P ? p0 + chunk : P;
+        const size_t xbase = (size_t)b * P * xC + c;
+        for (int i = p0 + pl; i < p1; i += NB_ROWS) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(&x[xbase + (size_t)i * xC]);
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+            if (acc_in) r = *reinterpret_cast<const f32x4*>(&acc_in[xbase + (size_t)i * xC]);
+            for (int v = 0; v < NV; ++v) {
+                const f32x4 d = *reinterpret_cast<const f32x4*>(&(v == 0 ? dy : dy1)[xbase + (size_t)i * xC]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float pc = eab_prelu(xv[j], a[v][j]) - mean[v][j];
+                    const float dp = k[v][j] * (d[j] - Am[v][j] - pc * Qm[v][j]);
+                    r[j] += xv[j] > 0.f ? dp : a[v][j] * dp;
+                    S[v][j] += xv[j] > 0.f ? 0.f : dp * xv[j];
+                }
+            }
+            *reinterpret_cast<f32x4*>(&dx[xbase + (size_t)i * xC]) = r;
+        }
+    }
+    red[0][pl][cl] = S[0];
+    red[1][pl][cl] = S[1];
+    __syncthreads();
+    if (pl < NV && c < xC) {
+        f32x4 t = red[pl][0][cl];
+#pragma unroll
+        for (int kk = 1; kk < NB_ROWS; ++kk) t += red[pl][kk][cl];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(&dslope[c + pl * xC + j], t[j]);
+    }
+}
+
 __global__ __launch_bounds__(64) void norm_bwd_params_kernel(const float* __restrict__ sums, int B, int C, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, float* __restrict__ dslope) {
     const int c = blockIdx.x * 64 + threadIdx.x;
@@ -399,13 +489,35 @@ extern "C" int eab_train_norm_bwd_f32(const float* dy, const float* x, const flo
     // (a kernel, not hipMemsetAsync: memset nodes of a captured graph were not reliably ordered on this stack)
     if (!zeroed)
         hipLaunchKernelGGL(tr_zero_kernel, dim3((B * C + TR_THREADS - 1) / TR_THREADS), dim3(TR_THREADS), 0, s, sums, (long long)B * C);
-    hipLaunchKernelGGL(norm_bwd_reduce_kernel, grid, dim3(TR_THREADS), 0, s, dy, x, mr, gamma, beta, slope, sums, P, C, mode, chunk);
+    hipLaunchKernelGGL(norm_bwd_reduce_kernel, grid, dim3(TR_THREADS), 0, s, dy, x, mr, gamma, beta, slope, sums, P, C, mode, chunk, C,
+                       nullptr);
     // parameter gradients inside the apply pass: always for NORM_PRELU (all three sums are final after the reduce pass); for
     // PRELU_NORM when its slope sums can go straight into dslope (<= 256 workgroups per address: the S-TCN's slabs)
     const bool merged = mode == EAB_XF_NORM_PRELU || (long long)grid.x * B <= 256;
     hipLaunchKernelGGL(norm_bwd_apply_kernel, grid, dim3(TR_THREADS), 0, s, dy, x, mr, gamma, beta, slope, sums, acc_in, dx,
                        merged ? dgamma : nullptr, dbeta, dslope, P, C, mode, chunk);
     if (!merged) hipLaunchKernelGGL(norm_bwd_params_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, B, C, dgamma, dbeta, dslope);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
+// Backward of the two one-dimensional units (PRELU_NORM order) that read the same xC-channel tensor x (the branch norms of a
+// SqueezedTCM, forward: eab_train_in1d_multi_f32): dy0 / dy1 = the views' output gradients, each [B][P][xC]; mr, gamma, slope,
+// sums and the parameter gradients are [..][2 xC] (view-major); dx [B][P][xC] = (acc_in) + both input gradients.
+// sums must be zero on entry.  Two launches.
+extern "C" int eab_train_norm_bwd_multi_f32(const float* dy0, const float* dy1, const float* x, const float* mr, const float* gamma,
+                                            const float* slope, float* sums, const float* acc_in, float* dx, float* dgamma,
+                                            float* dbeta, float* dslope, int B, int P, int xC, eab_stream_t stream) {
+    EAB_CHECK_ARG(dy0 && dy1 && x && mr && gamma && slope && sums && dx && dgamma && dbeta && dslope);
+    EAB_CHECK_ARG(B > 0 && P > 0 && xC > 0 && (xC % 4) == 0 && B <= 65535);
+    const int C = 2 * xC;
+    const float* const dy = dy0;
+    const float* const beta = gamma;            // (not read in the PRELU_NORM order)
+    const int chunk = nb_chunk(P, B, C);
+    hipStream_t s = eab_stream(stream);
+    hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3((P + chunk - 1) / chunk, (C + 63) / 64, B), dim3(TR_THREADS), 0, s, dy, x, mr, gamma,
+                       beta, slope, sums, P, C, EAB_XF_PRELU_NORM, chunk, xC, dy1);
+    hipLaunchKernelGGL(norm_bwd_apply_multi_kernel, dim3((P + chunk - 1) / chunk, (xC + 63) / 64, B), dim3(TR_THREADS), 0, s, dy, dy1, x,
+                       mr, gamma, slope, sums, acc_in, dx, dgamma, dbeta, dslope, P, C, xC, chunk);
     EAB_RETURN_LAUNCH_STATUS();
 }
 

@@ -477,6 +477,34 @@ class TrainLowering:
         self.tape.append(self._norm_back(name, raw, out, None, norm, act, XF_PRELU_NORM, mr, gam, bet, slp, P))
         return out
 
+    def in1d_multi(self, name: str, raw: TVar, norms: Sequence[str], acts: Sequence[str]) -> List[TVar]:
+        """Two units prelu -> InstanceNorm1d on the SAME input (the branch norms of an S-TCM): one forward launch writing two
+        contiguous tensors, one two-launch backward that sums both input gradients"""
+        assert len(norms) == 2 and len(acts) == 2
+        C = raw.C * 2
+        P = self.T * raw.F
+        n = self.B * P * raw.C
+        xf, mr = self.alloc(self.B * C * 2), self.alloc(self.B * C * 2)
+        base = self.alloc(2 * n)                                            # view v at base + v * n
+        outs = [TVar(Ref("a", base.off + v * n), raw.F, raw.C) for v in range(2)]
+        img_g = np.concatenate([self.idx(f"{k}.norm.weight") for k in norms])
+        img_b = np.concatenate([self.idx(f"{k}.norm.bias") for k in norms])
+        img_s = np.concatenate([self.idx(f"{k}.weight") for k in acts])
+        gam, bet, slp = self.wadd(name + ".gamma", img_g), self.wadd(name + ".beta", img_b), self.wadd(name + ".slope", img_s)
+        self.fwd.append(GenOp(OP_IN_STATS, [raw.ref, slp, gam, bet, xf, mr, base], [self.B, P, C, raw.C], [EPS_IN], name=name))
+
+        def back():
+            d0, d1 = self.grad_of(outs[0]), self.grad_of(outs[1])
+            dst, aux = self.grad_target(raw)
+            sums = Ref("g", self.g_size)                                     # zero-filled with the gradient arena
+            self.g_size += self.B * C * 4 + ((-self.B * C * 4) % ALIGN)
+            # (p[4], beta in the one-view form, carries the second view's gradient here: the PRELU_NORM backward never reads beta)
+            self.bwd.append(GenOp(OP_NORM_BWD, [d0, raw.ref, mr, gam, d1, slp, sums, aux, dst, self.gadd([img_g]), self.gadd([img_b]),
+                                                self.gadd([img_s])], [self.B, P, C, XF_PRELU_NORM | NB_SUMS_ZEROED, raw.C],
+                                  name=name + ".bwd"))
+        self.tape.append(back)
+        return outs
+
     def tcm(self, pre: str, x: TVar, dilation: int, x_acc: Optional[Ref], perm: np.ndarray) -> TVar:
         """SqueezedTCM.forward, EaBNet.py:572-578.  The closures go on the tape in forward order (they bind their
         operands late): in_conv | left norm | right norm | branch convs + gate | out norm | out_conv."""
@@ -486,8 +514,10 @@ class TrainLowering:
         w_in = self.idx(f"{pre}.in_conv.weight")[:, perm, :]                 # (cd, D, 1)
         y, back_in = self.conv1d(f"{pre}.in_conv", x, w_in, [0], None, prg.EPI_LINEAR, wname=f"{pre}.in_conv")
         self.tape.append(lambda: back_in(self.grad_of(y)))
-        yL = self.in1d(f"{pre}.left", y, f"{pre}.left_conv.1", f"{pre}.left_conv.0")
-        yR = self.in1d(f"{pre}.right", y, f"{pre}.right_conv.1", f"{pre}.right_conv.0")
+        # both branch norms read y: one launch normalises it twice (eab_train_in1d_multi_f32, two contiguous outputs) and one
+        # two-launch backward sums the two input gradients into dy
+        yL, yR = self.in1d_multi(f"{pre}.lr", y, [f"{pre}.left_conv.1", f"{pre}.right_conv.1"],
+                                 [f"{pre}.left_conv.0", f"{pre}.right_conv.0"])
         span = (kd - 1) * dilation
         lead = span if cfg.is_causal else span // 2
         dts = [j * dilation - lead for j in range(kd)]

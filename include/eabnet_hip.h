@@ -425,6 +425,11 @@ int eab_train_in_stats_f32(const float* x, const float* slope, int B, int P, int
  * y [B][P][C] (EaBNet.py:545-547: nn.PReLU -> NormSwitch 1-D).  One workgroup per (b, 64 channels), two passes. */
 int eab_train_in1d_f32(const float* x, const float* slope, int B, int P, int C, float eps, const float* gamma,
                        const float* beta, float* xf, float* mr, float* y, eab_stream_t stream);
+/* Several such units on ONE input in one launch: output channel c (of C = k * xC) normalises prelu(x[..][c % xC], slope[c]) -- the
+ * left and right branch norms of a SqueezedTCM (EaBNet.py:545-547, 559-560); view v = c / xC is written to its own contiguous
+ * tensor y + v * B*P*xC; xf, mr [B][C][2]. */
+int eab_train_in1d_multi_f32(const float* x, const float* slope, int B, int P, int C, int xC, float eps, const float* gamma,
+                             const float* beta, float* xf, float* mr, float* y, eab_stream_t stream);
 /* eab_in_finalize_f32 that also emits mr0 / mr1 [B][C][2] = (mean, rstd) for the backward pass (NULL = skip) */
 int eab_in_finalize_mr_f32(const float* stats, int B, int C, int nsets, int stat_tiles, int count, float eps,
                            const float* gamma0, const float* beta0, float* xf0, const float* gamma1,
@@ -441,6 +446,12 @@ int eab_train_norm_act_f32(const float* x, const float* xf, const float* slope, 
 int eab_train_norm_bwd_f32(const float* dy, const float* x, const float* mr, const float* gamma, const float* beta,
                            const float* slope, float* sums, const float* acc_in, float* dx, float* dgamma, float* dbeta,
                            float* dslope, int B, int P, int C, int mode, eab_stream_t stream);
+/* The same for the TWO units of the EAB_XF_PRELU_NORM order that read ONE xC-channel tensor x (forward:
+ * eab_train_in1d_multi_f32): dy0 / dy1 [B][P][xC] = the views' output gradients; mr, gamma, slope, sums, dgamma, dbeta, dslope
+ * [..][2 xC] view-major; dx [B][P][xC] = (acc_in) + both input gradients.  sums must be zero on entry. */
+int eab_train_norm_bwd_multi_f32(const float* dy0, const float* dy1, const float* x, const float* mr, const float* gamma,
+                                 const float* slope, float* sums, const float* acc_in, float* dx, float* dgamma, float* dbeta,
+                                 float* dslope, int B, int P, int xC, eab_stream_t stream);
 /* GLU backward (EaBNet.py:459-460, 489-490): dy [rows][N/2], dump [rows][N] (eab_conv_desc.glu_dump) -> dz [rows][N]
  * in the packed column order of the forward convolution */
 int eab_glu_bwd_f32(const float* dy, const float* dump, float* dz, long long rows, int N, eab_stream_t stream);
@@ -486,10 +497,11 @@ int eab_wgrad_batch_f32(const eab_wgrad_desc* descs, int n, int stride_bytes, ea
 
 /* op kinds of the training programs (eab_run_program); field use:
  *  GATHER       p = {flat, ia, ib, out}                 i = {n_lo, n_hi}
- *  IN_STATS     p = {x, slope, gamma, beta, xf, mr, y}  i = {B, P, C}          f = {eps}     (y != NULL: eab_train_in1d_f32)
+ *  IN_STATS     p = {x, slope, gamma, beta, xf, mr, y}  i = {B, P, C, xC}      f = {eps}     (y != NULL: eab_train_in1d_f32; xC > 0: _multi_)
  *  IN_FINALIZE  as before, plus p[7], p[8] = mr0, mr1
  *  TR_NORM_ACT  p = {x, xf, slope, add, y}              i = {B, P, C, mode}
- *  NORM_BWD     p = {dy, x, mr, gamma, beta, slope, sums, acc_in, dx, dgamma, dbeta, dslope}   i = {B, P, C, mode}
+ *  NORM_BWD     p = {dy, x, mr, gamma, beta, slope, sums, acc_in, dx, dgamma, dbeta, dslope}   i = {B, P, C, mode, xC}
+ *               (xC > 0: eab_train_norm_bwd_multi_f32 with p[4] = dy1 instead of beta)
  *  GLU_BWD      p = {dy, dump, dz}                      i = {rows_lo, rows_hi, N}
  *  GATE_FWD     p = {a, r, z}        GATE_BWD p = {dz, a, r, da, dr}       i = {n_lo, n_hi}
  *  ADD          p = {a, b, out}      RELU_BWD p = {dy, y, dx}              i = {n_lo, n_hi}
