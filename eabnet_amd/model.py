@@ -133,7 +133,10 @@ class _Bound:
                 self.run(side.cuda_stream)
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: other threads of the process (RCCL's watchdog under DistributedDataParallel, a data loader) may
+            # issue HIP calls while this thread captures; in the default global mode such a call invalidates the capture and the
+            # other thread aborts the process
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.run(torch.cuda.current_stream().cuda_stream)
             self.graph = g
         except Exception as e:                            # noqa: BLE001 - any capture failure -> direct launches

@@ -787,7 +787,10 @@ class TrainBound:
             graphs = []
             for which in ("fwd", "bwd"):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # thread_local: other threads of the process (RCCL's watchdog under DistributedDataParallel, a data loader) may
+                # issue HIP calls while this thread captures; in the default global mode such a call invalidates the capture and the
+                # other thread aborts the process
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self.run(which, torch.cuda.current_stream().cuda_stream)
                 graphs.append(g)
             self.graphs = tuple(graphs)
