@@ -1,0 +1,96 @@
+"""Host-side invariants of the training lowering (eabnet_amd/train.py); no GPU.
+
+The backward program emits every weight gradient at its END (sorted by geometry so that eab_run_program can serve runs of
+identical geometry with one launch).  That is only correct if a weight gradient's operands are final when their producer
+has run and are never written again: checked here on the op lists themselves, for the benchmark shape and a small one."""
+from dataclasses import replace
+
+import numpy as np
+import pytest
+
+from eabnet_amd import program as prg
+from eabnet_amd import spec, train
+
+
+def _writes(op):
+    """Refs an op writes (arena, offset)"""
+    k = op.kind
+    if k == prg.OP_CONV:
+        out = [op.dst, op.dst_acc, op.stats, getattr(op, "glu_dump", None)]
+    elif k == prg.OP_IN_FINALIZE:
+        out = [op.xf0, op.xf1, getattr(op, "mr0", None), getattr(op, "mr1", None)]
+    elif k == prg.OP_MEMSET0:
+        out = [op.ptr]
+    elif k == train.OP_WGRAD:
+        out = [op.dw, op.dbias]
+    else:
+        p = list(op.p) + [None] * 12
+        out = {train.OP_GATHER: [p[3]], train.OP_IN_STATS: [p[4], p[5], p[6]], train.OP_TR_NORM_ACT: [p[4]],
+               train.OP_NORM_BWD: [p[6], p[8], p[9], p[10], p[11]], train.OP_GLU_BWD: [p[2]], train.OP_GATE_FWD: [p[2]],
+               train.OP_GATE_BWD: [p[3], p[4]], train.OP_ADD: [p[2]], train.OP_RELU_BWD: [p[2]], train.OP_COLSUM: [p[1]],
+               train.OP_FILTER_SUM: [p[2]], train.OP_FS_BWD: [p[2]], train.OP_LN_FWD: [p[3], p[4]],
+               train.OP_LN_BWD: [p[4], p[5], p[6]], train.OP_LSTM_TRAIN: [p[3], p[4]], train.OP_LSTM_BWD: [p[3]]}[k]
+    res = [(r.arena, r.off) for r in out if r is not None]
+    if k == train.OP_IN_STATS and len(op.i) > 3 and op.i[3] and op.p[6] is not None:
+        B, P, C, xC = op.i[:4]                               # several views, one contiguous tensor each behind p[6]
+        res += [(op.p[6].arena, op.p[6].off + v * B * P * xC) for v in range(1, C // xC)]
+    return res
+
+
+@pytest.mark.parametrize("M,B,T,pq", [(8, 6, 601, (6, 3)), (9, 2, 24, (2, 2))])
+def test_deferred_weight_gradients_read_final_buffers(M, B, T, pq):
+    cfg = replace(spec.NetConfig(), M=M, p=pq[0], q=pq[1])
+    prog = train.lower_train(cfg, B, T)
+    bwd = prog.bwd
+    first_w = next(k for k, o in enumerate(bwd) if o.kind == train.OP_WGRAD)
+    assert all(o.kind == train.OP_WGRAD for o in bwd[first_w:]), "weight gradients are the tail of the backward program"
+    assert all(o.kind != train.OP_WGRAD for o in bwd[:first_w])
+    fwd_written = {w for o in prog.fwd for w in _writes(o)}
+    # last writer of every buffer the backward program writes (activation arena; accumulate-in-place counts as a write)
+    writes = {}
+    for k, o in enumerate(bwd[:first_w]):
+        for w in _writes(o):
+            writes.setdefault(w, []).append(k)
+    for o in bwd[first_w:]:
+        dz = (o.dz.arena, o.dz.off)
+        assert dz in writes or dz[0] == "dout", f"{o.name}: its output gradient is produced by nobody"
+        # the op that the lowering emitted right behind the gradient's producer would have read dz after writes[dz][-1] only
+        # if nobody writes it again: every write of dz must come from ONE producer chain (first write, then in-place
+        # accumulations by later contributions), all of them before any reader -- i.e. no write after the first reader.
+        readers = [k for k, q in enumerate(bwd[:first_w])
+                   if q.kind == prg.OP_CONV and (q.src0.arena, q.src0.off) == dz]          # its dgrad launches read dz too
+        if readers and dz in writes:
+            assert max(writes[dz]) < min(readers), f"{o.name}: dz is written after its dgrad has read it"
+        elif dz in writes:                                  # no input gradient wanted (first convolution): one producer, one write
+            assert len(writes[dz]) == 1, f"{o.name}: dz has several writers and no reader to order them against"
+        for src in (o.src0, o.src1):
+            if src is None:
+                continue
+            s = (src.arena, src.off)
+            assert s not in writes, f"{o.name}: forward activation {s} is written by the backward program"
+            assert s in fwd_written or s[0] == "in", f"{o.name}: operand {s} is written by nobody"
+
+
+def test_weight_gradients_batch_into_few_launches():
+    """identical geometries are adjacent (what eab_wgrad_batchable looks for): 153 descriptors -> 38 launches at the
+    benchmark shape"""
+    prog = train.lower_train(replace(spec.NetConfig(), M=8), 6, 601)
+
+    def geo(o):
+        return (o.N, o.C0, o.C1, o.Kpad, o.Fin, o.Fz, o.No, o.ostride, o.ophase, o.istride, tuple(o.dt), tuple(o.ioff),
+                o.src1 is None, o.dbias is None, o.precision)
+    w = [o for o in prog.bwd if o.kind == train.OP_WGRAD]
+    runs, prev, run = 0, None, 0
+    seen = set()
+    for o in w:
+        g = geo(o)
+        if g == prev and run < 24:
+            run += 1
+        else:
+            assert g not in seen or run == 24, "a geometry appears in two separate runs"
+            runs, run = runs + 1, 1
+        seen.add(g)
+        prev = g
+    assert len(w) == 153 and runs == 38
+    # every parameter element receives exactly one gradient entry (the inverse table is total on the trained parameters)
+    assert (np.asarray(prog.inv) >= 0).all()
