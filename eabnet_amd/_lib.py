@@ -86,6 +86,7 @@ _SIGS = {
                                             C.c_void_p]),
     "eab_gag_pack_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [TimeWindow, C.c_void_p]),
     "eab_gag_crm_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 6 + [TimeWindow, C.c_void_p]),
+    "eab_gag_crm_bwd_f32": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 6 + [C.c_void_p]),
     "eab_conv_tiles": (C.c_int, [C.c_int] * 3),
     "eab_conv_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "eab_conv_bf16": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),

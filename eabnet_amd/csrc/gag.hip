@@ -87,3 +87,62 @@ extern "C" int eab_gag_crm_f32(const float* pre, const float* g, const float* r,
                        r, i, pre_out, planar, T, F, ld, lin_ld, act, win.pos, win.count);
     EAB_RETURN_LAUNCH_STATUS();
 }
+
+// Backward of gag_crm_kernel (training of the post-filter): y = pre * gain(g) + (r, i) per TF bin, y feeding both the stage
+// output (planar) and the next module's pre.
+//   dy   = d planar[b][:][t][f] + d pre_out[b][t][2f..]        (either may be NULL)
+//   dg   = (dy.re pre.re + dy.im pre.im) * gain'(g),  dr = dy.re,  di = dy.im        [B][T][lin_ld], padding columns zeroed
+//   dpre = (acc_in) + dy * gain                                 [B][T][ld]            (NULL: not wanted)
+__global__ __launch_bounds__(GAG_THREADS) void gag_crm_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ g,
+                                                                  const float* __restrict__ dplanar, const float* __restrict__ dpre_out,
+                                                                  const float* __restrict__ acc_in, float* __restrict__ dg,
+                                                                  float* __restrict__ dr, float* __restrict__ di,
+                                                                  float* __restrict__ dpre, int T, int F, int ld, int lin_ld, int act) {
+    const int b = blockIdx.x / T, t = blockIdx.x - b * T;
+    const int bt = blockIdx.x;
+    const size_t plane = (size_t)T * F;
+    const float* d_r = dplanar ? dplanar + ((size_t)b * 2) * plane + (size_t)t * F : nullptr;
+    const int nf = ld / 2 > lin_ld ? ld / 2 : lin_ld;
+    for (int f = threadIdx.x; f < nf; f += GAG_THREADS) {
+        float2 dy = make_float2(0.0f, 0.0f), dp = make_float2(0.0f, 0.0f);
+        float dgv = 0.0f;
+        if (f < F) {
+            if (d_r) dy = make_float2(d_r[f], d_r[plane + f]);
+            if (dpre_out) {
+                const float2 q = *reinterpret_cast<const float2*>(&dpre_out[(size_t)bt * ld + 2 * f]);
+                dy.x += q.x;
+                dy.y += q.y;
+            }
+            const float2 p = *reinterpret_cast<const float2*>(&pre[(size_t)bt * ld + 2 * f]);
+            const float gv = g[(size_t)bt * lin_ld + f];
+            const float gain = gag_act(gv, act);
+            const float dact = act == EAB_ACT_SIGMOID ? gain * (1.0f - gain) : act == EAB_ACT_TANH ? 1.0f - gain * gain : (gv > 0.0f ? 1.0f : 0.0f);
+            dgv = (dy.x * p.x + dy.y * p.y) * dact;
+            dp = make_float2(dy.x * gain, dy.y * gain);
+        }
+        if (f < lin_ld) {
+            dg[(size_t)bt * lin_ld + f] = dgv;
+            dr[(size_t)bt * lin_ld + f] = dy.x;
+            di[(size_t)bt * lin_ld + f] = dy.y;
+        }
+        if (dpre && 2 * f < ld) {
+            if (acc_in) {
+                const float2 q = *reinterpret_cast<const float2*>(&acc_in[(size_t)bt * ld + 2 * f]);
+                dp.x += q.x;
+                dp.y += q.y;
+            }
+            *reinterpret_cast<float2*>(&dpre[(size_t)bt * ld + 2 * f]) = dp;
+        }
+    }
+}
+
+extern "C" int eab_gag_crm_bwd_f32(const float* pre, const float* g, const float* dplanar, const float* dpre_out, const float* acc_in,
+                                   float* dg, float* dr, float* di, float* dpre, int B, int T, int F, int ld, int lin_ld, int act,
+                                   eab_stream_t stream) {
+    EAB_CHECK_ARG(pre && g && dg && dr && di && (dplanar || dpre_out) && B > 0 && T > 0 && F > 0);
+    EAB_CHECK_ARG(ld >= 2 * F && (ld % 4) == 0 && lin_ld >= F && (long long)B * T < (1ll << 31));
+    EAB_CHECK_ARG(act == EAB_ACT_SIGMOID || act == EAB_ACT_TANH || act == EAB_ACT_RELU);
+    hipLaunchKernelGGL(gag_crm_bwd_kernel, dim3(B * T), dim3(GAG_THREADS), 0, eab_stream(stream), pre, g, dplanar, dpre_out, acc_in, dg,
+                       dr, di, dpre, T, F, ld, lin_ld, act);
+    EAB_RETURN_LAUNCH_STATUS();
+}

@@ -707,6 +707,14 @@ class GaGNet(_HipModule):
         if inpt.ndim != 4 or inpt.shape[1] != 2 or inpt.shape[3] != self.cfg.freq or pre_x.shape != inpt.shape:
             raise ValueError(f"expected two (B,2,T,{self.cfg.freq}) tensors, got {tuple(inpt.shape)} and {tuple(pre_x.shape)}")
         if self._needs_graph(inpt, pre_x):
+            # training: the default topology with InstanceNorm runs forward AND backward on the hand-written kernels
+            # (train_gag.py); other constructor branches, a differentiable input (the reference detaches the beam-former's
+            # estimate, EaBNet.py:142) and CPU tensors take the PyTorch-ROCm operator path
+            from . import train_gag
+            if self.use_hip_training and inpt.is_cuda and pre_x.is_cuda and not inpt.requires_grad and not pre_x.requires_grad \
+                    and torch.is_grad_enabled() and train_gag.supported(self.cfg) and next(self.parameters()).is_cuda \
+                    and not (self.norm_type == "BN" and self.training):
+                return train_gag.forward_train(self, inpt, pre_x)
             from .autograd_path import forward_gagnet
             return forward_gagnet(self, inpt, pre_x)
         if not (inpt.is_cuda and pre_x.is_cuda):

@@ -114,16 +114,19 @@ def _split64(n: int) -> Tuple[int, int]:
 
 
 class TrainLowering:
-    def __init__(self, cfg: NetConfig, B: int, T: int, F: int = 161, precision: str = "f32"):
+    spec_fn = staticmethod(param_specs)              # parameter inventory of the network being lowered (subclasses: GaGNet)
+    supports = staticmethod(supported)
+
+    def __init__(self, cfg, B: int, T: int, F: int = 161, precision: str = "f32"):
         if precision not in ("f32", "bf16"):
             raise ValueError("training precision is 'f32' or 'bf16' (bf16: forward, dgrad and wgrad contractions on the bf16 "
                              "matrix cores with fp32 accumulation; LSTM, norms, gradients and the optimiser state stay fp32)")
         self.prec = prg.PREC_CODE[precision]
-        if not supported(cfg):
+        if not self.supports(cfg):
             raise NotImplementedError("the HIP training path covers the default topology with InstanceNorm")
         cfg.check_supported()
         self.cfg, self.B, self.T, self.F = cfg, B, T, F
-        self.specs = {k: s for k, s in param_specs(cfg).items() if s.kind != "bn_count"}
+        self.specs = {k: s for k, s in self.spec_fn(cfg).items() if s.kind != "bn_count"}
         self.poff: Dict[str, int] = {}
         n = 0
         for k, s in self.specs.items():
@@ -712,6 +715,8 @@ class TrainProgram:
     flops_fwd: int = 0
     flops_bwd: int = 0
     grad_taps: Dict[str, tuple] = field(default_factory=dict)       # name -> (Ref of d loss / d activation, F, C)
+    out_shape: Optional[tuple] = None        # shape of the 'out' / 'dout' arenas (default: the beam-former's (B, 2, T, F))
+    has_in2: bool = False                    # a second input arena 'in2' (the post-filter's previous estimate)
 
 
 def lower_train(cfg: NetConfig, B: int, T: int, F: int = 161, precision: str = "f32") -> TrainProgram:
@@ -739,7 +744,7 @@ class TrainBound:
         self.use_graph = True
         self.graphs = None                  # (forward hipGraph, backward hipGraph) on the static boundary buffers
         self.graph_failed = False
-        self.static_x = self.static_out = self.static_dout = None
+        self.static_x = self.static_x2 = self.static_out = self.static_dout = None
         # Backward lanes: a weight gradient is a leaf of the backward graph -- nothing reads dW before the step ends, its
         # operands (the finished gradient of a convolution output, a forward activation) are never written again
         # (TrainLowering never recycles a buffer) -- so every block of wgrad launches forks onto a side stream right after
@@ -774,9 +779,11 @@ class TrainBound:
         prog = self.prog
         try:
             self.static_x = torch.zeros(x_shape, dtype=torch.float32, device=self.device)
-            self.static_out = torch.zeros((prog.B, 2, prog.T, prog.F), dtype=torch.float32, device=self.device)
+            self.static_x2 = torch.zeros(x_shape, dtype=torch.float32, device=self.device) if prog.has_in2 else None
+            self.static_out = torch.zeros(prog.out_shape or (prog.B, 2, prog.T, prog.F), dtype=torch.float32, device=self.device)
             self.static_dout = torch.zeros_like(self.static_out)
-            self.bind(self.static_x.data_ptr(), self.static_out.data_ptr(), self.static_dout.data_ptr())
+            self.bind(self.static_x.data_ptr(), self.static_out.data_ptr(), self.static_dout.data_ptr(),
+                      self.static_x2.data_ptr() if prog.has_in2 else None)
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                 # warm-up outside the capture (weights are packed already)
@@ -800,11 +807,11 @@ class TrainBound:
             self.graphs, self.graph_failed, self._bound = None, True, None
         return self.graphs is not None
 
-    def bind(self, in_ptr: int, out_ptr: int, dout_ptr: int) -> None:
-        if self._bound == (in_ptr, out_ptr, dout_ptr):
+    def bind(self, in_ptr: int, out_ptr: int, dout_ptr: int, in2_ptr: Optional[int] = None) -> None:
+        if self._bound == (in_ptr, out_ptr, dout_ptr, in2_ptr):
             return
         bases = {"a": self.acts.data_ptr(), "w": self.w.data_ptr(), "g": self.g.data_ptr(), "in": in_ptr, "out": out_ptr,
-                 "dout": dout_ptr}
+                 "dout": dout_ptr, "in2": in2_ptr}
 
         def A(r):
             return None if r is None else bases[r.arena] + 4 * r.off
@@ -855,7 +862,7 @@ class TrainBound:
                         o.i[j] = C.c_int32(int(v) & 0xFFFFFFFF).value if v > 0x7FFFFFFF else int(v)
                     for j, v in enumerate(op.f):
                         o.f[j] = float(v)
-        self._bound = (in_ptr, out_ptr, dout_ptr)
+        self._bound = (in_ptr, out_ptr, dout_ptr, in2_ptr)
 
     def run(self, which: str, stream: int, first: int = 0, count: Optional[int] = None) -> None:
         arr = self.fwd if which == "fwd" else self.bwd

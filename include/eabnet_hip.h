@@ -117,6 +117,12 @@ int eab_gag_pack_f32(const float* inpt, const float* pre_x, float* enc_in, float
 int eab_gag_crm_f32(const float* pre, const float* g, const float* r, const float* i, float* pre_out,
                     float* planar, int B, int T, int F, int ld, int lin_ld, int act, eab_time_window win,
                     eab_stream_t stream);
+/* Backward of eab_gag_crm_f32 (training of the post-filter; autograd of GaGNet.py:127-133 in its pre*gain + residual form):
+ * dplanar [B][2][T][F] = gradient of the stage output, dpre_out [B][T][ld] = gradient of the next module's pre (either may be
+ * NULL); dg, dr, di [B][T][lin_ld] (padding columns zeroed); dpre [B][T][ld] = (acc_in) + the gradient w.r.t. pre (NULL: skip). */
+int eab_gag_crm_bwd_f32(const float* pre, const float* g, const float* dplanar, const float* dpre_out, const float* acc_in,
+                        float* dg, float* dr, float* di, float* dpre, int B, int T, int F, int ld, int lin_ld, int act,
+                        eab_stream_t stream);
 
 /* --------------------------------------------------------------------------
  * Training loss, value and gradient in one pass (first piece).  Replaces com_mag_mse_loss
@@ -511,6 +517,7 @@ int eab_wgrad_batch_f32(const eab_wgrad_desc* descs, int n, int stride_bytes, ea
  *  LN_BWD       p = {dy, x, mr, g, dx, dg, db}          i = {rows_lo, rows_hi}
  *  LSTM_TRAIN   p = {x, wcat, bias, h_out, gates}       i = {B, T, F}
  *  LSTM_BWD     p = {gates, dh_out, wcat, dgates}       i = {B, T, F}
+ *  GAG_CRM_BWD  p = {pre, g, dplanar, dpre_out, acc_in, dg, dr, di, dpre}   i = {B, T, F, ld, lin_ld, act}
  *  WGRAD        the `wgrad` member */
 #define EAB_OP_GATHER      16
 #define EAB_OP_IN_STATS    17
@@ -555,6 +562,7 @@ int eab_gate_rows_f32(const float* a, const float* r, float* z, int B, int T, in
 #define EAB_OP_CLN_STATS 33
 #define EAB_OP_CLN_APPLY 34
 #define EAB_OP_GATE_ROWS 35
+#define EAB_OP_GAG_CRM_BWD 36
 
 /* struct-layout handshake for foreign-function mirrors of the structs above */
 int eab_sizeof_conv_desc(void);

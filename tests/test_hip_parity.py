@@ -1176,6 +1176,55 @@ def test_hip_training_gradients_vs_oracle_autograd(dev, M, B, T, pq, smooth):
         assert acts["bf_w"] <= 1e-4 and acts["de.4"] <= max(1e-4, 4.0 * floor)
 
 
+@pytest.mark.parametrize("smooth", [True, False])
+def test_hip_training_of_the_post_filter_vs_oracle_autograd(dev, smooth):
+    """GaGNet(inpt, pre_x) under autograd runs the two HIP training programs of eabnet_amd/train_gag.py: the forward equals
+    the inference program's output and loss.backward() (stage-wise loss, GaGNet.py:601-619) gives every parameter the
+    gradient fp64 autograd through the oracle gives.  smooth / non-smooth as in the beam-former's test above."""
+    import eabnet_amd
+    from oracle import eabnet_oracle as orc
+    kw = dict(p=1, q=2, dilas=[1, 2])
+    net, P = _gag_model(kw, 960, dev)
+    if smooth:
+        for k, sp in eabnet_amd.gag_param_specs(net.cfg).items():
+            if sp.kind == "prelu":
+                P[k] = torch.ones_like(P[k])
+        net.load_state_dict(P, strict=True)
+    B, T = 2, 26
+    inpt, pre_x = _planar(B, T, 961), _planar(B, T, 962)
+    label = _planar(B, T, 963).permute(0, 1, 3, 2).contiguous()              # (B,2,F,T)
+    frames = [T] * B
+    with torch.no_grad():
+        y_inf = net(inpt.to(dev), pre_x.to(dev))
+    net.train()
+    outs = net(inpt.to(dev), pre_x.to(dev))
+    assert outs[0].requires_grad and getattr(net, "_train_bound", None), "the HIP training path did not engage"
+    for a, b in zip(outs, y_inf):
+        assert_close(a.detach().cpu().numpy(), b.cpu().numpy(), 1e-5, "training forward vs inference program")
+    loss = eabnet_amd.stagewise_com_mag_mse_loss(outs, label.to(dev), frames)
+    loss.backward()
+
+    def oracle_grads(dtype):
+        Pd = {k: v.to(dtype).requires_grad_(True) for k, v in P.items()}
+        lo = orc.stagewise_com_mag_mse_loss(orc.gagnet_forward(Pd, inpt.to(dtype), pre_x.to(dtype), kd1=3, **kw), label.to(dtype), frames)
+        lo.backward()
+        return float(lo.detach()), {k: v.grad.double() for k, v in Pd.items()}
+    ref_loss, ref = oracle_grads(torch.float64)
+    assert abs(float(loss) - ref_loss) <= 1e-5 * abs(ref_loss)
+    got = {k: net.get_parameter(k).grad.cpu().double() for k in ref}
+    assert all(torch.isfinite(g).all() for g in got.values())
+    total, per = _grad_errors(got, ref)
+    print(f"post-filter, smooth={smooth}: parameter gradients global l2-rel {total:.2e}, worst tensor {max(per.values()):.2e}")
+    if smooth:
+        bad = sorted(((e, k) for k, e in per.items() if e > 1e-4), reverse=True)
+        assert total <= 1e-4 and not bad, f"global l2-rel {total:.3e}; tensors over 1e-4: {bad[:8]}"
+    else:
+        _, g32 = oracle_grads(torch.float32)
+        floor, _ = _grad_errors(g32, ref)
+        print(f"   reference fp32 autograd vs fp64: global l2-rel {floor:.2e}")
+        assert total <= max(1e-4, 4.0 * floor), f"global l2-rel {total:.3e} vs the reference's own fp32 floor {floor:.3e}"
+
+
 def test_hip_training_step_matches_operator_path(dev):
     """One optimiser step of the reference's loop (train_distributed.py:218-230: forward, loss, backward, clip, Adam)
     on the HIP training programs against the same step on the PyTorch-ROCm operator path (autograd_path.py): same
