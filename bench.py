@@ -147,8 +147,8 @@ def main_train(a, rank, world, dev, is_dist):
     if a.train_two_stage:
         assert world == 1, "--train-two-stage is a single-GPU comparison line"
         # the model train_distributed.py:181 actually builds: beam-former + GaGNet post-filter, both trained
-        # (eabnet_with_postnet_loss, :225).  The beam-former stage runs on the HIP training programs, the post-filter (fed
-        # esti0.detach(), EaBNet.py:142) on PyTorch-ROCm operators: its training lowering is not built yet.
+        # (eabnet_with_postnet_loss, :225), the post-filter fed esti0.detach() (EaBNet.py:142).  Both stages run on their HIP
+        # training programs (train.py, train_gag.py); --train-operator-path puts both on PyTorch-ROCm operators.
         pa = argparse.Namespace(
             k1=(2, 3), k2=(1, 3), c=64, M=M, embed_dim=64, kd1=5, cd1=64, d_feat=256, p=6, q=3, is_causal=True, is_u2=True,
             bf_type="lstm", topo_type="mimo", intra_connect="cat", norm_type="IN", ref_mic=0, freeze_eabnet=False,
@@ -158,8 +158,8 @@ def main_train(a, rank, world, dev, is_dist):
         torch.manual_seed(1)
         two = eabnet_amd.make_eabnet_with_postnet(pa).to(dev).train()
         two.eabnet.load_state_dict(net.state_dict(), strict=True)
-        two.eabnet.use_hip_training = net.use_hip_training
-        two.eabnet.precision = net.precision
+        two.eabnet.use_hip_training = two.postnet.use_hip_training = net.use_hip_training
+        two.eabnet.precision = two.postnet.precision = net.precision
         net = two.eabnet
     pd_args = argparse.Namespace(mics=M, sr=SR, wav_len=seconds, win_size=0.020, win_shift=0.010, fft_num=N_FFT)
     wav = synth_waves(B, M, L, 1234 + rank).to(dev)
@@ -206,9 +206,10 @@ def main_train(a, rank, world, dev, is_dist):
     frames = world * B * T * a.steps
     if a.train_two_stage:
         if rank == 0:
-            print(json.dumps({"mode": "training step of the two-stage model (train_distributed.py:181,225): beam-former on the HIP "
-                                      "training programs" + (" (operator path)" if a.train_operator_path else "") +
-                                      ", GaGNet post-filter on PyTorch-ROCm operators: comparison line",
+            print(json.dumps({"mode": "training step of the two-stage model (train_distributed.py:181,225): beam-former and GaGNet "
+                                      "post-filter on " + ("PyTorch-ROCm operators (comparison line)" if a.train_operator_path else
+                                                           "their HIP training programs"),
+                              "dtype": net.precision,
                               "value": frames / elapsed, "unit": "frames/s (trained)", "n_gpus": world, "steps": a.steps,
                               "ms_per_step": 1e3 * elapsed / a.steps, "final_loss": float(loss.detach()),
                               "params": eabnet_amd.numParams(two)}))
@@ -357,8 +358,8 @@ def main():
                     help="BASELINE configs[3]: training step (prepare_data, forward, loss, backward, clip, Adam) on the HIP "
                          "training programs, per-GPU batch 6 x 6 s x 8 mics, one flat RCCL gradient all-reduce per step")
     ap.add_argument("--train-two-stage", action="store_true",
-                    help="with --train: the two-stage model of train_distributed.py (beam-former on the HIP training programs, "
-                         "post-filter on PyTorch-ROCm operators); a comparison line, not the training headline")
+                    help="with --train: the two-stage model of train_distributed.py (beam-former + GaGNet post-filter, both on "
+                         "their HIP training programs; single GPU)")
     ap.add_argument("--train-operator-path", action="store_true",
                     help="with --train: forward/backward on PyTorch-ROCm operators (autograd_path.py, MIOpen) -- the comparison line")
     ap.add_argument("--train-ddp", action="store_true", help="with --train: wrap in torch DistributedDataParallel (one 64 MB bucket, "

@@ -175,7 +175,9 @@ class _GagTrainFn(torch.autograd.Function):
     def forward(ctx, bound: TrainBound, inpt: torch.Tensor, pre_x: torch.Tensor, *params: torch.Tensor) -> torch.Tensor:
         prog = bound.prog
         st = torch.cuda.current_stream().cuda_stream
-        flat = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in params])
+        flat = torch.cat([p.detach().reshape(-1) for p in params])      # (one batched copy; fp32 parameters)
+        if flat.dtype != torch.float32:
+            flat = flat.to(torch.float32)
         bound.pack(flat, st)
         bound.serial += 1
         ctx.serial = bound.serial
@@ -219,11 +221,12 @@ class _GagTrainFn(torch.autograd.Function):
             import torch.distributed as td
             td.all_reduce(gflat, group=sync if sync is not True else None)
             gflat.div_(td.get_world_size(sync if sync is not True else None))
-        grads, off = [], 0
-        for k, shp in enumerate(ctx.shapes):
-            n = int(np.prod(shp)) if len(shp) else 1
-            grads.append(gflat[off:off + n].view(shp).to(ctx.dtypes[k]) if ctx.needs_input_grad[3 + k] else None)
-            off += n
+        # one split call + a view per parameter (the Python loop over ~500-800 parameters is on the step's critical path)
+        sizes = [int(np.prod(shp)) if len(shp) else 1 for shp in ctx.shapes]
+        grads = [g.view(shp) if dt == torch.float32 else g.view(shp).to(dt)
+                 for g, shp, dt in zip(gflat.split(sizes), ctx.shapes, ctx.dtypes)]
+        if not all(ctx.needs_input_grad[3:]):
+            grads = [g if need else None for g, need in zip(grads, ctx.needs_input_grad[3:])]
         return (None, None, None, *grads)
 
 
