@@ -145,7 +145,6 @@ def main_train(a, rank, world, dev, is_dist):
     net.precision = "bf16" if a.precision == "bf16" else "f32"
     two = None
     if a.train_two_stage:
-        assert world == 1, "--train-two-stage is a single-GPU comparison line"
         # the model train_distributed.py:181 actually builds: beam-former + GaGNet post-filter, both trained
         # (eabnet_with_postnet_loss, :225), the post-filter fed esti0.detach() (EaBNet.py:142).  Both stages run on their HIP
         # training programs (train.py, train_gag.py); --train-operator-path puts both on PyTorch-ROCm operators.
@@ -165,7 +164,12 @@ def main_train(a, rank, world, dev, is_dist):
     wav = synth_waves(B, M, L, 1234 + rank).to(dev)
     tgt = synth_waves(B, 1, L, 4321 + rank).to(dev)
     model = net
-    if is_dist:
+    if is_dist and two is not None:
+        # data-parallel two-stage training: one flat gradient all-reduce per stage and step (RCCL)
+        tr.broadcast_parameters(two)
+        tr.enable_flat_allreduce(two.eabnet)
+        tr.enable_flat_allreduce(two.postnet)
+    elif is_dist:
         tr.broadcast_parameters(net)
         if a.train_ddp:
             model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[dev.index], bucket_cap_mb=64,
@@ -359,7 +363,7 @@ def main():
                          "training programs, per-GPU batch 6 x 6 s x 8 mics, one flat RCCL gradient all-reduce per step")
     ap.add_argument("--train-two-stage", action="store_true",
                     help="with --train: the two-stage model of train_distributed.py (beam-former + GaGNet post-filter, both on "
-                         "their HIP training programs; single GPU)")
+                         "their HIP training programs; --gpus N: one flat RCCL all-reduce per stage and step)")
     ap.add_argument("--train-operator-path", action="store_true",
                     help="with --train: forward/backward on PyTorch-ROCm operators (autograd_path.py, MIOpen) -- the comparison line")
     ap.add_argument("--train-ddp", action="store_true", help="with --train: wrap in torch DistributedDataParallel (one 64 MB bucket, "

@@ -49,14 +49,15 @@ extern "C" int eab_gather_f32(const float* flat, const int32_t* ia, const int32_
 //   xf[b][c] = (gamma*rstd, beta - mean*gamma*rstd),  mr[b][c] = (mean, rstd).
 // grid (B, C/64), block 256 = 64 channels x 4 position lanes.
 // ---------------------------------------------------------------------------------------------------
-template <bool APPLY>
-__global__ __launch_bounds__(TR_THREADS) void in_stats_kernel(const float* __restrict__ x, const float* __restrict__ slope,
+template <bool APPLY, int NPL>
+__global__ __launch_bounds__(16 * NPL) void in_stats_kernel(const float* __restrict__ x, const float* __restrict__ slope,
                                                               int P, int C, float eps, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* __restrict__ xf,
                                                               float* __restrict__ mr, float* __restrict__ y, int xC) {
     // thread -> 4 channels (float4) x every 16th position; shifted sums (shift = the channel's first value, so a
     // nearly constant channel loses nothing to cancellation) in fp64, combined through LDS in a fixed order
-    __shared__ double red[2][16][64];
+    __shared__ double red[2][NPL][64];                  // NPL position lanes x 16 float4 channel groups (NPL = 64: 1024 threads,
+                                                        // for slabs a lone workgroup walks: its own loads are all the parallelism)
     __shared__ float scsh[2][64];
     const int b = blockIdx.x, cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int c = blockIdx.y * 64 + cl * 4;
@@ -72,16 +73,16 @@ __global__ __launch_bounds__(TR_THREADS) void in_stats_kernel(const float* __res
         for (int j = 0; j < 4; ++j) k[j] = eab_prelu(k[j], a[j]);
         // four rows in flight per thread: a workgroup owns its slab alone, so its own loads are all the memory-level
         // parallelism there is (one row per iteration ran at one memory latency per 16 rows)
-        for (int i0 = pl; i0 < P; i0 += 64) {
+        for (int i0 = pl; i0 < P; i0 += 4 * NPL) {
             f32x4 v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int i = i0 + 16 * u;
+                const int i = i0 + NPL * u;
                 v[u] = i < P ? *reinterpret_cast<const f32x4*>(p + (size_t)i * xC) : k;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (i0 + 16 * u < P) {
+                if (i0 + NPL * u < P) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const double d = (double)(eab_prelu(v[u][j], a[j]) - k[j]);
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(TR_THREADS) void in_stats_kernel(const float* __res
         if (cc < C) {
             double ss = 0.0, qq = 0.0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < NPL; ++r) {
                 ss += red[0][r][threadIdx.x];
                 qq += red[1][r][threadIdx.x];
             }
@@ -137,16 +138,16 @@ __global__ __launch_bounds__(TR_THREADS) void in_stats_kernel(const float* __res
             // several views (xC < C): every view is its own contiguous [B][P][xC] tensor, one behind the other
             const int yC = xC < C ? xC : C;
             float* yp = y + (size_t)(c / yC) * gridDim.x * P * yC + (size_t)b * P * yC + (c % yC);
-            for (int i0 = pl; i0 < P; i0 += 64) {
+            for (int i0 = pl; i0 < P; i0 += 4 * NPL) {
                 f32x4 v[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + 16 * u;
+                    const int i = i0 + NPL * u;
                     v[u] = i < P ? *reinterpret_cast<const f32x4*>(p + (size_t)i * xC) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + 16 * u;
+                    const int i = i0 + NPL * u;
                     if (i < P) {
                         f32x4 o;
 #pragma unroll
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(TR_THREADS) void in_stats_kernel(const float* __res
 extern "C" int eab_train_in_stats_f32(const float* x, const float* slope, int B, int P, int C, float eps, const float* gamma,
                                       const float* beta, float* xf, float* mr, eab_stream_t stream) {
     EAB_CHECK_ARG(x && gamma && beta && xf && mr && B > 0 && P > 0 && C > 0 && (C % 4) == 0 && B <= 65535);
-    hipLaunchKernelGGL(in_stats_kernel<false>, dim3(B, (C + 63) / 64), dim3(TR_THREADS), 0, eab_stream(stream), x, slope, P, C, eps,
+    hipLaunchKernelGGL((in_stats_kernel<false, 16>), dim3(B, (C + 63) / 64), dim3(TR_THREADS), 0, eab_stream(stream), x, slope, P, C, eps,
                        gamma, beta, xf, mr, nullptr, C);
     EAB_RETURN_LAUNCH_STATUS();
 }
@@ -172,8 +173,13 @@ extern "C" int eab_train_in_stats_f32(const float* x, const float* slope, int B,
 extern "C" int eab_train_in1d_f32(const float* x, const float* slope, int B, int P, int C, float eps, const float* gamma,
                                   const float* beta, float* xf, float* mr, float* y, eab_stream_t stream) {
     EAB_CHECK_ARG(x && slope && gamma && beta && xf && mr && y && B > 0 && P > 0 && C > 0 && (C % 4) == 0 && B <= 65535);
-    hipLaunchKernelGGL(in_stats_kernel<true>, dim3(B, (C + 63) / 64), dim3(TR_THREADS), 0, eab_stream(stream), x, slope, P, C, eps,
-                       gamma, beta, xf, mr, y, C);
+    // few workgroups (B * C/64) each walking its whole slab twice: 1024 threads per workgroup when the grid cannot fill the chip
+    if ((long long)B * ((C + 63) / 64) < 256 && P >= 256)
+        hipLaunchKernelGGL((in_stats_kernel<true, 64>), dim3(B, (C + 63) / 64), dim3(1024), 0, eab_stream(stream), x, slope, P, C, eps,
+                           gamma, beta, xf, mr, y, C);
+    else
+        hipLaunchKernelGGL((in_stats_kernel<true, 16>), dim3(B, (C + 63) / 64), dim3(TR_THREADS), 0, eab_stream(stream), x, slope, P, C,
+                           eps, gamma, beta, xf, mr, y, C);
     EAB_RETURN_LAUNCH_STATUS();
 }
 
@@ -184,8 +190,12 @@ extern "C" int eab_train_in1d_multi_f32(const float* x, const float* slope, int 
                                         const float* gamma, const float* beta, float* xf, float* mr, float* y, eab_stream_t stream) {
     EAB_CHECK_ARG(x && slope && gamma && beta && xf && mr && y && B > 0 && P > 0 && C > 0 && xC > 0 && (xC % 4) == 0 && (C % xC) == 0 &&
                   B <= 65535);
-    hipLaunchKernelGGL(in_stats_kernel<true>, dim3(B, (C + 63) / 64), dim3(TR_THREADS), 0, eab_stream(stream), x, slope, P, C, eps,
-                       gamma, beta, xf, mr, y, xC);
+    if ((long long)B * ((C + 63) / 64) < 256 && P >= 256)
+        hipLaunchKernelGGL((in_stats_kernel<true, 64>), dim3(B, (C + 63) / 64), dim3(1024), 0, eab_stream(stream), x, slope, P, C, eps,
+                           gamma, beta, xf, mr, y, xC);
+    else
+        hipLaunchKernelGGL((in_stats_kernel<true, 16>), dim3(B, (C + 63) / 64), dim3(TR_THREADS), 0, eab_stream(stream), x, slope, P, C,
+                           eps, gamma, beta, xf, mr, y, xC);
     EAB_RETURN_LAUNCH_STATUS();
 }
 

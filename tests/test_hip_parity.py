@@ -660,6 +660,50 @@ def test_config4_two_stage_ddp_bf16_training_step(dev):
         dist.destroy_process_group()
 
 
+def test_two_stage_training_step_with_flat_allreduce(dev):
+    """BASELINE configs[3] as train_distributed.py:181-230 drives it: both stages trained, eabnet_with_postnet_loss, one flat
+    RCCL all-reduce per stage (single-rank group here): forward and backward of BOTH stages on the HIP training programs, and
+    the synchronised gradients equal those of an unsynchronised step."""
+    import os
+    import torch.distributed as dist
+    import eabnet_amd
+    from eabnet_amd import train as tr
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29535")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        args = _postnet_args(4, p=1, q=1, gagnet_p=1, gagnet_q=2, gagnet_dilas=[1, 2])
+        x = torch.from_numpy(paramgen.make_spec_input(2, 24, 161, 4, 180)).to(dev)
+        label = torch.from_numpy(paramgen.make_spec_input(2, 24, 161, 1, 181)[..., 0, :]).permute(0, 3, 1, 2).contiguous().to(dev)
+        grads = {}
+        for mode in ("plain", "flat"):
+            torch.manual_seed(5)
+            net = eabnet_amd.make_eabnet_with_postnet(args).to(dev).train()
+            if mode == "flat":
+                tr.broadcast_parameters(net)
+                tr.enable_flat_allreduce(net.eabnet)
+                tr.enable_flat_allreduce(net.postnet)
+            out = net(x)
+            loss = eabnet_amd.eabnet_with_postnet_loss(out, label, [24, 24])["final"]
+            loss.backward()
+            assert getattr(net.eabnet, "_train_bound", None) and getattr(net.postnet, "_train_bound", None), \
+                "both stages must train on the HIP programs"
+            assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+            grads[mode] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()
+            opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+            torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+            opt.step()
+            with torch.no_grad():
+                y = net.eval()(x)["esti_stft"]
+            assert y.shape == (2, 2, 24, 161) and torch.isfinite(y).all()
+        rel = float((grads["flat"] - grads["plain"]).norm() / grads["plain"].norm())
+        assert rel <= 1e-5, rel                      # (atomics order in the weight gradients)
+    finally:
+        dist.destroy_process_group()
+
+
 # ------------------------------------------------------------------ streaming (SURVEY §8f N4, BASELINE config 5)
 @pytest.mark.parametrize("chunk,use_graph", [(1, True), (7, True), (16, False)])
 def test_streaming_equals_offline_bit_for_bit(dev, chunk, use_graph):

@@ -136,11 +136,14 @@ def test_instance_norm_prelu_forward_and_backward(lib, mode, B, P, Cc):
     yd = torch.empty_like(xd)
     _ck(lib.eab_train_norm_act_f32(xd.data_ptr(), xf.data_ptr(), sd.data_ptr(), None, yd.data_ptr(), B, P, Cc, mode, _st()))
     assert_close(yd.cpu().numpy(), y.detach().permute(0, 2, 1).numpy(), TOL, "forward")
-    if mode == 2:       # the S-TCM unit as one launch: same statistics, bit-identical output
+    if mode == 2:       # the S-TCM unit as one launch: same statistics, same output
         xf1, mr1, y1 = torch.empty_like(xf), torch.empty_like(mr), torch.empty_like(xd)
         _ck(lib.eab_train_in1d_f32(xd.data_ptr(), sd.data_ptr(), B, P, Cc, 1e-5, gd.data_ptr(), bd.data_ptr(), xf1.data_ptr(),
                                    mr1.data_ptr(), y1.data_ptr(), _st()))
-        assert torch.equal(xf1, xf) and torch.equal(mr1, mr) and torch.equal(y1, yd)
+        # (the one-launch form sums its fp64 partials over 64 position lanes when few workgroups walk long slabs, the
+        # statistics-only kernel over 16: the fp32 results agree to the last bit or two)
+        for got_t, want_t, what in ((xf1, xf, "xf"), (mr1, mr, "mr"), (y1, yd, "y")):
+            assert_close(got_t.cpu().numpy(), want_t.cpu().numpy(), 1e-6, f"in1d one launch: {what}")
     sums = torch.full((B, Cc, 4), 7.0, device="cuda:0")
     acc = torch.randn(B, P, Cc, device="cuda:0")
     for acc_in in (None, acc):
