@@ -113,6 +113,35 @@ def _split64(n: int) -> Tuple[int, int]:
     return n & 0xFFFFFFFF, n >> 32
 
 
+class _LaneList(list):
+    """op list that tags every appended op with the lane (stream) the lowering is currently emitting for"""
+
+    def __init__(self, owner):
+        super().__init__()
+        self.owner = owner
+
+    def append(self, op) -> None:
+        op.lane = self.owner.cur_lane
+        super().append(op)
+
+
+class _Tape(list):
+    """backward closures; each one is replayed on the lane that was current when it was recorded"""
+
+    def __init__(self, owner):
+        super().__init__()
+        self.owner = owner
+
+    def append(self, fn) -> None:
+        owner, lane = self.owner, self.owner.cur_lane
+
+        def run():
+            prev, owner.cur_lane = owner.cur_lane, lane
+            fn()
+            owner.cur_lane = prev
+        super().append(run)
+
+
 class TrainLowering:
     spec_fn = staticmethod(param_specs)              # parameter inventory of the network being lowered (subclasses: GaGNet)
     supports = staticmethod(supported)
@@ -139,14 +168,22 @@ class TrainLowering:
         self.w_index: Dict[str, Ref] = {}
         self.g_imgs: List[Tuple[int, List[np.ndarray]]] = []                 # (offset, param-index images) of gradient entries
         self.g_size = 0
-        self.fwd: list = []
-        self.bwd: list = []
-        self.tape: List[Callable[[], None]] = []
+        self.cur_lane = 0                                                     # 0 = the caller's stream; > 0: parallel branches
+        self.fwd: list = _LaneList(self)
+        self.bwd: list = _LaneList(self)
+        self.sync = {"fwd": {}, "bwd": {}}                                    # op index -> [("fork" | "join", lanes)]
+        self.tape: List[Callable[[], None]] = _Tape(self)
         self.deferred: List[WgradOp] = []                                     # weight gradients, appended to bwd by finish()
         self.flops_fwd = 0
         self.flops_bwd = 0
         self.emit = self.fwd                                                  # the list ops are appended to
         self.gtaps: Dict[str, TVar] = {}                                      # named activations whose gradient tests read back
+
+    def mark(self, which: str, what: str, lanes: Sequence[int]) -> None:
+        """fork / join of parallel branches in front of the next op of the forward or backward list (executed by TrainBound.run
+        with side streams and events; inside a hipGraph capture they become parallel branches)"""
+        lst = self.fwd if which == "fwd" else self.bwd
+        self.sync[which].setdefault(len(lst), []).append((what, list(lanes)))
 
     # ---- arenas ------------------------------------------------------------------------------------
     def alloc(self, nfloats: int) -> Ref:
@@ -686,13 +723,16 @@ class TrainLowering:
         order: Dict[tuple, int] = {}
         for o in self.deferred:
             order.setdefault(geometry(o), len(order))
+        for o in self.deferred:
+            o.lane = 0
         self.bwd.extend(sorted(self.deferred, key=lambda o: order[geometry(o)]))      # stable: first-seen geometry first
         self.deferred = []
         return TrainProgram(cfg=self.cfg, B=self.B, T=self.T, F=self.F, fwd=self.fwd, bwd=self.bwd, a_floats=self.a_size,
                             w_floats=self.w_size, g_floats=self.g_size, ia=ia, ib=ib, inv=inv.astype(np.int32),
                             n_params=self.n_params, keys=list(self.specs), shapes=[tuple(s.shape) for s in self.specs.values()],
                             flops_fwd=self.flops_fwd, flops_bwd=self.flops_bwd,
-                            grad_taps={k: (v.slot.ref, v.F, v.C) for k, v in self.gtaps.items() if v.slot.ref is not None})
+                            grad_taps={k: (v.slot.ref, v.F, v.C) for k, v in self.gtaps.items() if v.slot.ref is not None},
+                            lanes={"fwd": [o.lane for o in self.fwd], "bwd": [o.lane for o in self.bwd]}, sync=self.sync)
 
 
 @dataclass
@@ -717,6 +757,8 @@ class TrainProgram:
     grad_taps: Dict[str, tuple] = field(default_factory=dict)       # name -> (Ref of d loss / d activation, F, C)
     out_shape: Optional[tuple] = None        # shape of the 'out' / 'dout' arenas (default: the beam-former's (B, 2, T, F))
     has_in2: bool = False                    # a second input arena 'in2' (the post-filter's previous estimate)
+    lanes: Dict[str, list] = field(default_factory=dict)          # per program: lane of every op (0 = the caller's stream)
+    sync: Dict[str, dict] = field(default_factory=dict)           # per program: op index -> [("fork" | "join", lanes)]
 
 
 def lower_train(cfg: NetConfig, B: int, T: int, F: int = 161, precision: str = "f32") -> TrainProgram:
@@ -770,6 +812,8 @@ class TrainBound:
             self.segments.append((1 + blk % 2 if is_w else 0, k, j - k))
             k = j
         self._side = None
+        self._lane_streams = {}
+        self.parallel_branches = os.environ.get("EAB_TRAIN_BRANCHES", "1") != "0"      # A/B knob
 
     def capture(self, x_shape) -> bool:
         """Both programs as hipGraphs on static boundary buffers (input, output, output gradient): a step is two graph
@@ -883,6 +927,34 @@ class TrainBound:
                     self.run(which, sd.cuda_stream, k, n)
             for sd in used:
                 main.wait_stream(sd)
+            return
+        sync = self.prog.sync.get(which) if self.parallel_branches else None
+        if sync and first == 0 and count is None:
+            # programs with parallel branches (the post-filter's three S-TCM chains): fork onto side streams with events --
+            # inside a hipGraph capture these become graph edges, so the branches replay concurrently
+            main = torch.cuda.current_stream()
+            assert main.cuda_stream == stream, "multi-lane programs run on torch's current stream"
+            lanes = self.prog.lanes[which]
+            streams = {0: main}
+            k, end = 0, len(arr)
+            while k <= end:
+                for what, ls in sync.get(k, ()):
+                    for l in ls:
+                        if l not in self._lane_streams:
+                            self._lane_streams[l] = torch.cuda.Stream(device=self.device)
+                        streams[l] = self._lane_streams[l]
+                        if what == "fork":
+                            streams[l].wait_stream(main)
+                        else:
+                            main.wait_stream(streams[l])
+                if k == end:
+                    break
+                j = k + 1
+                while j < end and lanes[j] == lanes[k] and j not in sync:
+                    j += 1
+                with torch.cuda.stream(streams[lanes[k]]):
+                    self.run(which, streams[lanes[k]].cuda_stream, k, j - k)
+                k = j
             return
         n = len(arr) - first if count is None else count
         ops = C.cast(C.byref(arr, first * C.sizeof(_lib.Op)), C.POINTER(_lib.Op))

@@ -138,9 +138,25 @@ class GagTrainLowering(TrainLowering):
             gl, gz = f"gags.{gi}.glance_block", f"gags.{gi}.gaze_block"
             xg0 = self.gated_in(gl, feat, pre, feat_perm)
             xz = self.gated_in(gz, feat, pre, feat_perm)
+            # The glance chain and the two gaze chains only meet again in the tail; each of their launches fills a fraction
+            # of the chip (57 workgroups at 6 x 6 s), so they run as three parallel branches, forward and backward.  The gaze
+            # chains both read xz: each gets its own gradient slot, summed after the backward join (two lanes must not
+            # accumulate into one buffer).
+            xz_r, xz_i = TVar(xz.ref, xz.F, xz.C, tr.Slot()), TVar(xz.ref, xz.F, xz.C, tr.Slot())
+
+            def join_back(xz=xz, xz_r=xz_r, xz_i=xz_i):
+                self.mark("bwd", "join", [1, 2])
+                self.contribute(xz, self.grad_of(xz_r))
+                self.contribute(xz, self.grad_of(xz_i))
+            self.tape.append(join_back)                 # replayed after the chains' closures, before the gated in-convs'
+            self.mark("fwd", "fork", [1, 2])
             gain, back_g = self.linear(f"{gl}.linear_g.0", self.chain(f"{gl}.tcn_g", xg0))
-            lr, back_r = self.linear(f"{gz}.linear_r", self.chain(f"{gz}.tcm_r", xz))
-            li, back_i = self.linear(f"{gz}.linear_i", self.chain(f"{gz}.tcm_i", xz))
+            self.cur_lane = 1
+            lr, back_r = self.linear(f"{gz}.linear_r", self.chain(f"{gz}.tcm_r", xz_r))
+            self.cur_lane = 2
+            li, back_i = self.linear(f"{gz}.linear_i", self.chain(f"{gz}.tcm_i", xz_i))
+            self.cur_lane = 0
+            self.mark("fwd", "join", [1, 2])
             nxt = TVar(self.alloc(B * T * PRE_LD), 1, PRE_LD, tr.Slot(), needs_grad=gi + 1 < cfg.q)
             self.fwd.append(GenOp(OP_GAG_CRM, [pre.ref, gain.ref, lr.ref, li.ref, nxt.ref, Ref("out", gi * n_stage)],
                                   [B, T, F, PRE_LD, LIN_LD, act], name=f"gags.{gi}.crm"))
@@ -151,9 +167,13 @@ class GagTrainLowering(TrainLowering):
                 dst, aux = self.grad_target(pre) if pre.needs_grad else (None, None)
                 self.bwd.append(GenOp(OP_GAG_CRM_BWD, [pre.ref, gain.ref, Ref("dout", gi * n_stage), nxt.slot.ref, aux, dg, dr, di, dst],
                                       [B, T, F, PRE_LD, LIN_LD, act], name=f"gags.{gi}.crm_bwd"))
+                self.mark("bwd", "fork", [1, 2])
                 back_g(dg)
+                self.cur_lane = 1
                 back_r(dr)
+                self.cur_lane = 2
                 back_i(di)
+                self.cur_lane = 0
             self.tape.append(back)
             pre = nxt
         for fn in reversed(self.tape):
