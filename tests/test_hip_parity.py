@@ -660,6 +660,33 @@ def test_config4_two_stage_ddp_bf16_training_step(dev):
         dist.destroy_process_group()
 
 
+def test_two_stage_training_reduces_the_loss(dev):
+    """train_distributed.py's loop (:214-230) on one fixed batch: 40 Adam steps of the two-stage model, both stages on the HIP
+    training programs (hipGraph replay, weights re-packed from the updated parameters every step), must fit the batch --
+    every stage's loss goes down, in fp32 and with bf16 products."""
+    import eabnet_amd
+    args = _postnet_args(4, p=1, q=1, gagnet_p=1, gagnet_q=2, gagnet_dilas=[1, 2])
+    x = torch.from_numpy(paramgen.make_spec_input(2, 30, 161, 4, 190)).to(dev)
+    label = torch.from_numpy(paramgen.make_spec_input(2, 30, 161, 1, 191)[..., 0, :]).permute(0, 3, 1, 2).contiguous().to(dev)
+    for prec in ("f32", "bf16"):
+        torch.manual_seed(7)
+        net = eabnet_amd.make_eabnet_with_postnet(args).to(dev).train()
+        net.eabnet.precision = net.postnet.precision = prec
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        hist = []
+        for _ in range(40):
+            opt.zero_grad(set_to_none=True)
+            losses = eabnet_amd.eabnet_with_postnet_loss(net(x), label, [30, 30])
+            losses["final"].backward()
+            torch.nn.utils.clip_grad_norm_(net.parameters(), 5.0)
+            opt.step()
+            hist.append((float(losses["eabnet"].detach()), float(losses["postnet"].detach())))
+        assert getattr(net.eabnet, "_train_bound", None) and getattr(net.postnet, "_train_bound", None)
+        assert all(np.isfinite(h).all() for h in hist)
+        print(f"{prec}: beam-former loss {hist[0][0]:.4f} -> {hist[-1][0]:.4f}, post-filter loss {hist[0][1]:.4f} -> {hist[-1][1]:.4f}")
+        assert hist[-1][0] < 0.8 * hist[0][0] and hist[-1][1] < 0.8 * hist[0][1], (prec, hist[0], hist[-1])
+
+
 def test_two_stage_training_step_with_flat_allreduce(dev):
     """BASELINE configs[3] as train_distributed.py:181-230 drives it: both stages trained, eabnet_with_postnet_loss, one flat
     RCCL all-reduce per stage (single-rank group here): forward and backward of BOTH stages on the HIP training programs, and
