@@ -451,25 +451,55 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
     };
     Stage sa;                       // stage s+1 in flight while stage s is multiplied
 
+    // Row state of the CURRENT tap, refreshed when the unit sequence enters a new tap (units run tap-major: UPT units per
+    // tap): validity of the tap's source position and its byte offset in either source.  Per unit that leaves one select and
+    // one add per row instead of six compares, two integer multiplies (quarter rate) and the scalar unit/tap division.
+    bool tap_ok[MI];
+    unsigned tap_b0[MI], tap_b1[MI];
+#pragma unroll
+    for (int p = 0; p < MI; ++p) {
+        tap_ok[p] = false;
+        tap_b0[p] = tap_b1[p] = 0u;
+    }
+    int g_tap = -1, g_c0 = 0;                              // tap and first channel of the next unit to fetch (u = g_tap*UPT + g_c0/16)
     auto fetch = [&](int stage, Stage& rg) {
 #pragma unroll
         for (int ku = 0; ku < KU; ++ku) {
             const int u = stage * KU + ku;
             const bool live = u < NU;                           // K tail of the last stage
+            // units are fetched in order 0, 1, 2, ...: advance (tap, channel) without dividing
+            if (u == 0) {
+                g_tap = 0;
+                g_c0 = 0;
+            } else if (live) {
+                g_c0 += 16;
+                if (g_c0 >= (UPT << 4)) {
+                    g_c0 = 0;
+                    ++g_tap;
+                }
+            }
             const int uu = live ? u : 0;
-            const int tap = uu / UPT;
-            const int c0 = (uu - tap * UPT) << 4;
-            const int dt = sm.dt[tap], io = sm.ioff[tap];
+            const int c0 = live ? g_c0 : 0;
+            if (live && c0 == 0) {                              // (workgroup-uniform) first unit of a tap
+                const int dt = sm.dt[g_tap], io = sm.ioff[g_tap];
+#pragma unroll
+                for (int p = 0; p < MI; ++p) {
+                    const int tt = a_t[p] + dt, fi = a_f0[p] + io;
+                    tap_ok[p] = a_ok[p] && tt >= 0 && tt < d.T && fi >= 0 && fi < d.Fin;
+                    const unsigned pos = (unsigned)(a_tf[p] + dt * d.Fin + io);
+                    tap_b0[p] = pos * (unsigned)(d.C0 * 4);
+                    tap_b1[p] = pos * (unsigned)(d.C1 * 4);
+                }
+            }
             const bool second = (d.C1 > 0) && (c0 >= d.C0);     // wave-uniform
             const int Cs = second ? d.C1 : d.C0;
             const int c = (second ? c0 - d.C0 : c0) + skq * 4;
             const bool cok = live && (c < Cs);
 #pragma unroll
             for (int p = 0; p < MI; ++p) {
-                const int tt = a_t[p] + dt, fi = a_f0[p] + io;
-                const bool ok = a_ok[p] && cok && tt >= 0 && tt < d.T && fi >= 0 && fi < d.Fin;
+                const bool ok = tap_ok[p] && cok;
                 rg.st_ok[ku][p] = ok;
-                const unsigned off = ok ? (unsigned)(((a_tf[p] + dt * d.Fin + io) * Cs + c) * 4) : CG_OOB;
+                const unsigned off = ok ? (second ? tap_b1[p] : tap_b0[p]) + (unsigned)(c * 4) : CG_OOB;
                 if (VEC) {
                     const u32x4 v = second ? __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0)
                                            : __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0);
