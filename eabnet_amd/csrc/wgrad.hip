@@ -35,14 +35,18 @@ struct WgRow {
         t = q / No;
         o = q - t * No;
     }
-    __device__ __forceinline__ void advance(int n, int T, int No) {
-        o += n;
-        while (o >= No) {
+    // advance by n = a * No + rem rows (a, rem workgroup-uniform, computed once): one conditional wrap of o instead of a
+    // per-lane loop (for the deep layers No is 4..10, so a 16-row stage wraps o several times)
+    __device__ __forceinline__ void advance(int a, int rem, int T, int No) {
+        o += rem;
+        t += a;
+        if (o >= No) {
             o -= No;
-            if (++t == T) {
-                t = 0;
-                ++b;
-            }
+            ++t;
+        }
+        while (t >= T) {                                     // (only at a batch-element boundary)
+            t -= T;
+            ++b;
         }
     }
 };
@@ -80,6 +84,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgBatch bt) {
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
 
     const long long R = (long long)d.T * d.No * d.B;
+    const int adv_a = WG_ROWS / d.No, adv_r = WG_ROWS - adv_a * d.No;         // a stage advances every row walker by WG_ROWS rows
     const long long r_begin = (long long)row_group * d.rows_per_wg;
     const long long r_end = r_begin + d.rows_per_wg < R ? r_begin + d.rows_per_wg : R;
     const int col0 = blockIdx.y * TC, n0 = blockIdx.z * TN;
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgBatch bt) {
                 v = *reinterpret_cast<const f32x4*>(
                     &m_dz[(((size_t)ra_[p].b * d.T + ra_[p].t) * d.Fz + (size_t)ra_[p].o * d.ostride + d.ophase) * d.N + n0 + a_c4 * 4]);
             ra[p] = v;
-            ra_[p].advance(WG_ROWS, d.T, d.No);
+            ra_[p].advance(adv_a, adv_r, d.T, d.No);
         }
         const bool rok = r0 + b_row < r_end;
 #pragma unroll
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgBatch bt) {
             }
             rb[j] = v;
         }
-        rb_.advance(WG_ROWS, d.T, d.No);
+        rb_.advance(adv_a, adv_r, d.T, d.No);
     };
     auto stash = [&](int buf) {
 #pragma unroll
@@ -266,6 +271,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_bf_kernel(const WgBatch bt) 
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
 
     const long long R = (long long)d.T * d.No * d.B;
+    const int adv_a = WG_ROWS / d.No, adv_r = WG_ROWS - adv_a * d.No;         // a stage advances every row walker by WG_ROWS rows
     const long long r_begin = (long long)row_group * d.rows_per_wg;
     const long long r_end = r_begin + d.rows_per_wg < R ? r_begin + d.rows_per_wg : R;
     const int col0 = blockIdx.y * TC, n0 = blockIdx.z * TN;
@@ -319,9 +325,9 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_bf_kernel(const WgBatch bt) 
             }
             ra[e] = va;
             rb[e] = vb;
-            if (e == 0) w.advance(1, d.T, d.No);
+            if (e == 0) w.advance(0, 1, d.T, d.No);
         }
-        rw.advance(WG_ROWS, d.T, d.No);
+        rw.advance(adv_a, adv_r, d.T, d.No);
     };
     auto stash = [&](int buf) {
         if (a_live) {
