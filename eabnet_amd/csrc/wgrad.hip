@@ -49,6 +49,22 @@ struct WgRow {
             ++b;
         }
     }
+    // the same step, telling whether o wrapped: byte offsets of a row are then stepped without multiplies --
+    // offset(row) is affine in (b*T + t, o), and b*T + t just keeps counting across batch elements
+    __device__ __forceinline__ bool step(int a, int rem, int T, int No) {
+        o += rem;
+        t += a;
+        const bool wrap = o >= No;
+        if (wrap) {
+            o -= No;
+            ++t;
+        }
+        while (t >= T) {
+            t -= T;
+            ++b;
+        }
+        return wrap;
+    }
 };
 
 // One launch serves up to WG_MAXB weight gradients of IDENTICAL geometry (the 18 S-TCMs' in/left/right/out convolutions, the
@@ -117,10 +133,37 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgBatch bt) {
                 tio[j] = d.ioff[k];
             }
     }
+    // Operands through bounds-checked buffer descriptors with 32-bit byte offsets (host: every tensor < 2 GiB), stepped
+    // incrementally: a stage moves every row walker by WG_ROWS rows = (adv_a, adv_r) in (t, o) plus one conditional wrap, and
+    // a row's offset is affine in (b*T + t, o) -- no multiplies, no 64-bit address arithmetic, no branches around the loads
+    // (an invalid row or tap gets an out-of-range offset and reads 0).
+    const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(m_dz), 0, (unsigned)((size_t)d.B * d.T * d.Fz * d.N * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_s0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(m_src0), 0, (unsigned)((size_t)d.B * d.T * d.Fin * d.C0 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_s1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(m_src1 ? m_src1 : m_src0), 0, m_src1 ? (unsigned)((size_t)d.B * d.T * d.Fin * d.C1 * 4) : 0u, 0x00020000);
+    constexpr unsigned WG_OOB = 0x80000000u;
     WgRow ra_[AP], rb_;
+    unsigned offA[AP];
+    int offB[BP];                                                // (may be negative while the tap is out of range: unused then)
 #pragma unroll
-    for (int p = 0; p < AP; ++p) ra_[p].init(r_begin + a_row + 8 * p, d.T, d.No);
+    for (int p = 0; p < AP; ++p) {
+        ra_[p].init(r_begin + a_row + 8 * p, d.T, d.No);
+        offA[p] = (unsigned)(((((size_t)ra_[p].b * d.T + ra_[p].t) * d.Fz + (size_t)ra_[p].o * d.ostride + d.ophase) * d.N + n0 + a_c4 * 4) * 4);
+    }
     rb_.init(r_begin + b_row, d.T, d.No);
+    const unsigned dA0 = (unsigned)((adv_a * d.Fz + adv_r * d.ostride) * d.N * 4), dA1 = (unsigned)((d.Fz - d.No * d.ostride) * d.N * 4);
+    int dB0[BP], dB1[BP];
+    bool b_second[BP];
+#pragma unroll
+    for (int j = 0; j < BP; ++j) {
+        b_second[j] = d.C1 > 0 && b_src[j] == m_src1;
+        const long long bt = (long long)rb_.b * d.T + rb_.t + tdt[j];
+        offB[j] = (int)(((bt * d.Fin + (long long)rb_.o * d.istride + tio[j]) * b_Cs[j] + b_cc[j]) * 4);
+        dB0[j] = (adv_a * d.Fin + adv_r * d.istride) * b_Cs[j] * 4;
+        dB1[j] = (d.Fin - d.No * d.istride) * b_Cs[j] * 4;
+    }
 
     f32x4 ra[AP], rb[BP];
     f32x4 bsum[AP];                                              // bias gradient: column sums of dz (column block 0 only)
@@ -131,31 +174,29 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgBatch bt) {
     auto fetch = [&](long long r0) {
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r0 + a_row + 8 * p < r_end)
-                v = *reinterpret_cast<const f32x4*>(
-                    &m_dz[(((size_t)ra_[p].b * d.T + ra_[p].t) * d.Fz + (size_t)ra_[p].o * d.ostride + d.ophase) * d.N + n0 + a_c4 * 4]);
-            ra[p] = v;
-            ra_[p].advance(adv_a, adv_r, d.T, d.No);
+            const bool ok = r0 + a_row + 8 * p < r_end;
+            ra[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dz, ok ? offA[p] : WG_OOB, 0, 0));
+            offA[p] += dA0 + (ra_[p].step(adv_a, adv_r, d.T, d.No) ? dA1 : 0u);
         }
         const bool rok = r0 + b_row < r_end;
 #pragma unroll
         for (int j = 0; j < BP; ++j) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             const int tt = rb_.t + tdt[j], fi = rb_.o * d.istride + tio[j];
-            if (rok && b_ok[j] && tt >= 0 && tt < d.T && fi >= 0 && fi < d.Fin) {
-                const float* sp = &b_src[j][(((size_t)rb_.b * d.T + tt) * d.Fin + fi) * b_Cs[j] + b_cc[j]];
-                if (vec_ok) {
-                    v = *reinterpret_cast<const f32x4*>(sp);
-                } else {            // channel count not a multiple of 4 (2M = 18 network inputs): element loads, row tail guarded
+            const bool ok = rok && b_ok[j] && tt >= 0 && tt < d.T && fi >= 0 && fi < d.Fin;
+            const unsigned off = ok ? (unsigned)offB[j] : WG_OOB;
+            if (vec_ok) {
+                rb[j] = __builtin_bit_cast(f32x4, b_second[j] ? __builtin_amdgcn_raw_buffer_load_b128(rs_s1, off, 0, 0)
+                                                              : __builtin_amdgcn_raw_buffer_load_b128(rs_s0, off, 0, 0));
+            } else {                // channel count not a multiple of 4 (2M = 18 network inputs): dword loads, row tail guarded
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (b_cc[j] + e < b_Cs[j]) v[e] = sp[e];
-                }
+                for (int e = 0; e < 4; ++e)
+                    rb[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                             rs_s0, (ok && b_cc[j] + e < b_Cs[j]) ? off + 4u * e : WG_OOB, 0, 0));
             }
-            rb[j] = v;
         }
-        rb_.advance(adv_a, adv_r, d.T, d.No);
+        const bool wrap = rb_.step(adv_a, adv_r, d.T, d.No);
+#pragma unroll
+        for (int j = 0; j < BP; ++j) offB[j] += dB0[j] + (wrap ? dB1[j] : 0);
     };
     auto stash = [&](int buf) {
 #pragma unroll
@@ -297,37 +338,48 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_bf_kernel(const WgBatch bt) 
             tio = d.ioff[k];
         }
     const bool vec_ok = (d.C0 & 3) == 0;
-    WgRow rw;
-    rw.init(r_begin + 2 * rp, d.T, d.No);
+    // (buffer descriptors and incremental 32-bit offsets as in wgrad_kernel; two row walkers per thread: rows 2 rp, 2 rp + 1)
+    const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(m_dz), 0, (unsigned)((size_t)d.B * d.T * d.Fz * d.N * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(b_src), 0, (unsigned)((size_t)d.B * d.T * d.Fin * b_Cs * 4), 0x00020000);
+    constexpr unsigned WG_OOB = 0x80000000u;
+    WgRow rw[2];
+    unsigned offA[2];
+    int offB[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        rw[e].init(r_begin + 2 * rp + e, d.T, d.No);
+        const long long bt = (long long)rw[e].b * d.T + rw[e].t;
+        offA[e] = (unsigned)((((bt * d.Fz) + (long long)rw[e].o * d.ostride + d.ophase) * d.N + n0 + c4 * 4) * 4);
+        offB[e] = (int)((((bt + tdt) * d.Fin + (long long)rw[e].o * d.istride + tio) * b_Cs + b_cc) * 4);
+    }
+    const unsigned dA0 = (unsigned)((adv_a * d.Fz + adv_r * d.ostride) * d.N * 4), dA1 = (unsigned)((d.Fz - d.No * d.ostride) * d.N * 4);
+    const int dB0 = (adv_a * d.Fin + adv_r * d.istride) * b_Cs * 4, dB1 = (d.Fin - d.No * d.istride) * b_Cs * 4;
 
     f32x4 ra[2], rb[2];
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     const bool do_bias = m_dbias != nullptr && blockIdx.y == 0;
     auto fetch = [&](long long r0) {
-        WgRow w = rw;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const bool rok = r0 + 2 * rp + e < r_end;
-            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
-            if (rok && a_live)
-                va = *reinterpret_cast<const f32x4*>(
-                    &m_dz[(((size_t)w.b * d.T + w.t) * d.Fz + (size_t)w.o * d.ostride + d.ophase) * d.N + n0 + c4 * 4]);
-            const int tt = w.t + tdt, fi = w.o * d.istride + tio;
-            if (rok && b_ok && tt >= 0 && tt < d.T && fi >= 0 && fi < d.Fin) {
-                const float* sp = &b_src[(((size_t)w.b * d.T + tt) * d.Fin + fi) * b_Cs + b_cc];
-                if (vec_ok) {
-                    vb = *reinterpret_cast<const f32x4*>(sp);
-                } else {
+            ra[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dz, (rok && a_live) ? offA[e] : WG_OOB, 0, 0));
+            const int tt = rw[e].t + tdt, fi = rw[e].o * d.istride + tio;
+            const bool ok = rok && b_ok && tt >= 0 && tt < d.T && fi >= 0 && fi < d.Fin;
+            const unsigned off = ok ? (unsigned)offB[e] : WG_OOB;
+            if (vec_ok) {
+                rb[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0));
+            } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (b_cc + q < b_Cs) vb[q] = sp[q];
-                }
+                for (int q = 0; q < 4; ++q)
+                    rb[e][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                             rs_src, (ok && b_cc + q < b_Cs) ? off + 4u * q : WG_OOB, 0, 0));
             }
-            ra[e] = va;
-            rb[e] = vb;
-            if (e == 0) w.advance(0, 1, d.T, d.No);
+            const bool wrap = rw[e].step(adv_a, adv_r, d.T, d.No);
+            offA[e] += dA0 + (wrap ? dA1 : 0u);
+            offB[e] += dB0 + (wrap ? dB1 : 0);
         }
-        rw.advance(adv_a, adv_r, d.T, d.No);
     };
     auto stash = [&](int buf) {
         if (a_live) {
@@ -437,6 +489,9 @@ extern "C" int eab_wgrad_batch_f32(const eab_wgrad_desc* descs, int n, int strid
     }
     EAB_CHECK_ARG(d->B > 0 && d->T > 0 && d->Fin > 0 && d->Fz > 0 && d->No > 0 && d->N > 0 && (d->N % 64) == 0);
     EAB_CHECK_ARG(d->precision == EAB_PREC_F32 || d->precision == EAB_PREC_BF16);
+    // 32-bit byte offsets inside the kernels
+    EAB_CHECK_ARG((unsigned long long)d->B * d->T * d->Fz * d->N * 4 < (1ull << 31));
+    EAB_CHECK_ARG((unsigned long long)d->B * d->T * d->Fin * (d->C0 > d->C1 ? d->C0 : d->C1) * 4 < (1ull << 31));
     EAB_CHECK_ARG(d->C0 > 0 && d->C1 >= 0 && (d->C1 == 0) == (d->src1 == nullptr));
     EAB_CHECK_ARG((d->C1 % 4) == 0 && (d->C1 == 0 || (d->C0 % 16) == 0));      // a single source may have any channel count
     EAB_CHECK_ARG(d->ntaps > 0 && d->ntaps <= EAB_MAX_TAPS && d->ostride >= 1 && d->istride >= 1);
