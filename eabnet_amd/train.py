@@ -667,6 +667,8 @@ class TrainLowering:
         self.fwd.append(GenOp(OP_FILTER_SUM, [bw.ref, Ref("in"), Ref("out")], [B, T, F, M, MLP_LD], name="filter_sum"))
 
         self.gtaps["bf_w"] = bw
+        self.gtaps["bf_map.ln"] = x_ln
+        self.gtaps["bf_map.y1"] = y1
 
         def back_head():
             dbw = self.alloc(rows * MLP_LD)
