@@ -137,8 +137,16 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
     const int t_hi = d.win.pos ? (t_lo + d.win.count < d.T ? t_lo + d.win.count : d.T) : d.T;
     const int Q = t_hi * d.No;                      // first row NOT computed
     const int tiles_per_b = ((d.win.pos ? d.win.count : d.T) * d.No + BM - 1) / BM;
-    const int b = blockIdx.x / tiles_per_b;
-    const int tile = blockIdx.x - b * tiles_per_b;
+    // Workgroups are dealt to the 8 XCDs round-robin by blockIdx.x, and every XCD has its own L2: let each XCD walk one
+    // contiguous eighth of the (b, tile) sequence, so that the k_t halo row two neighbouring tiles share (and the weights they
+    // both stream) is fetched into ONE L2 instead of two (HBM traffic of the dominant launches 299 -> see profiles/).
+    unsigned vblk = blockIdx.x;
+    if (gridDim.x >= 64) {
+        const unsigned G = gridDim.x, G8 = G >> 3, rem = G & 7, xcd = vblk & 7, idx = vblk >> 3;
+        vblk = xcd * G8 + (xcd < rem ? xcd : rem) + idx;
+    }
+    const int b = (int)(vblk / (unsigned)tiles_per_b);
+    const int tile = (int)vblk - b * tiles_per_b;
     const int q0 = t_lo * d.No + tile * BM;
     const int n_blk = blockIdx.y * BN;
     const float inv_no = 1.0f / (float)d.No;
