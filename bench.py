@@ -375,7 +375,7 @@ def main():
         # no launcher around us: start the ranks ourselves, as the reference's mp.spawn does
         # (train_distributed.py:363-366) -- fresh processes, one GPU each, before this one makes any GPU call;
         # rank 0's JSON line is the job's.  (Under torch.distributed.run WORLD_SIZE is set and this is skipped.)
-        sys.exit(dist.launch_local(a.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+        sys.exit(dist.launch_local(a.gpus, [os.path.abspath(__file__)] + sys.argv[1:], timeout=1500.0))
     if world != a.gpus:
         sys.exit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)

@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libeabnet_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_TAPS = 16
 _fp = C.POINTER(C.c_float)
 
@@ -46,6 +46,8 @@ class ConvDesc(C.Structure):
         ("fz_counter", C.c_void_p), ("fz_gamma0", C.c_void_p), ("fz_beta0", C.c_void_p), ("fz_xf0", C.c_void_p),
         ("fz_gamma1", C.c_void_p), ("fz_beta1", C.c_void_p), ("fz_xf1", C.c_void_p), ("fz_eps", C.c_float),
         ("glu_dump", C.c_void_p),
+        ("ph1_w", C.c_void_p), ("ph1_No", C.c_int32), ("ph1_ophase", C.c_int32), ("ph1_ntaps", C.c_int32), ("ph1_Kpad", C.c_int32),
+        ("ph1_dt", C.c_int32 * MAX_TAPS), ("ph1_ioff", C.c_int32 * MAX_TAPS),
     ]
 
 

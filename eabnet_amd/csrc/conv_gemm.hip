@@ -1010,10 +1010,12 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
 }
 
 extern "C" int eab_conv_tiles(int T, int No, int bm) {
-    if (T <= 0 || No <= 0 || (bm != 64 && bm != 128)) return -1;
+    if (T <= 0 || No <= 0 || (bm != 16 && bm != 32 && bm != 64 && bm != 128)) return -1;
     long long q = (long long)T * No;
     return (int)((q + bm - 1) / bm);
 }
+
+int eab_conv_st(const eab_conv_desc* d, hipStream_t s);      // conv_st.hip
 
 template <int MI, int NI, int KU, int MODE, int XF, bool VEC>
 static int cg_launch(const eab_conv_desc* d, hipStream_t s) {
@@ -1100,11 +1102,12 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
     // the per-utterance buffer bound; the patch pipeline is laid out for causal taps only
     for (int j = 0; j < d->ntaps; ++j) {
         EAB_CHECK_ARG(d->dt[j] < (1 << 20) && d->dt[j] > -(1 << 20));
-        EAB_CHECK_ARG(d->dt[j] <= 0 || d->korder == EAB_KORDER_TAP);
+        EAB_CHECK_ARG(d->dt[j] <= 0 || d->korder != EAB_KORDER_CHUNK);
     }
     EAB_CHECK_ARG(d->epi >= EAB_EPI_LINEAR && d->epi <= EAB_EPI_DUALGATE);
     EAB_CHECK_ARG(d->precision == EAB_PREC_F32 || d->precision == EAB_PREC_F16X3 || d->precision == EAB_PREC_BF16);
-    EAB_CHECK_ARG(d->korder == EAB_KORDER_TAP || d->korder == EAB_KORDER_CHUNK);
+    EAB_CHECK_ARG(d->korder == EAB_KORDER_TAP || d->korder == EAB_KORDER_CHUNK || d->korder == EAB_KORDER_FRAG);
+    EAB_CHECK_ARG(d->korder == EAB_KORDER_FRAG || d->ph1_No == 0);
     if (d->korder == EAB_KORDER_CHUNK) {   // patch pipeline: the tile's input patch must fit its LDS area
         EAB_CHECK_ARG(cg_patch_positions(d) <= CG_PMAX && d->epi != EAB_EPI_DUALGATE);
         EAB_CHECK_ARG(d->C0 % 4 == 0 && d->C1 % 4 == 0 && d->xf_mode != EAB_XF_PRELU_NORM);
@@ -1140,17 +1143,18 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
     }
     EAB_CHECK_ARG((d->epi != EAB_EPI_MULSIG && d->epi != EAB_EPI_ADD) || d->aux);
     EAB_CHECK_ARG(d->nsets >= 0 && d->nsets <= 2 && (d->nsets == 0) == (d->stats == nullptr));
-    EAB_CHECK_ARG(d->bm == 64 || d->bm == 128);
+    EAB_CHECK_ARG(d->korder == EAB_KORDER_FRAG ? (d->bm == 16 || d->bm == 32 || d->bm == 64) : (d->bm == 64 || d->bm == 128));
     if (d->fz_counter) {
         EAB_CHECK_ARG(d->stats && d->nsets >= 1 && d->nsets * d->Cout <= CG_THREADS && d->win.pos == nullptr);
         EAB_CHECK_ARG(d->fz_gamma0 && d->fz_beta0 && d->fz_xf0 && (d->nsets == 1 || (d->fz_gamma1 && d->fz_beta1 && d->fz_xf1)));
     }
     if (d->stats) {
-        const int tiles = eab_conv_tiles(d->T, d->No, d->bm);
+        const int tiles = eab_conv_tiles(d->T, d->No, d->bm) + (d->ph1_No > 0 ? eab_conv_tiles(d->T, d->ph1_No, d->bm) : 0);
         EAB_CHECK_ARG(d->stat_tile0 >= 0 && d->stat_tile0 + tiles <= d->stat_tiles);
     }
-    EAB_CHECK_ARG((long long)d->B * eab_conv_tiles(d->T, d->No, d->bm) < (1ll << 31));
+    EAB_CHECK_ARG((long long)d->B * (eab_conv_tiles(d->T, d->No, d->bm) + (d->ph1_No > 0 ? eab_conv_tiles(d->T, d->ph1_No, d->bm) : 0)) < (1ll << 31));
     hipStream_t s = eab_stream(stream);
+    if (d->korder == EAB_KORDER_FRAG) return eab_conv_st(d, s);       // small-tile kernel (conv_st.hip)
     const int mi = d->bm / 64;
     const bool vec = (d->C0 % 4 == 0) && (d->C1 % 4 == 0);
     const bool has_xf = d->xf_mode != EAB_XF_NONE && (d->xf0 || d->xf1 || fin);

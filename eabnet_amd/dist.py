@@ -90,6 +90,8 @@ def launch_local(n: int, argv: Sequence[str], env: Optional[dict] = None, timeou
     line is the job's); every rank inherits stderr.  Returns the worst exit code; a failing rank ends the rest."""
     base = dict(os.environ if env is None else env)
     base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    # this image's host driver only supports dmabuf IPC: without it RCCL's intra-node transport (and any CUDA-tensor sharing
+    # across processes) fails with `hipIpcGetMemHandle: invalid argument`.  The launching shell normally exports it already.
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     procs = []
     for r in range(n):
@@ -97,6 +99,21 @@ def launch_local(n: int, argv: Sequence[str], env: Optional[dict] = None, timeou
         procs.append(subprocess.Popen([sys.executable, *argv], env=e,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     import time
+
+    def reap(ps, grace: float = 10.0) -> None:
+        """SIGTERM, a grace period, then SIGKILL -- and always wait(): no zombies, and no rank still tearing its GPU
+        context down when the caller starts the next job (a rank stuck inside an RCCL collective can ignore SIGTERM)."""
+        for q in ps:
+            if q.poll() is None:
+                q.terminate()
+        t_end = time.monotonic() + grace
+        for q in ps:
+            try:
+                q.wait(timeout=max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                q.kill()
+                q.wait()
+
     t0, rc = time.monotonic(), 0
     alive = list(procs)
     while alive:
@@ -107,11 +124,11 @@ def launch_local(n: int, argv: Sequence[str], env: Optional[dict] = None, timeou
             alive.remove(p)
             if code != 0:
                 rc = rc or code
-                for q in alive:                      # one rank failed: the others would wait at a barrier forever
-                    q.terminate()
-        if timeout is not None and time.monotonic() - t0 > timeout:
-            for q in alive:
-                q.kill()
+                reap(alive)                          # one rank failed: the others would wait at a barrier forever
+                alive = []
+                break
+        if alive and timeout is not None and time.monotonic() - t0 > timeout:
+            reap(alive, grace=2.0)
             return rc or 124
         time.sleep(0.05)
     return rc

@@ -182,6 +182,12 @@ class _Bound:
                 for j in range(_lib.MAX_TAPS):
                     d.dt[j] = op.dt[j] if j < len(op.dt) else 0
                     d.ioff[j] = op.ioff[j] if j < len(op.ioff) else 0
+                # second output-column phase served by the same launch (small-tile kernel only)
+                d.ph1_w = A(op.ph1_w)
+                d.ph1_No, d.ph1_ophase, d.ph1_Kpad, d.ph1_ntaps = int(op.ph1_No), int(op.ph1_ophase), int(op.ph1_Kpad), len(op.ph1_dt)
+                for j in range(_lib.MAX_TAPS):
+                    d.ph1_dt[j] = op.ph1_dt[j] if j < len(op.ph1_dt) else 0
+                    d.ph1_ioff[j] = op.ph1_ioff[j] if j < len(op.ph1_ioff) else 0
             elif op.kind == prg.OP_IN_FINALIZE:
                 o.i[0:5] = [op.B, op.C, op.nsets, op.stat_tiles, op.count]
                 o.f[0] = op.eps
@@ -280,6 +286,17 @@ class _Bound:
 # ----------------------------------------------------------------------------
 # the module
 # ----------------------------------------------------------------------------
+def _warn_operator_path(module: nn.Module, reason: str) -> None:
+    """One warning per module when `use_hip_training` is on but a differentiable forward runs on PyTorch-ROCm operators
+    (autograd_path.py, ~5x slower at the training benchmark's size): the switch must not be silent."""
+    if module.__dict__.get("_warned_operator_path"):
+        return
+    module.__dict__["_warned_operator_path"] = True
+    import warnings
+    warnings.warn(f"{type(module).__name__}: training forward on PyTorch-ROCm operators instead of the HIP training programs "
+                  f"({reason}); module.training_backend == 'operators'", RuntimeWarning, stacklevel=3)
+
+
 class _HipModule(nn.Module):
     """Shared machinery of the two networks: reference-keyed parameters, the lowered-program cache
     (one resident shape, re-packed when a parameter or buffer changes) and the replay knobs."""
@@ -303,6 +320,9 @@ class _HipModule(nn.Module):
         # training forward/backward on the HIP programs (train.py) where the topology allows; False = the
         # PyTorch-ROCm operator path (autograd_path.py) everywhere
         self.use_hip_training = True
+        # which path the most recent differentiable forward took: "hip" (train.py / train_gag.py programs) or
+        # "operators" (autograd_path.py, PyTorch-ROCm); None before the first one
+        self.training_backend = None
 
     def _param_fingerprint(self) -> tuple:
         """Change detector for the packed weights (runs on every forward).  Every parameter / buffer slot
@@ -412,8 +432,13 @@ class EaBNet(_HipModule):
             from . import train
             if self.use_hip_training and inpt.is_cuda and not inpt.requires_grad and torch.is_grad_enabled() \
                     and train.supported(self.cfg) and next(self.parameters()).is_cuda:
+                self.training_backend = "hip"
                 return train.forward_train(self, inpt)
             from .autograd_path import forward_autograd
+            self.training_backend = "operators"
+            if self.use_hip_training and inpt.is_cuda:
+                _warn_operator_path(self, "input requires grad" if inpt.requires_grad else
+                                    f"topology outside train.supported(): {train.unsupported_reason(self.cfg)}")
             return forward_autograd(self, inpt)
         if not inpt.is_cuda:
             raise _lib.EabError("eabnet_amd.EaBNet inference runs on MI355X only: move the input (and module) to "
@@ -714,8 +739,13 @@ class GaGNet(_HipModule):
             if self.use_hip_training and inpt.is_cuda and pre_x.is_cuda and not inpt.requires_grad and not pre_x.requires_grad \
                     and torch.is_grad_enabled() and train_gag.supported(self.cfg) and next(self.parameters()).is_cuda \
                     and not (self.norm_type == "BN" and self.training):
+                self.training_backend = "hip"
                 return train_gag.forward_train(self, inpt, pre_x)
             from .autograd_path import forward_gagnet
+            self.training_backend = "operators"
+            if self.use_hip_training and inpt.is_cuda:
+                _warn_operator_path(self, "an input requires grad" if (inpt.requires_grad or pre_x.requires_grad) else
+                                    "post-filter topology outside train_gag.supported() (default U2 / IN / cat / causal only)")
             return forward_gagnet(self, inpt, pre_x)
         if not (inpt.is_cuda and pre_x.is_cuda):
             raise _lib.EabError("eabnet_amd.GaGNet inference runs on MI355X only: move the inputs (and module) to "
@@ -961,6 +991,11 @@ class _HostStager:
             slot["copied"].record(self.stream)
         torch.cuda.current_stream(self.device).wait_event(slot["copied"])
         slot["used"] = True
+        if src is t:
+            # the copy kernel reads the CALLER's pinned buffer: nothing ties that buffer's contents or lifetime to our side
+            # stream (a reused pinned batch, a DataLoader(pin_memory=True) block recycled for the next batch), so return only
+            # when the read has finished -- what the reference's blocking x.to(device) gives (train_distributed.py:76-77)
+            slot["copied"].synchronize()
         return slot["dev"], slot["consumed"]
 
 

@@ -38,7 +38,7 @@ GAG_PRE_LD = 324   # floats per (b, t) row of the interleaved previous estimate:
 GAG_LIN_LD = 192   # 161 linear outputs padded to three 64-column tiles
 PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 PREC_CODE = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16": PREC_BF16}
-KORDER_TAP, KORDER_CHUNK = 0, 1
+KORDER_TAP, KORDER_CHUNK, KORDER_FRAG = 0, 1, 2
 PATCH_MAX = 352    # CG_PMAX in csrc/conv_gemm.hip
 MAX_TAPS = 16
 EPS_IN = 1e-5      # nn.InstanceNorm*d default (reference EaBNet.py:684,686)
@@ -128,6 +128,13 @@ class ConvOp:
     fz_beta1: Optional[Ref] = None
     fz_xf1: Optional[Ref] = None
     fz_eps: float = 0.0
+    # KORDER_FRAG (small-tile kernel): second output-column phase of a transposed convolution in the same launch
+    ph1_w: Optional[Ref] = None
+    ph1_No: int = 0
+    ph1_ophase: int = 0
+    ph1_Kpad: int = 0
+    ph1_dt: List[int] = field(default_factory=list)
+    ph1_ioff: List[int] = field(default_factory=list)
 
 
 @dataclass
@@ -352,6 +359,40 @@ def pack_f16x3(wp: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(out).view(np.float32).reshape(N, K)
 
 
+def _frag_index(N: int, K: int):
+    """(n, k) of every element of the fragment-order array [N/16][K/16][64 lanes][4] (include/eabnet_hip.h, EAB_KORDER_FRAG)"""
+    nb, m2, lane, j = np.meshgrid(np.arange(N // 16), np.arange(K // 16), np.arange(64), np.arange(4), indexing="ij")
+    return nb * 16 + (lane & 15), 16 * m2 + 8 * (j >> 1) + 2 * (lane >> 4) + (j & 1)
+
+
+def frag_row_order(N: int, dual: bool) -> np.ndarray:
+    """fragment row -> original row.  Natural, except the dual-gate form: row block 2w+g (g = 0 value, 1 gate) holds
+    the original rows g*N/2 + 16w .. +15, so that a wave owns value and gate of the same 16 channels."""
+    r = np.arange(N)
+    if not dual:
+        return r
+    return ((r // 16) % 2) * (N // 2) + (r // 32) * 16 + r % 16
+
+
+def pack_frag(wp: np.ndarray, dual: bool = False) -> np.ndarray:
+    """[N][Kpad] (rows in original order, k = tap*UPT*16 + channel) -> MFMA-fragment order for conv_st_kernel:
+    a wave's b128 load of (row block, K step) is one contiguous 1-KB read of exactly its v_mfma_f32_16x16x4 operands."""
+    N, K = wp.shape
+    assert N % 16 == 0 and K % 16 == 0
+    n, k = _frag_index(N, K)
+    return np.ascontiguousarray(wp[frag_row_order(N, dual)][n, k], dtype=np.float32).reshape(-1)
+
+
+def unpack_frag(flat: np.ndarray, N: int, K: int, dual: bool = False) -> np.ndarray:
+    """inverse of pack_frag (tests/emulator.py)"""
+    n, k = _frag_index(N, K)
+    w = np.empty((N, K), np.float32)
+    w[n, k] = np.asarray(flat, np.float32).reshape(n.shape)
+    out = np.empty_like(w)
+    out[frag_row_order(N, dual)] = w
+    return out
+
+
 class WeightArena:
     """Flat fp32 buffer of packed parameters + name -> Ref table."""
 
@@ -422,6 +463,10 @@ class Lowering:
             raise ValueError(f"precision must be 'f32', 'f16x3' or 'bf16', got {precision!r}")
         self.precision = precision
         self.patch = os.environ.get("EAB_PATCH", "1") != "0"      # tuning knob: 0 = gather pipeline everywhere
+        # small-tile kernel (csrc/conv_st.hip, exact fp32) for the latency-bound launches: the S-TCN and the 64-column unit
+        # convolutions with at most `st_maxno` output columns; EAB_ST=0 puts everything back on conv_gemm_kernel
+        self.st = os.environ.get("EAB_ST", "1") != "0" and precision == "f32"
+        self.st_maxno = int(os.environ.get("EAB_ST_MAXNO", "5"))
         specs = self.spec_fn(cfg)
         specs = {k: v for k, v in specs.items() if v.kind != "bn_count"}     # the step counter is not arithmetic
         missing = [k for k in specs if k not in params]
@@ -522,16 +567,35 @@ class Lowering:
             return int(os.environ["EAB_BM"])
         return 128 if self.B * conv_tiles(self.T, No, 128) >= 2 * CUS else 64
 
+    def pick_st_bm(self, No: int, N: int, Kpad: int, dual: bool = False, max_tiles: Optional[int] = None) -> int:
+        """Rows per tile of a small-tile launch: the largest of 64 / 32 / 16 that still gives the chip two workgroups per
+        CU (else 16), within the kernel's LDS budget (the whole K extent of a tile is staged at once) and, when a consumer
+        merges this launch's InstanceNorm partials itself, within its 64-tile limit."""
+        if os.environ.get("EAB_ST_BM"):                  # tuning knob
+            return int(os.environ["EAB_ST_BM"])
+        rows = (self.chunk or self.T) * No
+        cands = [bm for bm in (64, 32, 16)
+                 if (bm < 64 or N == 64) and (2 if dual else 1) * bm * (Kpad + 4) * 4 <= 96 * 1024]
+        ok = [bm for bm in cands if max_tiles is None or conv_tiles(self.T, No, bm) <= max_tiles]
+        assert ok, "no small-tile geometry fits"
+        for bm in ok:
+            if self.B * ((rows + bm - 1) // bm) >= 2 * CUS:
+                return bm
+        return ok[-1]
+
     def emit_conv(self, name: str, srcs: Sequence[Act], w: Ref, bias: Optional[Ref], N: int, Kpad: int,
                   Fout: int, No: int, ostride: int, ophase: int, istride: int, dt, ioff, epi: int,
                   dst: Ref, stats: Optional[Ref] = None, nsets: int = 0, stat_slopes=(None, None),
                   stat_tiles: int = 0, stat_tile0: int = 0, bm: Optional[int] = None, aux: Optional[Ref] = None,
                   dst_acc: Optional[Ref] = None, fin: Optional[dict] = None, slope1: Optional[Ref] = None,
-                  xf1: Optional[Ref] = None, patch_ok: bool = True) -> ConvOp:
+                  xf1: Optional[Ref] = None, patch_ok: bool = True, st: bool = False, ph1: Optional[dict] = None) -> ConvOp:
         """fin = dict(stats, tiles, nsets, count, norms=[...]) asks the kernel to reduce the
         producer's InstanceNorm partials itself (single source, transform order from srcs[0].mode);
-        slope1 (+ xf1 when the table is static) = second transform of the SAME source for EPI_DUALGATE."""
+        slope1 (+ xf1 when the table is static) = second transform of the SAME source for EPI_DUALGATE.
+        st = small-tile kernel (KORDER_FRAG): `w` (and ph1["w"]) are [N][Kpad] in ORIGINAL row order and are re-packed in
+        fragment order here; ph1 = dict(w, Kpad, No, ophase, dt, ioff): second output-column phase in the same launch."""
         assert 1 <= len(srcs) <= 2 and len(dt) == len(ioff) <= MAX_TAPS
+        assert st or ph1 is None
         s0 = srcs[0]
         s1 = srcs[1] if len(srcs) == 2 else None
         modes = {s.mode for s in srcs if s.xf is not None or (fin is not None and s.mode != XF_NONE)}
@@ -546,8 +610,25 @@ class Lowering:
         # patch pipeline (input patch of a 16-channel chunk staged once, taps read it shifted): pays
         # when several taps re-read the same inputs; needs the patch of a tile to fit its LDS area
         korder = KORDER_TAP
+        ph1kw = {}
+        if st:
+            assert self.precision == "f32" and N in (64, 128, 256) and bm in (16, 32, 64)
+            assert Kpad <= {64: 256, 128: 320, 256: 64}[N], "small-tile kernel: the K extent must fit the wave's registers"
+            assert epi in (EPI_LINEAR, EPI_RELU, EPI_ADD, EPI_DUALGATE)
+            korder = KORDER_FRAG
+            dual = epi == EPI_DUALGATE
+
+            def frag(ref: Ref, K: int) -> Ref:
+                key = next(k for k, r in self.W.index.items() if r == ref)
+                return self.W.add(key + ".frag", pack_frag(self.W.chunks_by_name[key].reshape(N, K), dual))
+            w = frag(w, Kpad)
+            if ph1 is not None:
+                assert ph1["Kpad"] == len(ph1["dt"]) * upt * 16 and ph1["Kpad"] <= Kpad
+                ph1kw = dict(ph1_w=frag(ph1["w"], ph1["Kpad"]), ph1_No=ph1["No"], ph1_ophase=ph1["ophase"], ph1_Kpad=ph1["Kpad"],
+                             ph1_dt=list(ph1["dt"]), ph1_ioff=list(ph1["ioff"]))
+                self.flops += 2 * self.B * self.T * ph1["No"] * N * len(ph1["dt"]) * (C0 + C1)
         patch_min_n = int(os.environ.get("EAB_PATCH_MIN_N", "128"))      # tuning knob
-        if (self.patch and N >= patch_min_n and len(dt) >= 2 and s0.F > 1 and epi != EPI_DUALGATE and mode != XF_PRELU_NORM
+        if (not st and self.patch and N >= patch_min_n and len(dt) >= 2 and s0.F > 1 and epi != EPI_DUALGATE and mode != XF_PRELU_NORM
                 and C0 % 4 == 0 and C1 % 4 == 0 and patch_ok):
             for cand in ((bm,) if bm == 64 else (128, 64)):
                 if patch_positions(cand, No, s0.F, istride, dt, ioff) <= PATCH_MAX:
@@ -585,7 +666,7 @@ class Lowering:
                     Cout=N // 2 if epi in (EPI_GLU, EPI_DUALGATE) else N, stats=stats, nsets=nsets,
                     stat_slope0=stat_slopes[0], stat_slope1=stat_slopes[1], stat_tiles=stat_tiles,
                     stat_tile0=stat_tile0, bm=bm, name=name, precision=prec, korder=korder, win=bool(self.chunk),
-                    **finkw)
+                    **finkw, **ph1kw)
         self.ops.append(op)
         self.flops += 2 * self.B * self.T * No * N * len(dt) * (C0 + C1)
         return op
@@ -617,6 +698,12 @@ class Lowering:
                                    xf1=xfs[1] if nsets == 2 else None, name=name))
         return xfs
 
+    def st_ok(self, srcs: Sequence[Act], N: int, glu: bool) -> bool:
+        """the small-tile kernel's domain: exact fp32, plain 64/128/256-column launches, source channels 4 * 2^k"""
+        return (self.st and not glu and not self.cln and N in (64, 128, 256) and all(a.C in (64, 128, 256) for a in srcs)
+                and not any(a.raw or a.ref.arena == "in" for a in srcs)
+                and all(a.C <= 128 for a in srcs if a.xf is not None))
+
     # -- 2-D units -------------------------------------------------------------------
     def conv2d_fwd(self, name: str, srcs: Sequence[Act], wkey: str, glu: bool, norm: Optional[str], act: str,
                    in_perm: Optional[np.ndarray] = None, add: Optional[Act] = None) -> Act:
@@ -636,7 +723,8 @@ class Lowering:
         bref = self.W.add(f"{wkey}.bias#packed", self.P[f"{wkey}.bias"][order])
         Cout = N // 2 if glu else N
         dst = self.alloc_act(Fout, Cout)
-        bm = self.pick_bm(Fout)
+        st = self.st_ok(srcs, N, glu) and Fout <= self.st_maxno
+        bm = self.pick_st_bm(Fout, N, wp.shape[1]) if st else self.pick_bm(Fout)
         tiles = conv_tiles(self.T, Fout, bm)
         cln = self.cln and norm is not None
         xf = None if cln else self.fixed_norm(norm, Cout)
@@ -644,7 +732,7 @@ class Lowering:
         op = self.emit_conv(name, srcs, wref, bref, N, wp.shape[1], Fout, Fout, 1, 0, 2,
                             [a - (kt - 1) for a, _ in taps], [c for _, c in taps],
                             EPI_GLU if glu else EPI_LINEAR, dst, stats, 1 if stats else 0, (None, None),
-                            tiles if stats else 0, 0, bm)
+                            tiles if stats else 0, 0, bm, st=st)
         if cln:
             return self.cln_norm(name, dst, Fout, Cout, norm, f"{act}.weight", XF_NORM_PRELU, add)
         if xf is None:
@@ -676,20 +764,33 @@ class Lowering:
         Cout = N // 2 if glu else N
         dst = self.alloc_act(Fout, Cout)
         No = [(Fout + 1) // 2, Fout // 2]
-        bm = self.pick_bm(No[0])
+        upt = (Cin + 15) // 16
+        st = self.st_ok(srcs, N, glu) and No[0] <= self.st_maxno
+        bm = self.pick_st_bm(No[0] + No[1], N, len(range(0, kf, 2)) * kt * upt * 16) if st else self.pick_bm(No[0])
         tiles = [conv_tiles(self.T, n, bm) for n in No]
         cln = self.cln
         xf = None if cln else self.fixed_norm(norm, Cout)
         stats = self.alloc(self.B * sum(tiles) * Cout * 4) if (xf is None and not cln) else None
         phase_ops = []
+        phases = []
         for ph in (0, 1):
             taps = [(a, c) for a in range(kt) for c in range(ph, kf, 2)]
             wp = pack_taps(wn, [a * kf + c for a, c in taps])
             wref = self.W.add(f"{wkey}.weight#packed.ph{ph}", wp)
-            phase_ops.append(self.emit_conv(f"{name}.ph{ph}", srcs, wref, bref, N, wp.shape[1], Fout, No[ph], 2, ph, 1,
-                                            [-a for a, _ in taps], [-(c - ph) // 2 for _, c in taps],
-                                            EPI_GLU if glu else EPI_LINEAR, dst, stats, 1 if stats else 0, (None, None),
-                                            sum(tiles) if stats else 0, (0 if ph == 0 else tiles[0]) if stats else 0, bm))
+            phases.append(dict(w=wref, Kpad=wp.shape[1], No=No[ph], ophase=ph, dt=[-a for a, _ in taps],
+                               ioff=[-(c - ph) // 2 for _, c in taps]))
+        if st:
+            # small-tile kernel: both output-column phases in ONE launch (tiles of phase 0, then of phase 1, per utterance)
+            p0, p1 = phases
+            phase_ops.append(self.emit_conv(name, srcs, p0["w"], bref, N, p0["Kpad"], Fout, No[0], 2, 0, 1, p0["dt"], p0["ioff"],
+                                            EPI_LINEAR, dst, stats, 1 if stats else 0, (None, None),
+                                            sum(tiles) if stats else 0, 0, bm, st=True, ph1=p1))
+        else:
+            for ph, q in enumerate(phases):
+                phase_ops.append(self.emit_conv(f"{name}.ph{ph}", srcs, q["w"], bref, N, q["Kpad"], Fout, No[ph], 2, ph, 1,
+                                                q["dt"], q["ioff"],
+                                                EPI_GLU if glu else EPI_LINEAR, dst, stats, 1 if stats else 0, (None, None),
+                                                sum(tiles) if stats else 0, (0 if ph == 0 else tiles[0]) if stats else 0, bm))
         if cln:
             return self.cln_norm(name, dst, Fout, Cout, norm, f"{act}.weight", XF_NORM_PRELU, add)
         if xf is None:
@@ -746,10 +847,18 @@ class Lowering:
             return self.tcm_cln(pre, x, dilation, x_acc, perm)
         cfg, T, B = self.cfg, self.T, self.B
         D, cd, kd = cfg.d_feat, cfg.cd1, cfg.kd1
-        bm = 64
-        tiles = conv_tiles(T, 1, bm)
         bn = self.bn                                   # BatchNorm eval: static tables, no statistics at all
-        assert bn or tiles <= 64, "in-kernel finalisation is sized for <= 64 partial tiles per utterance"
+        Kd = kd * ((cd + 15) // 16) * 16
+        use_st = (self.st and D == 256 and cd == 64 and conv_tiles(T, 1, 32) <= 64)
+        if use_st:
+            # small-tile kernel: 16- or 32-row tiles (2-4 x the workgroups of a 64-row launch, one memory round trip each)
+            mt = None if bn else 64
+            bm_in, bm_lr, bm_out = (self.pick_st_bm(1, cd, D, max_tiles=mt), self.pick_st_bm(1, 2 * cd, Kd, dual=True, max_tiles=mt),
+                                    self.pick_st_bm(1, D, cd))
+        else:
+            bm_in = bm_lr = bm_out = 64
+        tiles, tiles_lr = conv_tiles(T, 1, bm_in), conv_tiles(T, 1, bm_lr)
+        assert bn or max(tiles, tiles_lr) <= 64, "in-kernel finalisation is sized for <= 64 partial tiles per utterance"
         nL, nR, nO = f"{pre}.left_conv.1", f"{pre}.right_conv.1", f"{pre}.out_conv.1"
         # in_conv 1x1 (no bias); statistics of BOTH branch PReLUs of its output
         w_in = self.P[f"{pre}.in_conv.weight"][:, perm, :]               # (cd, D, 1)
@@ -758,28 +867,31 @@ class Lowering:
         st = None if bn else self.alloc(B * tiles * 2 * cd * 4)
         slL, slR = self.vec(f"{pre}.left_conv.0.weight"), self.vec(f"{pre}.right_conv.0.weight")
         self.emit_conv(f"{pre}.in_conv", [x], wref, None, cd, D, 1, 1, 1, 0, 1, [0], [0], EPI_LINEAR, y,
-                       st, 0 if bn else 2, (None, None) if bn else (slL, slR), 0 if bn else tiles, 0, bm)
+                       st, 0 if bn else 2, (None, None) if bn else (slL, slR), 0 if bn else tiles, 0, bm_in, st=use_st)
         # z = left(y) * sigmoid(right(y)): columns [0,cd) see PReLU_L/IN_L(y), columns [cd,2cd) PReLU_R/IN_R(y)
         # taps (EaBNet.py:550-553): all in the past when causal, centred otherwise
         span = (kd - 1) * dilation
         lead = span if cfg.is_causal else span // 2
         dts = [j * dilation - lead for j in range(kd)]
         wlr = np.concatenate([self.P[f"{pre}.left_conv.3.weight"], self.P[f"{pre}.right_conv.3.weight"]], axis=0)
-        wd = self.W.add(f"{pre}.lr_conv.weight#packed", pack_taps(wlr[glu_row_order(2 * cd)], range(kd)))
+        if use_st:     # rows stay in original order: emit_conv packs them in fragment order (value / gate blocks per wave)
+            wd = self.W.add(f"{pre}.lr_conv.weight#rows", pack_taps(wlr, range(kd)))
+        else:
+            wd = self.W.add(f"{pre}.lr_conv.weight#packed", pack_taps(wlr[glu_row_order(2 * cd)], range(kd)))
         z = self.alloc_act(1, cd)
-        st2 = None if bn else self.alloc(B * tiles * cd * 4)
+        st2 = None if bn else self.alloc(B * tiles_lr * cd * 4)
         slO = self.vec(f"{pre}.out_conv.0.weight")
         self.emit_conv(f"{pre}.lr_conv", [Act(y, 1, cd, self.bn_xf(nL) if bn else None, slL, XF_PRELU_NORM)], wd, None,
-                       2 * cd, kd * ((cd + 15) // 16) * 16, 1, 1, 1, 0, 1, dts, [0] * kd, EPI_DUALGATE, z, st2,
-                       0 if bn else 1, (None, None) if bn else (slO, None), 0 if bn else tiles, 0, bm, slope1=slR,
+                       2 * cd, Kd, 1, 1, 1, 0, 1, dts, [0] * kd, EPI_DUALGATE, z, st2,
+                       0 if bn else 1, (None, None) if bn else (slO, None), 0 if bn else tiles_lr, 0, bm_lr, slope1=slR,
                        xf1=self.bn_xf(nR) if bn else None,
-                       fin=None if bn else dict(stats=st, tiles=tiles, nsets=2, count=T, norms=[nL, nR]))
+                       fin=None if bn else dict(stats=st, tiles=tiles, nsets=2, count=T, norms=[nL, nR]), st=use_st)
         w_out = self.P[f"{pre}.out_conv.2.weight"][perm]                  # (D, cd, 1), rows permuted
         wo = self.W.add(f"{pre}.out_conv.2.weight#packed", pack_taps(w_out, [0]))
         xn = self.alloc_act(1, D)
         self.emit_conv(f"{pre}.out_conv", [Act(z, 1, cd, self.bn_xf(nO) if bn else None, slO, XF_PRELU_NORM)], wo, None,
-                       D, cd, 1, 1, 1, 0, 1, [0], [0], EPI_ADD, xn, bm=bm, aux=x.ref, dst_acc=x_acc,
-                       fin=None if bn else dict(stats=st2, tiles=tiles, nsets=1, count=T, norms=[nO]))
+                       D, cd, 1, 1, 1, 0, 1, [0], [0], EPI_ADD, xn, bm=bm_out, aux=x.ref, dst_acc=x_acc,
+                       fin=None if bn else dict(stats=st2, tiles=tiles_lr, nsets=1, count=T, norms=[nO]), st=use_st)
         return Act(xn, 1, D)
 
     def tcm_cln(self, pre: str, x: Act, dilation: int, x_acc: Optional[Ref], perm: np.ndarray) -> Act:

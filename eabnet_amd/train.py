@@ -44,11 +44,30 @@ XF_NORM_PRELU, XF_PRELU_NORM = prg.XF_NORM_PRELU, prg.XF_PRELU_NORM
  OP_FILTER_SUM, OP_FS_BWD, OP_LN_FWD, OP_LN_BWD, OP_LSTM_TRAIN, OP_LSTM_BWD, OP_WGRAD) = range(16, 33)
 NB_SUMS_ZEROED = 0x100   # include/eabnet_hip.h EAB_NB_SUMS_ZEROED
 MLP_LD = 64          # the second Linear of w_dnn is run with its 2M rows padded to one 64-column tile
+TRAIN_BOUND_CACHE = 3   # bound training programs kept per module (LRU over (B, T, F, device, precision))
 
 
 def supported(cfg: NetConfig) -> bool:
     return (cfg.is_u2 and cfg.bf_type == "lstm" and cfg.topo_type == "mimo" and cfg.intra_connect == "cat"
             and cfg.norm_type == "IN" and 2 * cfg.M <= MLP_LD)
+
+
+def unsupported_reason(cfg: NetConfig) -> str:
+    """which constructor switch keeps a configuration off the HIP training programs ('' when supported)"""
+    why = []
+    if not cfg.is_u2:
+        why.append("is_u2=False")
+    if cfg.bf_type != "lstm":
+        why.append(f"bf_type={cfg.bf_type!r}")
+    if cfg.topo_type != "mimo":
+        why.append(f"topo_type={cfg.topo_type!r}")
+    if cfg.intra_connect != "cat":
+        why.append(f"intra_connect={cfg.intra_connect!r}")
+    if cfg.norm_type != "IN":
+        why.append(f"norm_type={cfg.norm_type!r}")
+    if 2 * cfg.M > MLP_LD:
+        why.append(f"M={cfg.M} > {MLP_LD // 2}")
+    return ", ".join(why)
 
 
 @dataclass
@@ -1042,11 +1061,16 @@ def forward_train(module, inpt: torch.Tensor) -> torch.Tensor:
     cache = module.__dict__.setdefault("_train_bound", {})
     prec = "bf16" if module.precision == "bf16" else "f32"
     key = (B, T, F, str(x.device), prec)
-    bound = cache.get(key)
+    bound = cache.pop(key, None)
     if bound is None:
-        cache.clear()
+        # a small LRU of bound programs (variable-length batches, a smaller last batch, alternating train / validation
+        # shapes): re-lowering and re-capturing two hipGraphs on every shape change costs seconds
+        while len(cache) >= TRAIN_BOUND_CACHE:
+            torch.cuda.synchronize(x.device)      # the dropped program's arenas may still be read by kernels in flight
+            cache.pop(next(iter(cache)))
         with torch.cuda.device(x.device):
-            bound = cache[key] = TrainBound(lower_train(module.cfg, B, T, F, prec), x.device)
+            bound = TrainBound(lower_train(module.cfg, B, T, F, prec), x.device)
+    cache[key] = bound                               # most recently used last
     bound.use_graph = bool(getattr(module, "use_graph", True)) and not torch.cuda.is_current_stream_capturing()
     sd = dict(module.named_parameters())
     params = [sd[k] for k in bound.prog.keys]

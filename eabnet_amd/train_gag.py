@@ -260,11 +260,16 @@ def forward_train(module, inpt: torch.Tensor, pre_x: torch.Tensor) -> List[torch
     cache = module.__dict__.setdefault("_train_bound", {})
     prec = "bf16" if module.precision == "bf16" else "f32"
     key = (B, T, F, str(a.device), prec)
-    bound = cache.get(key)
+    bound = cache.pop(key, None)
     if bound is None:
-        cache.clear()
+        # a small LRU of bound programs (variable-length batches, a smaller last batch, alternating train / validation
+        # shapes): re-lowering and re-capturing two hipGraphs on every shape change costs seconds
+        while len(cache) >= tr.TRAIN_BOUND_CACHE:
+            torch.cuda.synchronize(a.device)      # the dropped program's arenas may still be read by kernels in flight
+            cache.pop(next(iter(cache)))
         with torch.cuda.device(a.device):
-            bound = cache[key] = TrainBound(lower_train(module.cfg, B, T, F, prec), a.device)
+            bound = TrainBound(lower_train(module.cfg, B, T, F, prec), a.device)
+    cache[key] = bound                               # most recently used last
     bound.use_graph = bool(getattr(module, "use_graph", True)) and not torch.cuda.is_current_stream_capturing()
     bound.sync_group = module.__dict__.get("grad_allreduce", None)
     sd = dict(module.named_parameters())

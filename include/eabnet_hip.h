@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EAB_ABI_VERSION 4
+#define EAB_ABI_VERSION 5
 
 #define EAB_OK          0
 #define EAB_EINVAL      1   /* bad argument (shape, alignment, limit) */
@@ -215,7 +215,7 @@ typedef struct eab_conv_desc {
     const float* stat_slope1;
     int32_t stat_tiles;     /* tiles per batch element over ALL launches feeding this norm */
     int32_t stat_tile0;     /* first tile index of this launch */
-    int32_t bm;             /* rows per tile: 64 or 128 (host's choice, see eab_conv_tiles) */
+    int32_t bm;             /* rows per tile: 64 or 128 (host's choice, see eab_conv_tiles); 16, 32 or 64 with EAB_KORDER_FRAG */
     /* optional in-kernel InstanceNorm finalisation (replaces eab_in_finalize_f32 + xf0[/xf1]
      * when the producer wrote few tiles): fin_stats = the producer's partials
      * [B][fin_tiles][fin_nsets][C0][4]; set 0 -> transform 0 with (fin_gamma0, fin_beta0),
@@ -258,6 +258,15 @@ typedef struct eab_conv_desc {
     /* training (EAB_EPI_GLU only): optional [B][T][Fout][N] dump of the gated epilogue's two factors in the packed
      * column order -- value columns hold acc+bias, gate columns hold sigmoid(acc+bias) -- read by eab_glu_bwd_f32 */
     float* glu_dump;
+    /* EAB_KORDER_FRAG only (small-tile kernel, csrc/conv_st.hip): the second output-column phase of a transposed
+     * convolution served by the SAME launch.  ph1_No > 0: per batch element the tiles of phase 0 (No, ophase, w, Kpad,
+     * ntaps, dt, ioff above) are followed by the tiles of phase 1 described here; both phases share sources, bias,
+     * epilogue, dst and the statistics array (stat_tile0 must be 0: partial tile index = phase-0 tiles, then phase-1
+     * tiles; stat_tiles = their sum).  ph1_No == 0: single-phase launch. */
+    const float* ph1_w;
+    int32_t ph1_No, ph1_ophase, ph1_ntaps, ph1_Kpad;
+    int32_t ph1_dt[EAB_MAX_TAPS];
+    int32_t ph1_ioff[EAB_MAX_TAPS];
 } eab_conv_desc;
 
 #define EAB_PREC_F32   0
@@ -270,6 +279,14 @@ typedef struct eab_conv_desc {
 #define EAB_PREC_BF16  2
 #define EAB_KORDER_TAP   0
 #define EAB_KORDER_CHUNK 1
+/* EAB_KORDER_FRAG selects the small-tile kernel (csrc/conv_st.hip; exact fp32 only) for latency-bound launches: the
+ * S-TCN's 1-D convolutions and 64-column unit convolutions on few frequency bins.  bm = 16, 32 or 64 rows per tile;
+ * N = 64, 128 or 256; C0, C1 in {64, 128, 256}; epilogues LINEAR / RELU / ADD / DUALGATE.  `w` holds the weights in
+ * MFMA-fragment order, unit order as EAB_KORDER_TAP (k = tap*UPT*16 + channel):
+ *     w[((nb*(Kpad/16) + m2)*64 + lane)*4 + j] = W[16*nb + (lane & 15)][16*m2 + 8*(j >> 1) + 2*(lane >> 4) + (j & 1)]
+ * with rows in natural order, except EAB_EPI_DUALGATE: row block 2*w + g (g = 0 value, 1 gate) holds the original rows
+ * g*Cout + 16*w .. +15, so a wave owns value and gate of the same 16 channels. */
+#define EAB_KORDER_FRAG  2
 
 /* number of tiles per batch element a launch with this geometry produces */
 int eab_conv_tiles(int T, int No, int bm);

@@ -82,6 +82,21 @@ class Emulator:
 
     # ------------------------------------------------------------------ ops
     def conv(self, op: prg.ConvOp):
+        if op.korder == prg.KORDER_FRAG:
+            # small-tile kernel: weights in MFMA-fragment order, optionally two output-column phases in one launch.
+            # Interpreted as one or two launches of the tap-ordered form (what the fragment layout encodes).
+            import dataclasses
+            dual = op.epi == prg.EPI_DUALGATE
+            order = prg.glu_row_order(op.N) if dual else np.arange(op.N)
+            passes = [(op.w, op.Kpad, op.No, op.ophase, op.dt, op.ioff, op.stat_tile0)]
+            if op.ph1_No > 0:
+                passes.append((op.ph1_w, op.ph1_Kpad, op.ph1_No, op.ph1_ophase, op.ph1_dt, op.ph1_ioff,
+                               op.stat_tile0 + prg.conv_tiles(op.T, op.No, op.bm)))
+            for wref, K, No_, oph, dt, ioff, st0 in passes:
+                self.arena["tmp"] = prg.unpack_frag(self.v(wref, (op.N * K,)), op.N, K, dual)[order].reshape(-1)
+                self.conv(dataclasses.replace(op, korder=prg.KORDER_TAP, w=prg.Ref("tmp", 0), Kpad=K, No=No_, ophase=oph, dt=list(dt),
+                                              ioff=list(ioff), stat_tile0=st0, ph1_w=None, ph1_No=0, ph1_dt=[], ph1_ioff=[]))
+            return
         B, T, Fin, No = op.B, op.T, op.Fin, op.No
         def xform(x, tab, a):
             s, h = tab[:, None, None, :, 0], tab[:, None, None, :, 1]
