@@ -131,23 +131,27 @@ def cpu_baseline(state, M: int, L: int, budget_s: float = 15.0):
 _CALIBRATED: list = []
 
 
-def main_train(a, rank, world, dev, is_dist):
-    """BASELINE configs[3] / train_distributed.py:214-230 for the beam-former stage: per step
-    prepare_data (noisy + target STFT) -> net(noisy) -> com_mag_mse_loss -> backward -> clip_grad_norm_(1.0) -> Adam(5e-4),
-    forward and backward on the HIP training programs (eabnet_amd/train.py), gradients averaged over the ranks."""
+def train_measure(rank, world, dev, is_dist, *, precision="f32", two_stage=False, operator_path=False, ddp=False,
+                  steps=5, warmup=2, per_op="", roofline=True, check=False):
+    """BASELINE configs[3] / train_distributed.py:214-230: per step prepare_data (noisy + target STFT) -> net(noisy) ->
+    com_mag_mse_loss (two_stage: eabnet_with_postnet_loss of the model train_distributed.py:181 builds) -> backward ->
+    clip_grad_norm_(1.0) -> Adam(5e-4), forward and backward on the HIP training programs (eabnet_amd/train.py, train_gag.py),
+    gradients averaged over the ranks.  Returns the result dict of one configuration (nothing is printed).
+    check=True: before the timed steps, the loss of the first step is compared with the PyTorch-ROCm operator path
+    (autograd_path.py) on the same parameters and batch, and every gradient must be finite."""
     from eabnet_amd import train as tr
     B, M, seconds = 6, MICS, 6.0                            # train_distributed.py:273,279 (batch 6, wav_len 6 s)
     L = int(seconds * SR)
     T = 1 + L // HOP
     net, _ = make_model(M, dev)
     net.train()
-    net.use_hip_training = not a.train_operator_path
-    net.precision = "bf16" if a.precision == "bf16" else "f32"
+    net.use_hip_training = not operator_path
+    net.precision = "bf16" if precision == "bf16" else "f32"
     two = None
-    if a.train_two_stage:
+    if two_stage:
         # the model train_distributed.py:181 actually builds: beam-former + GaGNet post-filter, both trained
         # (eabnet_with_postnet_loss, :225), the post-filter fed esti0.detach() (EaBNet.py:142).  Both stages run on their HIP
-        # training programs (train.py, train_gag.py); --train-operator-path puts both on PyTorch-ROCm operators.
+        # training programs (train.py, train_gag.py); operator_path puts both on PyTorch-ROCm operators.
         pa = argparse.Namespace(
             k1=(2, 3), k2=(1, 3), c=64, M=M, embed_dim=64, kd1=5, cd1=64, d_feat=256, p=6, q=3, is_causal=True, is_u2=True,
             bf_type="lstm", topo_type="mimo", intra_connect="cat", norm_type="IN", ref_mic=0, freeze_eabnet=False,
@@ -171,7 +175,7 @@ def main_train(a, rank, world, dev, is_dist):
         tr.enable_flat_allreduce(two.postnet)
     elif is_dist:
         tr.broadcast_parameters(net)
-        if a.train_ddp:
+        if ddp:
             model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[dev.index], bucket_cap_mb=64,
                                                               gradient_as_bucket_view=True, static_graph=True)
         else:
@@ -180,25 +184,54 @@ def main_train(a, rank, world, dev, is_dist):
     opt = torch.optim.Adam(trained.parameters(), lr=5e-4)
     frames_list = [T] * B
 
+    def loss_of(noisy, target):
+        if two is not None:
+            return eabnet_amd.eabnet_with_postnet_loss(two(noisy), target, frames_list)["final"]
+        return eabnet_amd.com_mag_mse_loss(model(noisy), target, frames_list)
+
     def step():
         opt.zero_grad(set_to_none=True)
         noisy, target = eabnet_amd.prepare_data(wav, tgt, dev, pd_args)
-        if two is not None:
-            loss = eabnet_amd.eabnet_with_postnet_loss(two(noisy), target, frames_list)["final"]
-        else:
-            loss = eabnet_amd.com_mag_mse_loss(model(noisy), target, frames_list)
+        loss = loss_of(noisy, target)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(trained.parameters(), 1.0)
         opt.step()
         return loss
 
-    for _ in range(max(1, a.warmup)):
+    checked = None
+    if check and not operator_path:
+        # in-run check on the untouched initial parameters: the HIP programs' loss against the operator path's on the same
+        # batch (fp32: 1e-4 relative; bf16 products: its stated 5e-2 bound), all gradients finite
+        noisy, target = eabnet_amd.prepare_data(wav, tgt, dev, pd_args)
+        opt.zero_grad(set_to_none=True)
+        l_hip = loss_of(noisy, target)
+        l_hip.backward()
+        finite = all(bool(torch.isfinite(p.grad).all()) for p in trained.parameters() if p.grad is not None)
+        n_grads = sum(1 for p in trained.parameters() if p.grad is not None)
+        mods = [two.eabnet, two.postnet] if two is not None else [net]
+        for m_ in mods:
+            m_.use_hip_training = False
+        l_op = loss_of(noisy, target)                      # operator path (needs grad mode to be taken; no backward)
+        for m_ in mods:
+            m_.use_hip_training = True
+        rel = abs(float(l_hip.detach()) - float(l_op.detach())) / max(abs(float(l_op.detach())), 1e-12)
+        tol = 1e-4 if precision == "f32" else 5e-2
+        checked = {"loss_hip": float(l_hip.detach()), "loss_operator_path": float(l_op.detach()), "rel_diff": rel, "tolerance": tol,
+                   "gradients_finite": finite, "gradient_tensors": n_grads, "backends": [m_.training_backend for m_ in mods],
+                   "ok": bool(rel <= tol and finite)}
+        del l_op, l_hip
+        opt.zero_grad(set_to_none=True)
+        torch.cuda.empty_cache()
+        if not checked["ok"]:
+            return {"check": checked, "failed": True}
+
+    for _ in range(max(1, warmup)):
         loss = step()
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         loss = step()
     torch.cuda.synchronize()
     dist.barrier()
@@ -207,52 +240,54 @@ def main_train(a, rank, world, dev, is_dist):
     per_rank = dist.gather_over_ranks(el, dev)
     elapsed = dist.max_over_ranks(el, dev)
     assert bool(torch.isfinite(loss)), "training diverged"
-    frames = world * B * T * a.steps
-    if a.train_two_stage:
-        if rank == 0:
-            print(json.dumps({"mode": "training step of the two-stage model (train_distributed.py:181,225): beam-former and GaGNet "
-                                      "post-filter on " + ("PyTorch-ROCm operators (comparison line)" if a.train_operator_path else
-                                                           "their HIP training programs"),
-                              "dtype": net.precision,
-                              "value": frames / elapsed, "unit": "frames/s (trained)", "n_gpus": world, "steps": a.steps,
-                              "ms_per_step": 1e3 * elapsed / a.steps, "final_loss": float(loss.detach()),
-                              "params": eabnet_amd.numParams(two)}))
-        if is_dist:
-            dist.barrier()
-            torch.distributed.destroy_process_group()
-        return
-    if a.train_operator_path:
-        if rank == 0:
-            print(json.dumps({"mode": "training step on PyTorch-ROCm operators (autograd_path.py): comparison line", "value": frames / elapsed,
-                              "unit": "frames/s (trained)", "n_gpus": world, "steps": a.steps, "ms_per_step": 1e3 * elapsed / a.steps,
-                              "final_loss": float(loss.detach())}))
-        if is_dist:
-            dist.barrier()
-            torch.distributed.destroy_process_group()
-        return
-    bound = next(iter(net._train_bound.values()))
+    if not operator_path:
+        assert net.training_backend == "hip", "the HIP training programs did not engage (see the RuntimeWarning)"
+    frames = world * B * T * steps
+    if two_stage:
+        out = {"mode": "training step of the two-stage model (train_distributed.py:181,225): beam-former and GaGNet "
+                       "post-filter on " + ("PyTorch-ROCm operators (comparison line)" if operator_path else
+                                            "their HIP training programs"),
+               "dtype": net.precision,
+               "value": frames / elapsed, "unit": "frames/s (trained)", "n_gpus": world, "steps": steps,
+               "ms_per_step": 1e3 * elapsed / steps, "final_loss": float(loss.detach()),
+               "params": eabnet_amd.numParams(two)}
+        if not operator_path:
+            fl = sum(next(iter(m_._train_bound.values())).prog.flops_fwd + next(iter(m_._train_bound.values())).prog.flops_bwd
+                     for m_ in (two.eabnet, two.postnet))
+            out["whole_step_tflops"] = world * fl / (elapsed / steps) / 1e12
+        if checked:
+            out["check"] = checked
+        return out
+    if operator_path:
+        return {"mode": "training step on PyTorch-ROCm operators (autograd_path.py): comparison line", "value": frames / elapsed,
+                "unit": "frames/s (trained)", "n_gpus": world, "steps": steps, "ms_per_step": 1e3 * elapsed / steps,
+                "final_loss": float(loss.detach())}
+    bound = next(reversed(net._train_bound.values()))
     prog = bound.prog
     out = {
         "metric": "enhanced frames/sec (16 kHz, 8-mic) at 1/2/4/8 MI355X; RTF per utterance",
         "mode": "training step (BASELINE configs[3])",
-        "value": frames / elapsed, "unit": "frames/s (trained)", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": frames / elapsed, "unit": "frames/s (trained)", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if net.precision == "f32" else "bf16 products (forward, dgrad and wgrad contractions), fp32 accumulate / LSTM / norms / gradients / Adam",
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[3] (train_distributed.py:214-230) for the beam-former stage: per-GPU batch 6 x 6 s x "
                                "8 mics; prepare_data (noisy + target STFT), EaBNet forward, com_mag_mse_loss, backward, "
                                "clip_grad_norm_(1.0), Adam(5e-4); forward and backward on the HIP training programs",
                    "batch_per_gpu": B, "global_batch": world * B, "mics": M, "frames_per_utt": T,
-                   "parallelism": f"dp{world}: " + ("torch DDP, one 64 MB bucket" if a.train_ddp else
+                   "parallelism": f"dp{world}: " + ("torch DDP, one 64 MB bucket" if ddp else
                                                     "one flat RCCL all-reduce of the 2.84 M-float gradient per step")},
         "final_loss": float(loss.detach()),
         "gflop_per_step": {"forward": prog.flops_fwd / 1e9, "backward": prog.flops_bwd / 1e9},
+        "whole_step_tflops": world * (prog.flops_fwd + prog.flops_bwd) / (elapsed / steps) / 1e12,
         "ranks": {"world_size_seen_by_torch_distributed": torch.distributed.get_world_size() if is_dist else 1,
-                  "frames_per_s_per_rank": [B * T * a.steps / e for e in per_rank]},
+                  "frames_per_s_per_rank": [B * T * steps / e for e in per_rank]},
         "workspace_GB": prog.a_floats * 4 / 1e9,
     }
+    if checked:
+        out["check"] = checked
     try:
-        if rank == 0 and not a.no_roofline:
+        if rank == 0 and roofline:
             # per-op device time of both programs (HIP events on the launch stream, one more forward/backward state is live)
             stream = torch.cuda.current_stream()
             res = {}
@@ -274,8 +309,8 @@ def main_train(a, rank, world, dev, is_dist):
                           tr.OP_GLU_BWD: "glu_bwd", prg.OP_IN_FINALIZE: "in_finalize"}.get(o.kind, "other")
                     by[nm] = by.get(nm, 0.0) + float(ms[k])
                 res[which] = {"ms_total": float(ms.sum()), "ms_by_kernel": {k: round(v, 3) for k, v in sorted(by.items(), key=lambda kv: -kv[1])}}
-                if a.per_op:
-                    with open(a.per_op + "." + which, "w") as f:
+                if per_op:
+                    with open(per_op + "." + which, "w") as f:
                         f.write("idx kind ms gflop tflops name geometry\n")
                         for k, o in enumerate(ops):
                             gf, geo = 0.0, ""
@@ -335,6 +370,14 @@ def main_train(a, rank, world, dev, is_dist):
             out["programs"] = res
     except Exception as e:  # noqa: BLE001
         out["secondary_sections_error"] = repr(e)
+    return out
+
+
+def main_train(a, rank, world, dev, is_dist):
+    """`bench.py --train [...]`: one training configuration, printed as the job's JSON line"""
+    out = train_measure(rank, world, dev, is_dist, precision=a.precision, two_stage=a.train_two_stage,
+                        operator_path=a.train_operator_path, ddp=a.train_ddp, steps=a.steps, warmup=a.warmup,
+                        per_op=a.per_op, roofline=not a.no_roofline)
     if rank == 0:
         print(json.dumps(out))
     if is_dist:
@@ -355,6 +398,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=2,
                     help="batches in flight on separate HIP streams (eabnet_amd.Pipeline); 1 = strictly one step after the other")
     ap.add_argument("--no-next", action="store_true", help="skip the next-row measurements (post-filter, ISTFT)")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step section of the next rows (BASELINE configs[3])")
     ap.add_argument("--precision", choices=("f32", "f16x3", "bf16"), default="f32",
                     help="MFMA arithmetic of the timed path (DESIGN.md §4.4)")
     ap.add_argument("--per-op", type=str, default="", help="write the per-op timing table (instrumented replay) here")
@@ -669,7 +713,7 @@ def main():
                             net(eabnet_amd.prepare_data(hw, hw[:, :1], dev, pd_args)[0])
                         torch.cuda.synchronize()
                         rounds.append((time.perf_counter() - t0) / 10)
-                dth = min(rounds)
+                dth = sorted(rounds)[len(rounds) // 2]       # the median round (the best one flattered the path in round 2)
                 pc[kind] = {"ms_per_step": 1e3 * dth, "frames_per_s": B_PER_GPU * T / dth,
                             "ms_per_step_rounds": [round(1e3 * r, 3) for r in rounds]}
             pc["note"] = (f"host wave ({wav.numel() * 4 / 1e6:.1f} MB per step) -> prepare_data (noisy + target STFT) -> EaBNet; "
@@ -804,6 +848,37 @@ def main():
             out.setdefault("next_rows", {}).update(nxt)
             two = None
             torch.cuda.empty_cache()
+
+        if rank == 0 and world == 1 and not a.no_next and not a.no_train:
+            # BASELINE configs[3] inside the driver-timed line: the training step of the beam-former and of the two-stage model
+            # (train_distributed.py:181,214-230; batch 6 x 6 s x 8 mics, Adam, clip, loss) on the HIP training programs, exact
+            # fp32 and bf16 products.  Each configuration first passes an in-run check (loss against the PyTorch-ROCm operator
+            # path on the same parameters and batch, all gradients finite); a configuration that fails it reports no number.
+            net = None
+            torch.cuda.empty_cache()
+            trn = {"config": "per-GPU batch 6 x 6 s x 8 mics (T = 601): prepare_data (noisy + target STFT), forward, loss, backward, "
+                             "clip_grad_norm_(1.0), Adam(5e-4) inside every timed step; 5 timed steps after 2 warm-up steps; "
+                             "`bench.py --train [--train-two-stage] [--precision bf16] [--gpus N]` runs one configuration alone"}
+            for two_ in (False, True):
+                for prec_ in ("f32", "bf16"):
+                    key = ("two_stage" if two_ else "beam_former") + "_" + prec_
+                    t_cfg = time.perf_counter()
+                    try:
+                        r = train_measure(0, 1, dev, False, precision=prec_, two_stage=two_, steps=5, warmup=2, roofline=not two_,
+                                          check=True)
+                        if r.get("failed"):
+                            trn[key] = {"dropped": "in-run check failed; no throughput reported", "check": r["check"]}
+                        else:
+                            keep = ("ms_per_step", "value", "unit", "whole_step_tflops", "final_loss", "check", "roofline", "dgrad",
+                                    "gflop_per_step", "workspace_GB", "params")
+                            trn[key] = {k: r[k] for k in keep if k in r}
+                            if "programs" in r:
+                                trn[key]["program_ms_by_kernel"] = {w: r["programs"][w]["ms_by_kernel"] for w in r["programs"]}
+                    except Exception as e:  # noqa: BLE001
+                        trn[key] = {"error": repr(e)}
+                    trn[key]["bench_seconds"] = round(time.perf_counter() - t_cfg, 1)
+                    torch.cuda.empty_cache()
+            out.setdefault("next_rows", {})["training"] = trn
 
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(state, MICS, L)

@@ -380,7 +380,9 @@ def pack_frag(wp: np.ndarray, dual: bool = False) -> np.ndarray:
     N, K = wp.shape
     assert N % 16 == 0 and K % 16 == 0
     n, k = _frag_index(N, K)
-    return np.ascontiguousarray(wp[frag_row_order(N, dual)][n, k], dtype=np.float32).reshape(-1)
+    # (integer input = an index image of the training programs' parameter gather: same permutation, dtype kept)
+    return np.ascontiguousarray(wp[frag_row_order(N, dual)][n, k],
+                                dtype=wp.dtype if np.issubdtype(wp.dtype, np.integer) else np.float32).reshape(-1)
 
 
 def unpack_frag(flat: np.ndarray, N: int, K: int, dual: bool = False) -> np.ndarray:
@@ -1049,31 +1051,38 @@ class GagLowering(Lowering):
         PReLU/norm/out_conv + residual, three launches, InstanceNorm partials reduced by the consumer."""
         cfg, T, B = self.cfg, self.T, self.B
         D, cd, kd = cfg.d_feat, cfg.cd1, cfg.kd1
-        bm, bn = 64, self.bn
-        tiles = conv_tiles(T, 1, bm)
-        assert bn or tiles <= 64
+        bn = self.bn
+        Kd = kd * ((cd + 15) // 16) * 16
+        use_st = self.st and D == 256 and cd == 64 and Kd <= 256 and conv_tiles(T, 1, 32) <= 64
+        if use_st:     # small-tile kernel (see Lowering.tcm)
+            mt = None if bn else 64
+            bm, bm_d, bm_out = self.pick_st_bm(1, cd, D, max_tiles=mt), self.pick_st_bm(1, cd, Kd, max_tiles=mt), self.pick_st_bm(1, D, cd)
+        else:
+            bm = bm_d = bm_out = 64
+        tiles, tiles_d = conv_tiles(T, 1, bm), conv_tiles(T, 1, bm_d)
+        assert bn or max(tiles, tiles_d) <= 64
         nD, nO = f"{pre}.d_conv.1", f"{pre}.out_conv.1"
         slD, slO = self.vec(f"{pre}.d_conv.0.weight"), self.vec(f"{pre}.out_conv.0.weight")
         wref = self.W.add(f"{pre}.in_conv.weight#packed", pack_taps(self.P[f"{pre}.in_conv.weight"], [0]))
         y = self.alloc_act(1, cd)
         st = None if bn else self.alloc(B * tiles * cd * 4)
         self.emit_conv(f"{pre}.in_conv", [x], wref, None, cd, D, 1, 1, 1, 0, 1, [0], [0], EPI_LINEAR, y,
-                       st, 0 if bn else 1, (None, None) if bn else (slD, None), 0 if bn else tiles, 0, bm)
+                       st, 0 if bn else 1, (None, None) if bn else (slD, None), 0 if bn else tiles, 0, bm, st=use_st)
         span = (kd - 1) * dilation
         lead = span if cfg.is_causal else span // 2
         dts = [j * dilation - lead for j in range(kd)]
         wd = self.W.add(f"{pre}.d_conv.3.weight#packed", pack_taps(self.P[f"{pre}.d_conv.3.weight"], range(kd)))
         z = self.alloc_act(1, cd)
-        st2 = None if bn else self.alloc(B * tiles * cd * 4)
+        st2 = None if bn else self.alloc(B * tiles_d * cd * 4)
         self.emit_conv(f"{pre}.d_conv", [Act(y, 1, cd, self.bn_xf(nD) if bn else None, slD, XF_PRELU_NORM)], wd, None, cd,
-                       kd * ((cd + 15) // 16) * 16, 1, 1, 1, 0, 1, dts, [0] * kd, EPI_LINEAR, z, st2, 0 if bn else 1,
-                       (None, None) if bn else (slO, None), 0 if bn else tiles, 0, bm,
-                       fin=None if bn else dict(stats=st, tiles=tiles, nsets=1, count=T, norms=[nD]))
+                       Kd, 1, 1, 1, 0, 1, dts, [0] * kd, EPI_LINEAR, z, st2, 0 if bn else 1,
+                       (None, None) if bn else (slO, None), 0 if bn else tiles_d, 0, bm_d,
+                       fin=None if bn else dict(stats=st, tiles=tiles, nsets=1, count=T, norms=[nD]), st=use_st)
         wo = self.W.add(f"{pre}.out_conv.2.weight#packed", pack_taps(self.P[f"{pre}.out_conv.2.weight"], [0]))
         xn = self.alloc_act(1, D)
         self.emit_conv(f"{pre}.out_conv", [Act(z, 1, cd, self.bn_xf(nO) if bn else None, slO, XF_PRELU_NORM)], wo, None,
-                       D, cd, 1, 1, 1, 0, 1, [0], [0], EPI_ADD, xn, bm=bm, aux=x.ref,
-                       fin=None if bn else dict(stats=st2, tiles=tiles, nsets=1, count=T, norms=[nO]))
+                       D, cd, 1, 1, 1, 0, 1, [0], [0], EPI_ADD, xn, bm=bm_out, aux=x.ref,
+                       fin=None if bn else dict(stats=st2, tiles=tiles_d, nsets=1, count=T, norms=[nO]), st=use_st)
         return Act(xn, 1, D)
 
     def chain(self, pre: str, x: Act) -> Act:

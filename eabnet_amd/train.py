@@ -170,6 +170,8 @@ class TrainLowering:
             raise ValueError("training precision is 'f32' or 'bf16' (bf16: forward, dgrad and wgrad contractions on the bf16 "
                              "matrix cores with fp32 accumulation; LSTM, norms, gradients and the optimiser state stay fp32)")
         self.prec = prg.PREC_CODE[precision]
+        # small-tile kernel (csrc/conv_st.hip) for the 1-D convolutions of the S-TCMs and their dgrads (exact fp32 only)
+        self.st = os.environ.get("EAB_ST", "1") != "0"
         if not self.supports(cfg):
             raise NotImplementedError("the HIP training path covers the default topology with InstanceNorm")
         cfg.check_supported()
@@ -293,7 +295,8 @@ class TrainLowering:
 
     def conv_op(self, name, srcs: Sequence[TVar], w: Ref, bias: Optional[Ref], N: int, Kpad: int, Fin: int, Fout: int, No: int,
                 ostride: int, ophase: int, istride: int, dt, ioff, epi: int, dst: Ref, Cout: int, stats=None, stat_tiles=0,
-                stat_tile0=0, bm=None, aux=None, dst_acc=None, glu_dump=None) -> prg.ConvOp:
+                stat_tile0=0, bm=None, aux=None, dst_acc=None, glu_dump=None, st: bool = False) -> prg.ConvOp:
+        """st: `w` is in MFMA-fragment order and the launch goes to the small-tile kernel (csrc/conv_st.hip, KORDER_FRAG)"""
         s0, s1 = srcs[0], (srcs[1] if len(srcs) > 1 else None)
         bm = bm or self.pick_bm(No)
         op = prg.ConvOp(src0=s0.ref, src1=s1.ref if s1 else None, xf0=None, xf1=None, slope0=None, slope1=None,
@@ -302,6 +305,8 @@ class TrainLowering:
                         epi=epi, aux=aux, dst=dst, dst_acc=dst_acc, Cout=Cout, stats=stats, nsets=1 if stats else 0,
                         stat_slope0=None, stat_slope1=None, stat_tiles=stat_tiles, stat_tile0=stat_tile0, bm=bm, name=name)
         op.glu_dump = glu_dump
+        if st:
+            op.korder = prg.KORDER_FRAG
         if self.prec != prg.PREC_F32 and s0.ref.arena != "in" and s0.C % 4 == 0 and (s1 is None or s1.C % 4 == 0):
             op.precision = self.prec                  # the convolution on the raw network input stays exact
         self.emit.append(op)
@@ -331,7 +336,7 @@ class TrainLowering:
     def colsum(self, name, x: Ref, rows: int, N: int, imgs: Sequence[np.ndarray]) -> None:
         self.bwd.append(GenOp(OP_COLSUM, [x, self.gadd(imgs)], list(_split64(rows)) + [N], name=name))
 
-    def dgrad(self, name: str, var: TVar, dz: Ref, Kd: int, Fz: int, launches: Sequence[tuple]) -> None:
+    def dgrad(self, name: str, var: TVar, dz: Ref, Kd: int, Fz: int, launches: Sequence[tuple], st_bm: int = 0) -> None:
         """grad(var) (+)= conv(dz; w) with the forward kernel on the gradient tensor dz [B][T][Fz][Kd]; `launches` =
         (w, No, ostride, ophase, istride, dt, ioff) per launch -- the launches of one call write disjoint output
         columns and share the accumulate operand."""
@@ -342,7 +347,8 @@ class TrainLowering:
         self.emit = self.bwd
         for k, (w, No, ostride, ophase, istride, dt, ioff) in enumerate(launches):
             self.conv_op(f"{name}.{k}", [src], w, None, var.C, len(dt) * ((Kd + 15) // 16) * 16, Fz, var.F, No, ostride, ophase,
-                         istride, dt, ioff, prg.EPI_ADD if aux is not None else prg.EPI_LINEAR, dst, var.C, aux=aux)
+                         istride, dt, ioff, prg.EPI_ADD if aux is not None else prg.EPI_LINEAR, dst, var.C, aux=aux,
+                         st=st_bm > 0, bm=st_bm or None)
         self.emit = self.fwd
 
     # ---- norm + activation ---------------------------------------------------------------------------------
@@ -512,17 +518,27 @@ class TrainLowering:
         N, Cc, K = wimg_nck.shape
         wimg = self.pack_taps_idx(wimg_nck, range(K))
         out = self.act(1, N)
-        wref = self.wadd(wname + ".w", wimg)
+
+        def st_geometry(n, c, kp, epi_=prg.EPI_LINEAR):
+            """rows per tile of a small-tile launch (csrc/conv_st.hip; exact fp32 only), 0 = conv_gemm_kernel"""
+            if not (self.st and self.prec == prg.PREC_F32 and n in (64, 128, 256) and c in (64, 128, 256)
+                    and kp <= {64: 256, 128: 320, 256: 64}[n] and epi_ in (prg.EPI_LINEAR, prg.EPI_RELU, prg.EPI_ADD)):
+                return 0
+            return 32 if self.B * ((self.T + 31) // 32) >= 2 * prg.CUS else 16
+        st_bm = st_geometry(N, Cc, wimg.shape[1], epi)
+        wref = self.wadd(wname + (".wf" if st_bm else ".w"), prg.pack_frag(wimg) if st_bm else wimg)
         bref = self.wadd(wname + ".b", bimg) if bimg is not None else None
-        self.conv_op(name, [src], wref, bref, N, wimg.shape[1], 1, 1, 1, 1, 0, 1, list(dts), [0] * K, epi, out.ref, N, bm=64,
-                     aux=aux.ref if aux is not None else None, dst_acc=dst_acc)
+        self.conv_op(name, [src], wref, bref, N, wimg.shape[1], 1, 1, 1, 1, 0, 1, list(dts), [0] * K, epi, out.ref, N,
+                     bm=st_bm or 64, aux=aux.ref if aux is not None else None, dst_acc=dst_acc, st=st_bm > 0)
         rows = self.B * self.T
 
         def back(dz: Ref):
             self.wgrad_op(name + ".wgrad", dz, N, 1, [src], 1, 1, 0, 1, list(dts), [0] * K, wimg,
                           dbias=self.gadd([bimg]) if bimg is not None else None)
             img = self.pack_taps_idx(np.ascontiguousarray(wimg_nck.transpose(1, 0, 2)), range(K))      # (Cc, N, K)
-            self.dgrad(name + ".dgrad", src, dz, N, 1, [(self.wadd(wname + ".wd", img), 1, 1, 0, 1, [-d for d in dts], [0] * K)])
+            d_bm = st_geometry(Cc, N, img.shape[1])
+            self.dgrad(name + ".dgrad", src, dz, N, 1, [(self.wadd(wname + (".wdf" if d_bm else ".wd"), prg.pack_frag(img) if d_bm else img),
+                                                         1, 1, 0, 1, [-d for d in dts], [0] * K)], st_bm=d_bm)
         return out, back
 
     def in1d(self, name: str, raw: TVar, norm: str, act: str) -> TVar:
