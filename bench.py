@@ -209,6 +209,7 @@ def train_measure(rank, world, dev, is_dist, *, precision="f32", two_stage=False
         finite = all(bool(torch.isfinite(p.grad).all()) for p in trained.parameters() if p.grad is not None)
         n_grads = sum(1 for p in trained.parameters() if p.grad is not None)
         mods = [two.eabnet, two.postnet] if two is not None else [net]
+        hip_engaged = all(m_.training_backend == "hip" for m_ in mods)
         for m_ in mods:
             m_.use_hip_training = False
         l_op = loss_of(noisy, target)                      # operator path (needs grad mode to be taken; no backward)
@@ -217,8 +218,8 @@ def train_measure(rank, world, dev, is_dist, *, precision="f32", two_stage=False
         rel = abs(float(l_hip.detach()) - float(l_op.detach())) / max(abs(float(l_op.detach())), 1e-12)
         tol = 1e-4 if precision == "f32" else 5e-2
         checked = {"loss_hip": float(l_hip.detach()), "loss_operator_path": float(l_op.detach()), "rel_diff": rel, "tolerance": tol,
-                   "gradients_finite": finite, "gradient_tensors": n_grads, "backends": [m_.training_backend for m_ in mods],
-                   "ok": bool(rel <= tol and finite)}
+                   "gradients_finite": finite, "gradient_tensors": n_grads, "hip_programs_engaged": hip_engaged,
+                   "ok": bool(rel <= tol and finite and hip_engaged)}
         del l_op, l_hip
         opt.zero_grad(set_to_none=True)
         torch.cuda.empty_cache()
@@ -227,6 +228,8 @@ def train_measure(rank, world, dev, is_dist, *, precision="f32", two_stage=False
 
     for _ in range(max(1, warmup)):
         loss = step()
+    import gc
+    gc.collect()
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -855,6 +858,9 @@ def main():
             # fp32 and bf16 products.  Each configuration first passes an in-run check (loss against the PyTorch-ROCm operator
             # path on the same parameters and batch, all gradients finite); a configuration that fails it reports no number.
             net = None
+            import gc
+            gc.collect()            # nets of the earlier sections: their bound programs drain the device when they are finalised
+            torch.cuda.synchronize()
             torch.cuda.empty_cache()
             trn = {"config": "per-GPU batch 6 x 6 s x 8 mics (T = 601): prepare_data (noisy + target STFT), forward, loss, backward, "
                              "clip_grad_norm_(1.0), Adam(5e-4) inside every timed step; 5 timed steps after 2 warm-up steps; "

@@ -376,8 +376,9 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_st_kernel(const eab_conv_d
 
     // ---- main loop ----------------------------------------------------------------------------------------------------------
     // A fragments of UA K steps are read together (the LDS latency is paid once per UA steps, not once per MFMA pair);
-    // a wave with a single 16x16 block runs two accumulation chains (e = 0 / 1), summed at the end in a fixed order
-    constexpr int NACC = (RB * NCB == 1) ? 2 : 1;
+    // every 16x16 block runs two accumulation chains (e = 0 / 1: the 16x16x4 MFMA's dependent latency is 40 cycles against
+    // an issue interval of 32), summed at the end in a fixed order
+    constexpr int NACC = 2;       // (the same chain structure for every tile shape: a row's bits must not depend on the tile it is in)
     constexpr int UA0 = RB * NA >= 8 ? 1 : RB * NA == 4 ? 2 : RB * NA == 2 ? 4 : 8;
     constexpr int UA = UA0 < U ? UA0 : U;
     f32x4 acc[NACC][RB][NCB];

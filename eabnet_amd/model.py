@@ -954,7 +954,10 @@ class _HostStager:
     enqueued while batch k still computes and nothing on the path allocates or synchronises the device; a slot is
     reused only after the kernels that read its device buffer have been enqueued AND its previous copy completed."""
 
-    always_stage = False
+    # True: every host tensor is copied into the ring's own pinned slot first.  The direct path (the copy kernel reads the
+    # caller's pinned buffer) measured SLOWER on MI355X (20 ms vs 10-12 ms per 32.8 MB batch, bench.py next_rows.pcie_inclusive)
+    # and has to block until the read has finished, because nothing else protects a caller's pinned buffer from being refilled.
+    always_stage = True
 
     def __init__(self, device: torch.device, depth: int = 3):
         self.device, self.depth, self.k = device, depth, 0

@@ -700,6 +700,15 @@ class Lowering:
                                    xf1=xfs[1] if nsets == 2 else None, name=name))
         return xfs
 
+    def st_small(self, No: int) -> bool:
+        """Is a launch with `No` output columns per frame latency-bound?  Yes when 64-row tiles would give the chip fewer
+        than two workgroups per CU (one utterance, a streaming chunk, the deepest U-Net levels of a batch) or when the
+        layer has at most `st_maxno` columns; those go to the small-tile kernel."""
+        # (T, not the streaming chunk: a streamed program must pick the kernel its offline twin of the same (B, T) picks --
+        # the two kernels sum in different orders, and streamed frames are promised bit-identical to the offline pass)
+        rows = self.T * No
+        return No <= self.st_maxno or self.B * ((rows + 63) // 64) < 2 * CUS
+
     def st_ok(self, srcs: Sequence[Act], N: int, glu: bool) -> bool:
         """the small-tile kernel's domain: exact fp32, plain 64/128/256-column launches, source channels 4 * 2^k"""
         return (self.st and not glu and not self.cln and N in (64, 128, 256) and all(a.C in (64, 128, 256) for a in srcs)
@@ -725,7 +734,7 @@ class Lowering:
         bref = self.W.add(f"{wkey}.bias#packed", self.P[f"{wkey}.bias"][order])
         Cout = N // 2 if glu else N
         dst = self.alloc_act(Fout, Cout)
-        st = self.st_ok(srcs, N, glu) and Fout <= self.st_maxno
+        st = self.st_ok(srcs, N, glu) and wp.shape[1] <= 256 and self.st_small(Fout)
         bm = self.pick_st_bm(Fout, N, wp.shape[1]) if st else self.pick_bm(Fout)
         tiles = conv_tiles(self.T, Fout, bm)
         cln = self.cln and norm is not None
@@ -767,7 +776,7 @@ class Lowering:
         dst = self.alloc_act(Fout, Cout)
         No = [(Fout + 1) // 2, Fout // 2]
         upt = (Cin + 15) // 16
-        st = self.st_ok(srcs, N, glu) and No[0] <= self.st_maxno
+        st = self.st_ok(srcs, N, glu) and len(range(0, kf, 2)) * kt * upt * 16 <= 256 and self.st_small(No[0])
         bm = self.pick_st_bm(No[0] + No[1], N, len(range(0, kf, 2)) * kt * upt * 16) if st else self.pick_bm(No[0])
         tiles = [conv_tiles(self.T, n, bm) for n in No]
         cln = self.cln

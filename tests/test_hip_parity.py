@@ -1549,3 +1549,29 @@ def test_prepare_data_with_a_window_shorter_than_the_fft(dev):
     assert_compressed_close(np.moveaxis(tgt.cpu().numpy(), 1, -1), np.moveaxis(want_t.numpy(), 1, -1), TOL_HIP, "target")
     with pytest.raises(RuntimeError):
         eabnet_amd.prepare_data(x, x[:, :1], dev, type("A", (), dict(mics=4, sr=16000, wav_len=0.2, win_size=0.03, win_shift=0.010, fft_num=320)))
+
+
+@pytest.mark.parametrize("stage", [True, False])
+def test_prepare_data_is_done_with_a_pinned_source_when_it_returns(dev, stage):
+    """A caller may refill its (pinned) batch buffer as soon as prepare_data returns -- the reference's x.to(device) is
+    synchronous for exactly this case (train_distributed.py:76-77).  Both host paths: staged through the ring's own pinned
+    slot (default) and the direct read of the caller's pinned buffer, which must not return before the read has finished."""
+    import eabnet_amd
+    from eabnet_amd import model as mdl
+    args = type("A", (), dict(mics=8, sr=16000, wav_len=4.0, win_size=0.020, win_shift=0.010, fft_num=320))
+    src = torch.from_numpy(paramgen.make_wave(4, 8, 64000, 77))
+    want_n, want_t = eabnet_amd.prepare_data(src.clone(), src[:, :1].clone(), dev, args)
+    want_n, want_t = want_n.clone(), want_t.clone()
+    saved = mdl._HostStager.always_stage
+    mdl._HostStager.always_stage = stage
+    try:
+        for _ in range(4):                                   # several slots of the ring
+            x = src.clone().pin_memory()
+            t = src[:, :1].clone().contiguous().pin_memory()
+            noisy, tgt = eabnet_amd.prepare_data(x, t, dev, args)
+            x.fill_(1e6)                                     # the caller recycles its buffers immediately
+            t.fill_(-1e6)
+            torch.cuda.synchronize()
+            assert torch.equal(noisy, want_n) and torch.equal(tgt, want_t)
+    finally:
+        mdl._HostStager.always_stage = saved
