@@ -2,6 +2,8 @@
 // and K12b+K13 fused: second Linear of w_dnn + filter-and-sum (EaBNet.py:596,613-117).
 #include "common.h"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // one thread per TF bin; W and X rows are M*2 contiguous floats (64 B at M=8).
 __global__ __launch_bounds__(256) void filter_sum_kernel(const float* __restrict__ w, const float* __restrict__ x,
                                                          float* __restrict__ y, int T, int F, int M, long long bins) {
@@ -32,9 +34,10 @@ extern "C" int eab_filter_sum_f32(const float* w, const float* x, float* y, int 
 
 // ---------------------------------------------------------------------------
 // bfw_filter_sum: 64 TF bins per workgroup.  The 64x64 activation tile and the
-// (2M)x64 weight matrix are staged in LDS; 4 lanes share a bin, lane p of the
-// quad computes mics p, p+4, ... (both re and im weights), multiplies with the
-// bin's X and the quad is reduced with two xor-shuffles.
+// (2M)x64 weight matrix are staged in LDS; the per-bin beam-forming weights are one
+// 64 x 2M x 64 product on v_mfma_f32_16x16x4_f32 (a wave per 16 bins), written back
+// into the tile; then 4 lanes share a bin, lane p of the quad multiplies mics p, p+4, ...
+// with the bin's X and the quad is reduced with two xor-shuffles.
 // MLP = true: the tile staged from HBM is the LSTM output h and the first
 // Linear + ReLU of LSTM_BF.w_dnn (EaBNet.py:594-595,612) runs here too --
 // y1 = relu(h W1^T + b1) as one 64x64x64 fp32-MFMA product per workgroup
@@ -79,16 +82,29 @@ __global__ __launch_bounds__(256) void bfw_filter_sum_kernel(
     }
     // the weights stay in LDS while the workgroup walks over its 64-bin tiles (grid-stride)
     const long long ntiles = (bins + BFW_ROWS - 1) / BFW_ROWS;
+    // the activation tile of the NEXT step of the grid-stride walk is fetched into registers while this one is multiplied
+    // (4 float4 per thread): the HBM round trip used to sit in front of every tile's MFMAs
+    constexpr int TPT = BFW_ROWS * (BFW_K / 4) / 256;
+    f32x4 pre[TPT];
+    auto fetch_tile = [&](long long tl) {
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) {
+            const int e = tid + k * 256, r = e / (BFW_K / 4), c4 = e % (BFW_K / 4);
+            const long long bn = tl < ntiles ? to_bin(tl * BFW_ROWS + r) : -1;
+            pre[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (bn >= 0) pre[k] = *reinterpret_cast<const f32x4*>(&y1[(size_t)bn * BFW_K + c4 * 4]);
+        }
+    };
+    fetch_tile(blockIdx.x);
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long long row0 = tile * BFW_ROWS;
     __syncthreads();                                 // previous tile fully consumed (and weights staged)
-    for (int e = tid; e < BFW_ROWS * (BFW_K / 4); e += 256) {
-        int r = e / (BFW_K / 4), c4 = e % (BFW_K / 4);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const long long bn = to_bin(row0 + r);
-        if (bn >= 0) v = *reinterpret_cast<const f32x4*>(&y1[(size_t)bn * BFW_K + c4 * 4]);
-        *reinterpret_cast<f32x4*>(&ytile[r * (BFW_K + 4) + c4 * 4]) = v;
+#pragma unroll
+    for (int k = 0; k < TPT; ++k) {
+        const int e = tid + k * 256, r = e / (BFW_K / 4), c4 = e % (BFW_K / 4);
+        *reinterpret_cast<f32x4*>(&ytile[r * (BFW_K + 4) + c4 * 4]) = pre[k];
     }
+    fetch_tile(tile + gridDim.x);
     if (MLP) {
         __syncthreads();
         // y1[row][n] = relu(b1[n] + sum_k h[row][k] W1[n][k]): wave (wm, wn) owns the 32x32 block
@@ -114,23 +130,54 @@ __global__ __launch_bounds__(256) void bfw_filter_sum_kernel(
             ytile[(wm * 32 + 8 * (i >> 2) + 4 * lh + (i & 3)) * (BFW_K + 4) + wn * 32 + li] = fmaxf(acc[i] + bias, 0.0f);
     }
     __syncthreads();
+    {
+        // Second Linear of w_dnn (EaBNet.py:596): bfw[row][n] = b2[n] + sum_k y1[row][k] W2[n][k], n < 2M, on
+        // v_mfma_f32_16x16x4_f32 (it ran on the vector unit before: 256 FMAs + ~100 LDS reads per thread and tile made this
+        // HBM-side kernel VALU-bound).  Wave w owns rows 16w .. 16w+15 of the tile -- the rows its own lanes reduce below, so
+        // the result goes back into the wave's rows of `ytile` without a workgroup barrier.  Lane (i = l & 15, kq = l >> 4)
+        // reads floats [8 m + 2 kq, +2) of its row: conflict-free ds_read_b64 (row stride 68 floats = 2 * 17 eight-byte slots).
+        const int lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+        const int NB = (2 * M + 15) >> 4;             // 16-column blocks of the 2M outputs (<= 4)
+        const float* ar = &ytile[(wave * 16 + li) * (BFW_K + 4) + 2 * kq];
+        f32x2 af[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) af[m] = *reinterpret_cast<const f32x2*>(ar + 8 * m);
+        f32x4 acc2[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            acc2[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (cb < NB) {                            // workgroup-uniform
+                const int n = cb * 16 + li;
+                const float* br = &wl[(n < 2 * M ? n : 2 * M - 1) * (BFW_K + 4) + 2 * kq];   // columns past 2M: a copy, never stored
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const f32x2 bq = *reinterpret_cast<const f32x2*>(br + 8 * m);
+                    acc2[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][0], bq[0], acc2[cb], 0, 0, 0);
+                    acc2[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][1], bq[1], acc2[cb], 0, 0, 0);
+                }
+            }
+        }
+        // C layout: column n = cb*16 + li, rows 4 kq + r.  (All of this wave's reads of its ytile rows are complete: the
+        // MFMAs that consumed them have produced acc2.)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int n = cb * 16 + li;
+            if (cb < NB && n < 2 * M) {
+                const float bias2 = b2[n];
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) ytile[(wave * 16 + 4 * kq + r4) * (BFW_K + 4) + n] = acc2[cb][r4] + bias2;
+            }
+        }
+    }
+    // per bin: 4 lanes share a row, lane p takes microphones p, p+4, ..; (wr, wi) come from the wave's own rows of ytile
     const int r = tid >> 2, p = tid & 3;
     const long long bin = to_bin(row0 + r);
     const bool valid = bin >= 0;
     const float* yr_ = &ytile[r * (BFW_K + 4)];
     float accr = 0.0f, acci = 0.0f;
     for (int m = p; m < M; m += 4) {
-        const float* wr_ = &wl[(2 * m) * (BFW_K + 4)];
-        const float* wi_ = &wl[(2 * m + 1) * (BFW_K + 4)];
-        float wr = b2[2 * m], wi = b2[2 * m + 1];
-#pragma unroll 4
-        for (int k = 0; k < BFW_K; k += 4) {
-            f32x4 a = *reinterpret_cast<const f32x4*>(&yr_[k]);
-            f32x4 u = *reinterpret_cast<const f32x4*>(&wr_[k]);
-            f32x4 v = *reinterpret_cast<const f32x4*>(&wi_[k]);
-            wr += a[0] * u[0] + a[1] * u[1] + a[2] * u[2] + a[3] * u[3];
-            wi += a[0] * v[0] + a[1] * v[1] + a[2] * v[2] + a[3] * v[3];
-        }
+        const float2 wv = *reinterpret_cast<const float2*>(&yr_[2 * m]);
+        const float wr = wv.x, wi = wv.y;
         if (valid) {
             float2 xv = reinterpret_cast<const float2*>(x)[bin * M + m];
             accr += wr * xv.x - wi * xv.y;

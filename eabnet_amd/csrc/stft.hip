@@ -105,7 +105,15 @@ __global__ __launch_bounds__(STFT_THREADS) void stft_fft_kernel(
     float2* tw = reinterpret_cast<float2*>(smem);                         // [n_fft]  exp(-2 pi i j / n_fft)
     float2* buf0 = tw + n_fft;                                            // [FFT_SIGS][NH]
     float2* buf1 = buf0 + FFT_SIGS * NH;
-    const int b = blockIdx.x / T, t = blockIdx.x % T;
+    // Workgroups are dealt to the 8 XCDs round-robin and every XCD has its own L2: neighbouring frames share half of their
+    // samples, so let each XCD walk one contiguous eighth of the (b, t) sequence -- the overlap is then fetched from HBM once
+    // (measured before: 2 x the wave bytes, profiles/r02_final).
+    unsigned vblk = blockIdx.x;
+    if (gridDim.x >= 64) {
+        const unsigned G = gridDim.x, G8 = G >> 3, rem = G & 7, xcd = vblk & 7, idx = vblk >> 3;
+        vblk = xcd * G8 + (xcd < rem ? xcd : rem) + idx;
+    }
+    const int b = (int)(vblk / (unsigned)T), t = (int)(vblk - (unsigned)b * T);
     const int tid = threadIdx.x;
     for (int k = tid; k < n_fft; k += STFT_THREADS) {       // table is (cos, sin)(+theta); the passes use exp(-i theta)
         const float2 cs = reinterpret_cast<const float2*>(twiddle)[k];

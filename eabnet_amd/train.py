@@ -48,7 +48,7 @@ TRAIN_BOUND_CACHE = 3   # bound training programs kept per module (LRU over (B, 
 
 
 def supported(cfg: NetConfig) -> bool:
-    return (cfg.is_u2 and cfg.bf_type == "lstm" and cfg.topo_type == "mimo" and cfg.intra_connect == "cat"
+    return (cfg.is_u2 and cfg.bf_type == "lstm" and cfg.topo_type == "mimo" and cfg.intra_connect in ("cat", "add")
             and cfg.norm_type == "IN" and 2 * cfg.M <= MLP_LD)
 
 
@@ -61,7 +61,7 @@ def unsupported_reason(cfg: NetConfig) -> str:
         why.append(f"bf_type={cfg.bf_type!r}")
     if cfg.topo_type != "mimo":
         why.append(f"topo_type={cfg.topo_type!r}")
-    if cfg.intra_connect != "cat":
+    if cfg.intra_connect not in ("cat", "add"):
         why.append(f"intra_connect={cfg.intra_connect!r}")
     if cfg.norm_type != "IN":
         why.append(f"norm_type={cfg.norm_type!r}")
@@ -506,9 +506,29 @@ class TrainLowering:
             downs.append(y)
         for j in range(scale):
             q = f"{pre}.deco.{j}.deconv"
-            ins = [y] if j == 0 else [y, downs[-(j + 1)]]
+            if j == 0:
+                ins = [y]
+            elif self.cfg.intra_connect == "add":
+                ins = [self.add_vars(f"{q}.skip_add", y, downs[-(j + 1)])]       # Skip_connect 'add' (EaBNet.py:499-500)
+            else:
+                ins = [y, downs[-(j + 1)]]
             y = self.conv2d_transposed(q, ins, f"{q}.0", False, f"{q}.1", f"{q}.2", add=g if j == scale - 1 else None)
         return y
+
+    def add_vars(self, name: str, a: TVar, b: TVar) -> TVar:
+        """s = a + b, materialised (the training programs materialise every operand of a backward op anyway); the gradient
+        of s flows to both summands unchanged"""
+        assert a.F == b.F and a.C == b.C
+        out = self.act(a.F, a.C)
+        n = self.B * self.T * a.F * a.C
+        self.fwd.append(GenOp(OP_ADD, [a.ref, b.ref, out.ref], list(_split64(n)), name=name))
+
+        def back():
+            d = self.grad_of(out)
+            self.contribute(a, d)
+            self.contribute(b, d)
+        self.tape.append(back)
+        return out
 
     # ---- 1-D units (S-TCM, Linear) -------------------------------------------------------------------------
     def conv1d(self, name: str, src: TVar, wimg_nck: np.ndarray, dts: Sequence[int], bimg: Optional[np.ndarray], epi: int,

@@ -1187,6 +1187,16 @@ def _grad_errors(got: dict, ref: dict):
                                              (8, 1, 70, (6, 3), False), (9, 2, 24, (2, 2), True),       # M = 9: the reference's default
                                              (1, 1, 17, (1, 1), True), (16, 2, 19, (1, 2), True)])     # one microphone; config 5's 16
 def test_hip_training_gradients_vs_oracle_autograd(dev, M, B, T, pq, smooth):
+    _check_training_gradients(dev, M, B, T, pq, smooth)
+
+
+@pytest.mark.parametrize("smooth", [True, False])
+def test_hip_training_gradients_add_skips_vs_oracle_autograd(dev, smooth):
+    """the same for intra_connect="add" (Skip_connect, EaBNet.py:499-500): the HIP training programs materialise the sum"""
+    _check_training_gradients(dev, 4, 2, 30, (2, 2), smooth, intra_connect="add")
+
+
+def _check_training_gradients(dev, M, B, T, pq, smooth, **extra):
     """net(x) under autograd runs the two HIP training programs (eabnet_amd/train.py): the forward equals the
     inference program's output, and loss.backward() gives every parameter the gradient fp64 autograd through the
     oracle gives.
@@ -1202,7 +1212,7 @@ def test_hip_training_gradients_vs_oracle_autograd(dev, M, B, T, pq, smooth):
     import eabnet_amd
     from eabnet_amd.spec import NetConfig, param_specs
     p, q = pq
-    kw = dict(p=p, q=q)
+    kw = dict(p=p, q=q, **extra)
     P = torch_params(M, 910 + M, **kw)
     if smooth:
         for k, sp in param_specs(NetConfig(M=M, **kw)).items():
