@@ -48,7 +48,7 @@ TRAIN_BOUND_CACHE = 3   # bound training programs kept per module (LRU over (B, 
 
 
 def supported(cfg: NetConfig) -> bool:
-    return (cfg.is_u2 and cfg.bf_type == "lstm" and cfg.topo_type == "mimo" and cfg.intra_connect in ("cat", "add")
+    return (cfg.is_u2 and cfg.bf_type in ("lstm", "cnn") and cfg.topo_type == "mimo" and cfg.intra_connect in ("cat", "add")
             and cfg.norm_type == "IN" and 2 * cfg.M <= MLP_LD)
 
 
@@ -57,7 +57,7 @@ def unsupported_reason(cfg: NetConfig) -> str:
     why = []
     if not cfg.is_u2:
         why.append("is_u2=False")
-    if cfg.bf_type != "lstm":
+    if cfg.bf_type not in ("lstm", "cnn"):
         why.append(f"bf_type={cfg.bf_type!r}")
     if cfg.topo_type != "mimo":
         why.append(f"topo_type={cfg.topo_type!r}")
@@ -686,8 +686,32 @@ class TrainLowering:
         assert e.F == F and e.C == 64
         self.gtaps["de.4"] = e
 
-        # ---- LSTM_BF (EaBNet.py:600-614), unfused
         rows = B * T * F
+        if cfg.bf_type == "cnn":
+            # ---- pointwise head (EaBNet.py:80-81,111-113): Conv2d(64 -> 2M, 1x1); output plane m*2+ri is the column order the
+            # filter-and-sum kernels read (rows padded to one 64-column tile)
+            wc = np.full((MLP_LD, 64, 1), -1, np.int64)
+            wc[:2 * M] = self.idx("bf_map.weight").reshape(2 * M, 64)[:, :, None]
+            bcimg = np.full(MLP_LD, -1, np.int64)
+            bcimg[:2 * M] = self.idx("bf_map.bias")
+            wcimg = self.pack_taps_idx(wc, [0])
+            bw = self.act(F, MLP_LD)
+            self.conv_op("bf_map", [e], self.wadd("bf_map.w", wcimg), self.wadd("bf_map.b", bcimg), MLP_LD, 64, F, F, F, 1, 0, 1,
+                         [0], [0], prg.EPI_LINEAR, bw.ref, MLP_LD)
+            self.fwd.append(GenOp(OP_FILTER_SUM, [bw.ref, Ref("in"), Ref("out")], [B, T, F, M, MLP_LD], name="filter_sum"))
+            self.gtaps["bf_w"] = bw
+
+            def back_head_cnn():
+                dbw = self.alloc(rows * MLP_LD)
+                bw.slot.ref = dbw
+                self.bwd.append(GenOp(OP_FS_BWD, [Ref("dout"), Ref("in"), dbw], [B, T, F, M, MLP_LD], name="filter_sum.bwd"))
+                self.wgrad_op("bf_map.wgrad", dbw, MLP_LD, F, [e], F, 1, 0, 1, [0], [0], wcimg, dbias=self.gadd([bcimg]))
+                wcd = self.pack_taps_idx(np.ascontiguousarray(wc.transpose(1, 0, 2)), [0])      # (64 channels of e, 64 padded rows)
+                self.dgrad("bf_map.dgrad", e, dbw, MLP_LD, F, [(self.wadd("bf_map.wd", wcd), F, 1, 0, 1, [0], [0])])
+            self.tape.append(back_head_cnn)
+            return self._finish_build()
+
+        # ---- LSTM_BF (EaBNet.py:600-614), unfused
         x_ln, mr_ln = self.act(F, 64), self.alloc(rows * 2)
         lg, lb = self.vec("bf_map.norm.weight"), self.vec("bf_map.norm.bias")
         self.fwd.append(GenOp(OP_LN_FWD, [e.ref, lg, lb, x_ln.ref, mr_ln], list(_split64(rows)), [EPS_LN], name="bf_map.norm"))
@@ -756,7 +780,9 @@ class TrainLowering:
                                               self.gvec("bf_map.norm.bias")], list(_split64(rows)), name="bf_map.norm.bwd"))
             self.contribute(e, de)
         self.tape.append(back_head)
+        return self._finish_build()
 
+    def _finish_build(self) -> "TrainProgram":
         # ---- backward: replay the tape in reverse
         for fn in reversed(self.tape):
             fn()

@@ -1196,7 +1196,12 @@ def test_hip_training_gradients_add_skips_vs_oracle_autograd(dev, smooth):
     _check_training_gradients(dev, 4, 2, 30, (2, 2), smooth, intra_connect="add")
 
 
-def _check_training_gradients(dev, M, B, T, pq, smooth, **extra):
+def test_hip_training_gradients_cnn_head_vs_oracle_autograd(dev):
+    """bf_type="cnn" (pointwise head, EaBNet.py:80-81,111-113) on the HIP training programs"""
+    _check_training_gradients(dev, 4, 2, 30, (2, 2), True, bf_type="cnn", taps=("bf_w", "de.4", "de.0", "stcns", "en.4", "en.0"))
+
+
+def _check_training_gradients(dev, M, B, T, pq, smooth, taps=None, **extra):
     """net(x) under autograd runs the two HIP training programs (eabnet_amd/train.py): the forward equals the
     inference program's output, and loss.backward() gives every parameter the gradient fp64 autograd through the
     oracle gives.
@@ -1240,7 +1245,7 @@ def _check_training_gradients(dev, M, B, T, pq, smooth, **extra):
     # activation gradients at the oracle's taps (backward order): localises a deviation to a stage
     bound = next(iter(net._train_bound.values()))
     acts = {}
-    for name in ("bf_w", "de.4", "de.3", "de.2", "de.1", "de.0", "stcns", "en.4", "en.3", "en.2", "en.1", "en.0"):
+    for name in (taps or ("bf_w", "de.4", "de.3", "de.2", "de.1", "de.0", "stcns", "en.4", "en.3", "en.2", "en.1", "en.0")):
         r, Fv, Cv = bound.prog.grad_taps[name]
         g_ = bound.acts[r.off:r.off + B * T * Fv * Cv].view(B, T, Fv, Cv).cpu().double()
         want = ref_taps[name]
