@@ -58,6 +58,14 @@ __device__ __forceinline__ void st_merge(float& n, float& mean, float& m2, float
     n = nt;
 }
 
+typedef __bf16 st_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 st_bf16x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> packed bf16 (round to nearest even: v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned st_bf2(float x0, float x1) {
+    const st_bf16x2 v = {(__bf16)x0, (__bf16)x1};
+    return __builtin_bit_cast(unsigned, v);
+}
+
 // buffer descriptor from wave-uniform inputs, made provably uniform for the compiler (MI355X guide, T20)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t st_rsrc(const float* p, unsigned bytes) {
     const unsigned long long a = reinterpret_cast<unsigned long long>(p);
@@ -89,8 +97,10 @@ struct StTables {
     double fin[3][ST_THREADS];   // slice partials of the in-kernel InstanceNorm finalisation
 };
 
-template <int RB, int NCB, int MODE, int XF>
+template <int RB, int NCB, int MODE, int XF, bool BF>
 __global__ __launch_bounds__(ST_THREADS, 2) void conv_st_kernel(const eab_conv_desc d) {
+    // BF = EAB_PREC_BF16: tensors and weights stay fp32 in memory (the same fragment-order `w`); A is rounded to bf16 on
+    // its way into LDS, B in registers, products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation
     constexpr bool DUAL = MODE == ST_DUAL;
     constexpr int BM = 16 * RB;
     constexpr int NA = DUAL ? 2 : 1;
@@ -134,11 +144,13 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_st_kernel(const eab_conv_d
     const int Q = t_hi * No;
     const int q0 = t_lo * No + tile * BM;
     const float inv_no = 1.0f / (float)No;
-    const int LD = d.Kpad + 4;                          // (phase 0 has the larger K)
+    // row stride of the A tiles in ELEMENTS (fp32, or bf16 in the BF form): 16 bytes of padding per row
+    const int LD = BF ? d.Kpad + 8 : d.Kpad + 4;        // (phase 0 has the larger K)
     const int M2 = Kpad >> 4;
 
     float* const sa = st_lds;
-    StTables& tb = *reinterpret_cast<StTables*>(st_lds + NA * BM * LD);
+    StTables& tb = *reinterpret_cast<StTables*>(st_lds + (BF ? NA * BM * LD / 2 : NA * BM * LD));
+    unsigned short* const sh = reinterpret_cast<unsigned short*>(st_lds);     // the A tiles as bf16 (BF)
     // diagnostic only (tools/diag_st_stamps.py): d.glu_dump, which this kernel has no other use for, may point to
     // 8 x 64-bit cycle stamps per workgroup; no output value depends on them and production descriptors leave it NULL
     unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(d.glu_dump);
@@ -253,7 +265,19 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_st_kernel(const eab_conv_d
                             x = st_xform<XF>(x, sh01[a], sh23[a], sl[a]);
                             x = bt.ok[tt * NS + j] ? x : f32x4{0.f, 0.f, 0.f, 0.f};   // zero padding acts on the NORMALISED tensor
                         }
-                        *reinterpret_cast<f32x4*>(dst + a * BM * LD) = x;
+                        if constexpr (BF) {
+                            // bf16 image with the K order of the 16x16x32 MFMA's lanes: inside a 32-deep block, k = 16a + 8b +
+                            // 2kq + e sits at 8kq + 4a + 2b + e, so lane kq reads its 8 operands of a block as one b128 and
+                            // they pair with the fp32 weight fragments of two consecutive 16-deep steps
+                            const int k0 = (tap0 + tt) * Cpad + coff + c;          // multiple of 4
+                            const int blk = k0 & ~31, r32 = k0 & 31;
+                            const int pos = blk + 8 * ((r32 & 7) >> 1) + 4 * (r32 >> 4) + 2 * ((r32 >> 3) & 1);
+                            unsigned short* hrow = sh + (a * BM + (tid >> SH4) + j * RPS) * LD;
+                            *reinterpret_cast<unsigned*>(hrow + pos) = st_bf2(x[0], x[1]);
+                            *reinterpret_cast<unsigned*>(hrow + pos + 8) = st_bf2(x[2], x[3]);
+                        } else {
+                            *reinterpret_cast<f32x4*>(dst + a * BM * LD) = x;
+                        }
                     }
                 }
             }
@@ -361,7 +385,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_st_kernel(const eab_conv_d
         else if (sh4_1 == 5) { rows_of(SH32{}, rw1); stage_rest(SH32{}, rs1, d.C0, 1, rw1, false); }
         else { rows_of(SH64{}, rw1); stage_rest(SH64{}, rs1, d.C0, 1, rw1, false); }
     }
-    if (Cpad != Ctot) {                                  // channel padding of a tap (C0 + C1 not a multiple of 16): zeros
+    if (!BF && Cpad != Ctot) {                           // channel padding of a tap (C0 + C1 not a multiple of 16): zeros
         const int padc = Cpad - Ctot;
         for (int e = tid; e < BM * ntaps * padc; e += ST_THREADS) {
             const int c = e % padc, rt = e / padc;
@@ -388,6 +412,43 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_st_kernel(const eab_conv_d
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) acc[n][rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (BF) {
+        constexpr int UB = U / 2;                        // 32-deep steps
+        constexpr int UAB = UA >= 2 ? UA / 2 : 1;
+        const unsigned short* h_lane = sh + li * LD + 8 * kq;
+        const int M32 = M2 >> 1;
+#pragma unroll
+        for (int ua = 0; ua < UB; ua += UAB) {
+            if (ua < M32) {                              // workgroup-uniform
+                st_bf16x8 ah[UAB][NA][RB];
+#pragma unroll
+                for (int sI = 0; sI < UAB; ++sI) {
+                    const int uc = ua + sI < M32 ? ua + sI : M32 - 1;
+#pragma unroll
+                    for (int a = 0; a < NA; ++a)
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb)
+                            ah[sI][a][rb] = *reinterpret_cast<const st_bf16x8*>(h_lane + (a * BM + rb * 16) * LD + 32 * uc);
+                }
+#pragma unroll
+                for (int sI = 0; sI < UAB; ++sI) {
+                    const int u = ua + sI;
+                    if (u < UB && u < M32) {
+#pragma unroll
+                        for (int cb = 0; cb < NCB; ++cb) {
+                            const f32x4 w0 = bq[2 * u < U ? 2 * u : 0][cb], w1 = bq[2 * u + 1 < U ? 2 * u + 1 : 0][cb];
+                            const u32x4 bw = {st_bf2(w0[0], w0[1]), st_bf2(w0[2], w0[3]), st_bf2(w1[0], w1[1]), st_bf2(w1[2], w1[3])};
+                            const st_bf16x8 bh = __builtin_bit_cast(st_bf16x8, bw);
+#pragma unroll
+                            for (int rb = 0; rb < RB; ++rb)
+                                acc[u & 1][rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[sI][DUAL ? cb : 0][rb], bh,
+                                                                                               acc[u & 1][rb][cb], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    } else {
     const float* a_lane = sa + li * LD + 2 * kq;
 #pragma unroll
     for (int ua = 0; ua < U; ua += UA) {
@@ -422,6 +483,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_st_kernel(const eab_conv_d
                 }
             }
         }
+    }
     }
     if (NACC == 2) {
 #pragma unroll
@@ -580,11 +642,12 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_st_kernel(const eab_conv_d
 
 // LDS bytes of a launch
 static size_t st_lds_bytes(const eab_conv_desc* d, int bm, bool dual) {
-    return (size_t)(dual ? 2 : 1) * bm * (d->Kpad + 4) * sizeof(float) + sizeof(StTables);
+    const bool bf = d->precision == EAB_PREC_BF16;
+    return (size_t)(dual ? 2 : 1) * bm * (bf ? (d->Kpad + 8) * 2 : (d->Kpad + 4) * 4) + sizeof(StTables);
 }
 
-template <int RB, int NCB, int MODE, int XF>
-static int st_launch(const eab_conv_desc* d, hipStream_t s) {
+template <int RB, int NCB, int MODE, int XF, bool BF>
+static int st_launch_p(const eab_conv_desc* d, hipStream_t s) {
     constexpr int BM = 16 * RB;
     const int Tw = d->win.pos ? d->win.count : d->T;
     const long long tiles = ((long long)Tw * d->No + BM - 1) / BM + (d->ph1_No > 0 ? ((long long)Tw * d->ph1_No + BM - 1) / BM : 0);
@@ -592,13 +655,18 @@ static int st_launch(const eab_conv_desc* d, hipStream_t s) {
     if (lds > 160 * 1024) return EAB_EUNSUPPORTED;
     static bool attr_set = false;                        // per instantiation: allow more than the default 64 KB
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_st_kernel<RB, NCB, MODE, XF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_st_kernel<RB, NCB, MODE, XF, BF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return eab_hip_status(e);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_st_kernel<RB, NCB, MODE, XF>), dim3((unsigned)(d->B * tiles)), dim3(ST_THREADS), lds, s, *d);
+    hipLaunchKernelGGL((conv_st_kernel<RB, NCB, MODE, XF, BF>), dim3((unsigned)(d->B * tiles)), dim3(ST_THREADS), lds, s, *d);
     EAB_RETURN_LAUNCH_STATUS();
+}
+
+template <int RB, int NCB, int MODE, int XF>
+static int st_launch(const eab_conv_desc* d, hipStream_t s) {
+    return d->precision == EAB_PREC_BF16 ? st_launch_p<RB, NCB, MODE, XF, true>(d, s) : st_launch_p<RB, NCB, MODE, XF, false>(d, s);
 }
 
 template <int NCB, int MODE, int XF>
@@ -615,7 +683,8 @@ static int st_pick_rb(const eab_conv_desc* d, hipStream_t s) {
 
 // eab_conv_f32 with d->korder == EAB_KORDER_FRAG lands here (arguments common to both kernels are checked there)
 int eab_conv_st(const eab_conv_desc* d, hipStream_t s) {
-    EAB_CHECK_ARG(d->precision == EAB_PREC_F32);
+    EAB_CHECK_ARG(d->precision == EAB_PREC_F32 || d->precision == EAB_PREC_BF16);
+    EAB_CHECK_ARG(d->precision == EAB_PREC_F32 || (d->Kpad % 32 == 0 && (d->ph1_No == 0 || d->ph1_Kpad % 32 == 0)));
     EAB_CHECK_ARG(d->bm == 16 || d->bm == 32 || d->bm == 64);
     EAB_CHECK_ARG((d->C0 == 64 || d->C0 == 128 || d->C0 == 256) && (d->C1 == 0 || d->C1 == 64 || d->C1 == 128 || d->C1 == 256));
     EAB_CHECK_ARG(d->epi == EAB_EPI_LINEAR || d->epi == EAB_EPI_RELU || d->epi == EAB_EPI_ADD || d->epi == EAB_EPI_DUALGATE);

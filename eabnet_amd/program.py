@@ -465,9 +465,9 @@ class Lowering:
             raise ValueError(f"precision must be 'f32', 'f16x3' or 'bf16', got {precision!r}")
         self.precision = precision
         self.patch = os.environ.get("EAB_PATCH", "1") != "0"      # tuning knob: 0 = gather pipeline everywhere
-        # small-tile kernel (csrc/conv_st.hip, exact fp32) for the latency-bound launches: the S-TCN and the 64-column unit
+        # small-tile kernel (csrc/conv_st.hip; exact fp32 or bf16 products) for the latency-bound launches: the S-TCN and the 64-column unit
         # convolutions with at most `st_maxno` output columns; EAB_ST=0 puts everything back on conv_gemm_kernel
-        self.st = os.environ.get("EAB_ST", "1") != "0" and precision == "f32"
+        self.st = os.environ.get("EAB_ST", "1") != "0" and precision in ("f32", "bf16")
         self.st_maxno = int(os.environ.get("EAB_ST_MAXNO", "5"))
         specs = self.spec_fn(cfg)
         specs = {k: v for k, v in specs.items() if v.kind != "bn_count"}     # the step counter is not arithmetic
@@ -614,7 +614,7 @@ class Lowering:
         korder = KORDER_TAP
         ph1kw = {}
         if st:
-            assert self.precision == "f32" and N in (64, 128, 256) and bm in (16, 32, 64)
+            assert self.precision in ("f32", "bf16") and N in (64, 128, 256) and bm in (16, 32, 64)
             assert Kpad <= {64: 256, 128: 320, 256: 64}[N], "small-tile kernel: the K extent must fit the wave's registers"
             assert epi in (EPI_LINEAR, EPI_RELU, EPI_ADD, EPI_DUALGATE)
             korder = KORDER_FRAG

@@ -170,7 +170,7 @@ class TrainLowering:
             raise ValueError("training precision is 'f32' or 'bf16' (bf16: forward, dgrad and wgrad contractions on the bf16 "
                              "matrix cores with fp32 accumulation; LSTM, norms, gradients and the optimiser state stay fp32)")
         self.prec = prg.PREC_CODE[precision]
-        # small-tile kernel (csrc/conv_st.hip) for the 1-D convolutions of the S-TCMs and their dgrads (exact fp32 only)
+        # small-tile kernel (csrc/conv_st.hip) for the 1-D convolutions of the S-TCMs and their dgrads
         self.st = os.environ.get("EAB_ST", "1") != "0"
         if not self.supports(cfg):
             raise NotImplementedError("the HIP training path covers the default topology with InstanceNorm")
@@ -540,8 +540,8 @@ class TrainLowering:
         out = self.act(1, N)
 
         def st_geometry(n, c, kp, epi_=prg.EPI_LINEAR):
-            """rows per tile of a small-tile launch (csrc/conv_st.hip; exact fp32 only), 0 = conv_gemm_kernel"""
-            if not (self.st and self.prec == prg.PREC_F32 and n in (64, 128, 256) and c in (64, 128, 256)
+            """rows per tile of a small-tile launch (csrc/conv_st.hip), 0 = conv_gemm_kernel"""
+            if not (self.st and self.prec in (prg.PREC_F32, prg.PREC_BF16) and n in (64, 128, 256) and c in (64, 128, 256)
                     and kp <= {64: 256, 128: 320, 256: 64}[n] and epi_ in (prg.EPI_LINEAR, prg.EPI_RELU, prg.EPI_ADD)):
                 return 0
             return 32 if self.B * ((self.T + 31) // 32) >= 2 * prg.CUS else 16

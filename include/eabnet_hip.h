@@ -279,7 +279,7 @@ typedef struct eab_conv_desc {
 #define EAB_PREC_BF16  2
 #define EAB_KORDER_TAP   0
 #define EAB_KORDER_CHUNK 1
-/* EAB_KORDER_FRAG selects the small-tile kernel (csrc/conv_st.hip; exact fp32 only) for latency-bound launches: the
+/* EAB_KORDER_FRAG selects the small-tile kernel (csrc/conv_st.hip; EAB_PREC_F32 or EAB_PREC_BF16, `w` fp32 in both) for latency-bound launches: the
  * S-TCN's 1-D convolutions and 64-column unit convolutions on few frequency bins.  bm = 16, 32 or 64 rows per tile;
  * N = 64, 128 or 256; C0, C1 in {64, 128, 256}; epilogues LINEAR / RELU / ADD / DUALGATE.  `w` holds the weights in
  * MFMA-fragment order, unit order as EAB_KORDER_TAP (k = tap*UPT*16 + channel):

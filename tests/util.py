@@ -26,9 +26,11 @@ def rel_errs(a, b):
     return float(np.abs(d).max() / max(np.abs(b).max(), 1e-30)), float(np.linalg.norm(d) / max(np.linalg.norm(b), 1e-30))
 
 
-def assert_close(a, b, tol, what=""):
+def assert_close(a, b, tol, what="", tol_max=None):
+    """max-abs/max <= tol_max (default: tol) and L2-rel <= tol"""
     m, l2 = rel_errs(a, b)
-    assert m <= tol and l2 <= tol, f"{what}: max-rel {m:.3e}, l2-rel {l2:.3e} > {tol:.1e}"
+    tm = tol if tol_max is None else tol_max
+    assert m <= tm and l2 <= tol, f"{what}: max-rel {m:.3e} (bound {tm:.1e}), l2-rel {l2:.3e} (bound {tol:.1e})"
     return m, l2
 
 
