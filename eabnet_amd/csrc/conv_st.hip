@@ -98,7 +98,7 @@ struct StTables {
 };
 
 template <int RB, int NCB, int MODE, int XF, bool BF>
-__global__ __launch_bounds__(ST_THREADS, 2) void conv_st_kernel(const eab_conv_desc d) {
+__global__ __launch_bounds__(ST_THREADS, MODE == ST_DUAL ? 1 : 2) void conv_st_kernel(const eab_conv_desc d) {
     // BF = EAB_PREC_BF16: tensors and weights stay fp32 in memory (the same fragment-order `w`); A is rounded to bf16 on
     // its way into LDS, B in registers, products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation
     constexpr bool DUAL = MODE == ST_DUAL;
@@ -170,6 +170,16 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_st_kernel(const eab_conv_d
         const int m2 = u < M2 ? u : 0;
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) bq[u][cb] = *reinterpret_cast<const f32x4*>(wb[cb] + (size_t)m2 * 256);
+    }
+
+    // fused second convolution (eab_conv_desc.f2_*; N = 256 launches only): its 64 x 256 weights, 16 columns per wave
+    constexpr bool F2OK = NCB == 4 && !DUAL && !BF;
+    const bool f2 = F2OK && d.f2_w != nullptr;
+    f32x4 bq2[F2OK ? 16 : 1];
+    if (f2) {
+#pragma unroll
+        for (int u = 0; u < (F2OK ? 16 : 1); ++u)
+            bq2[u] = *reinterpret_cast<const f32x4*>(d.f2_w + ((size_t)(wave * 16 + u) * 64 + lane) * 4);
     }
 
     // ---- tap tables -> LDS (needed for the gather addresses) --------------------------------------------------------------
@@ -574,6 +584,8 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_st_kernel(const eab_conv_d
 #pragma unroll
         for (int c = 0; c < NC; ++c) skk[s][c] = ssum[s][c] = ssq[s][c] = 0.0f;
     const bool two_sets = d.nsets == 2;
+    constexpr int LD2 = 256 + 4;                         // fused second convolution: its A tile [BM][256 + 4] behind the tables
+    float* const t2 = reinterpret_cast<float*>(&tb + 1);
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -590,6 +602,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_st_kernel(const eab_conv_d
                 else if (d.epi == EAB_EPI_ADD) v = v + auxv[rb][r][c];
                 const unsigned o4 = rowok[rb][r] ? off[rb][r] + 4u * ch[c] : ST_OOB;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_dst, o4, 0, 0);
+                if (F2OK && f2) t2[(rb * 16 + 4 * kq + r) * LD2 + ch[c]] = v;      // A operand of the fused second convolution
                 if (d.dst_acc)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + accv[rb][r][c]), r_acc, o4, 0, 0);
                 if (d.stats && rowok[rb][r]) {
@@ -634,6 +647,90 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_st_kernel(const eab_conv_d
             }
         }
     }
+    if constexpr (F2OK) {
+        if (f2) {
+            // ---- fused second convolution: y2[row][n2] = sum_c W2[n2][c] * out[row][c] on the tile this workgroup just wrote
+            __syncthreads();                             // every wave's 64 output columns are in t2
+            f32x4 acc2[2][RB];
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc2[n][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* a2_lane = t2 + li * LD2 + 2 * kq;
+#pragma unroll
+            for (int ua = 0; ua < 16; ua += 4) {
+                f32x2 af2[4][2][RB];
+#pragma unroll
+                for (int sI = 0; sI < 4; ++sI)
+#pragma unroll
+                    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb)
+                            af2[sI][ms][rb] = *reinterpret_cast<const f32x2*>(a2_lane + rb * 16 * LD2 + 16 * (ua + sI) + 8 * ms);
+#pragma unroll
+                for (int sI = 0; sI < 4; ++sI)
+#pragma unroll
+                    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+#pragma unroll
+                            for (int rb = 0; rb < RB; ++rb)
+                                acc2[e][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af2[sI][ms][rb][e], bq2[ua + sI][2 * ms + e],
+                                                                                    acc2[e][rb], 0, 0, 0);
+            }
+            const int N2 = d.f2_N, ch2 = wave * 16 + li;
+            const __amdgpu_buffer_rsrc_t r_d2 = st_rsrc(d.f2_dst + (size_t)b * d.T * N2, (unsigned)d.T * N2 * 4u);
+            float sl2[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const float* sp = s2 == 0 ? d.f2_stat_slope0 : d.f2_stat_slope1;
+                sl2[s2] = (d.f2_stats && s2 < d.f2_nsets && sp) ? sp[ch2] : 1.0f;
+            }
+            float kk2[2] = {0.f, 0.f}, su2[2] = {0.f, 0.f}, sq2[2] = {0.f, 0.f}, cnt2 = 0.0f;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = q0 + rb * 16 + 4 * kq + r;                       // No == 1: row = frame
+                    const bool okr = q < Q;
+                    const float v2 = acc2[0][rb][r] + acc2[1][rb][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v2), r_d2,
+                                                          okr ? (unsigned)((q * N2 + ch2) * 4) : ST_OOB, 0, 0);
+                    if (d.f2_stats && okr) {
+                        const bool first = cnt2 == 0.0f;
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const float g = eab_prelu(v2, sl2[s2]);
+                            if (first) kk2[s2] = g;
+                            const float e2 = g - kk2[s2];
+                            su2[s2] += e2;
+                            sq2[s2] = fmaf(e2, e2, sq2[s2]);
+                        }
+                    }
+                    if (okr) cnt2 += 1.0f;
+                }
+            if (d.f2_stats) {
+                const float inv_n = cnt2 > 0.0f ? 1.0f / cnt2 : 0.0f;
+                const size_t tbase = ((size_t)b * d.f2_stat_tiles + stat_tile) * d.f2_nsets;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    if (s2 >= d.f2_nsets) break;
+                    float n = cnt2;
+                    float mean = fmaf(su2[s2], inv_n, kk2[s2]);
+                    float m2 = fmaxf(sq2[s2] - su2[s2] * su2[s2] * inv_n, 0.0f);
+                    float no = __shfl_xor(n, 16), mo = __shfl_xor(mean, 16), qo = __shfl_xor(m2, 16);
+                    if ((kq & 1) == 0) st_merge(n, mean, m2, no, mo, qo);
+                    no = __shfl_xor(n, 32);
+                    mo = __shfl_xor(mean, 32);
+                    qo = __shfl_xor(m2, 32);
+                    if (kq == 0) {
+                        st_merge(n, mean, m2, no, mo, qo);
+                        *reinterpret_cast<f32x4*>(&d.f2_stats[((tbase + s2) * N2 + ch2) * 4]) = f32x4{n, mean, m2, 0.0f};
+                    }
+                }
+            }
+        }
+    }
     if (stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(5);
@@ -643,7 +740,8 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_st_kernel(const eab_conv_d
 // LDS bytes of a launch
 static size_t st_lds_bytes(const eab_conv_desc* d, int bm, bool dual) {
     const bool bf = d->precision == EAB_PREC_BF16;
-    return (size_t)(dual ? 2 : 1) * bm * (bf ? (d->Kpad + 8) * 2 : (d->Kpad + 4) * 4) + sizeof(StTables);
+    return (size_t)(dual ? 2 : 1) * bm * (bf ? (d->Kpad + 8) * 2 : (d->Kpad + 4) * 4) + sizeof(StTables) +
+           (d->f2_w ? (size_t)bm * (256 + 4) * sizeof(float) : 0);
 }
 
 template <int RB, int NCB, int MODE, int XF, bool BF>
@@ -700,6 +798,12 @@ int eab_conv_st(const eab_conv_desc* d, hipStream_t s) {
         if (d->win.pos)
             for (int j = 0; j < d->ph1_ntaps; ++j) EAB_CHECK_ARG(d->ph1_dt[j] <= 0);
         EAB_CHECK_ARG((long long)d->T * d->ph1_No < (1ll << 22));
+    }
+    if (d->f2_w) {                                       // fused second 1x1 convolution on this launch's output rows
+        EAB_CHECK_ARG(d->precision == EAB_PREC_F32 && d->N == 256 && !dual && d->f2_N == 64 && d->f2_dst);
+        EAB_CHECK_ARG(d->No == 1 && d->Fin == 1 && d->Fout == 1 && d->ph1_No == 0 && d->ostride == 1 && d->ophase == 0);
+        EAB_CHECK_ARG(d->f2_nsets >= 0 && d->f2_nsets <= 2 && (d->f2_nsets == 0) == (d->f2_stats == nullptr));
+        EAB_CHECK_ARG(d->f2_stats == nullptr || (d->win.pos == nullptr && d->f2_stat_tiles >= eab_conv_tiles(d->T, 1, d->bm)));
     }
     const bool has_xf = d->xf_mode != EAB_XF_NONE && (d->xf0 || d->xf1 || d->fin_stats);
     const int xf = has_xf ? d->xf_mode : EAB_XF_NONE;

@@ -188,6 +188,10 @@ class _Bound:
                 for j in range(_lib.MAX_TAPS):
                     d.ph1_dt[j] = op.ph1_dt[j] if j < len(op.ph1_dt) else 0
                     d.ph1_ioff[j] = op.ph1_ioff[j] if j < len(op.ph1_ioff) else 0
+                # fused second 1x1 convolution (out_conv of one S-TCM + in_conv of the next)
+                for f in ("f2_w", "f2_dst", "f2_stats", "f2_stat_slope0", "f2_stat_slope1"):
+                    setattr(d, f, A(getattr(op, f)))
+                d.f2_N, d.f2_nsets, d.f2_stat_tiles = int(op.f2_N), int(op.f2_nsets), int(op.f2_stat_tiles)
             elif op.kind == prg.OP_IN_FINALIZE:
                 o.i[0:5] = [op.B, op.C, op.nsets, op.stat_tiles, op.count]
                 o.f[0] = op.eps

@@ -135,6 +135,15 @@ class ConvOp:
     ph1_Kpad: int = 0
     ph1_dt: List[int] = field(default_factory=list)
     ph1_ioff: List[int] = field(default_factory=list)
+    # KORDER_FRAG, N = 256, 1-D: fused second 1x1 convolution on this launch's output rows (eab_conv_desc.f2_*)
+    f2_w: Optional[Ref] = None
+    f2_dst: Optional[Ref] = None
+    f2_stats: Optional[Ref] = None
+    f2_stat_slope0: Optional[Ref] = None
+    f2_stat_slope1: Optional[Ref] = None
+    f2_N: int = 0
+    f2_nsets: int = 0
+    f2_stat_tiles: int = 0
 
 
 @dataclass
@@ -469,6 +478,7 @@ class Lowering:
         # convolutions with at most `st_maxno` output columns; EAB_ST=0 puts everything back on conv_gemm_kernel
         self.st = os.environ.get("EAB_ST", "1") != "0" and precision in ("f32", "bf16")
         self.st_maxno = int(os.environ.get("EAB_ST_MAXNO", "5"))
+        self.fuse_out_in = os.environ.get("EAB_ST_FUSE", "1") != "0"      # out_conv of one S-TCM + in_conv of the next in one launch
         specs = self.spec_fn(cfg)
         specs = {k: v for k, v in specs.items() if v.kind != "bn_count"}     # the step counter is not arithmetic
         missing = [k for k in specs if k not in params]
@@ -849,13 +859,17 @@ class Lowering:
         return self.materialise(pre, g, y)
 
     # -- squeezed TCM --------------------------------------------------------------------
-    def tcm(self, pre: str, x: Act, dilation: int, x_acc: Optional[Ref], perm: np.ndarray) -> Act:
+    def tcm(self, pre: str, x: Act, dilation: int, x_acc: Optional[Ref], perm: np.ndarray, next_pre: Optional[str] = None,
+            have_in: Optional[dict] = None):
         """SqueezedTCM.forward, reference EaBNet.py:572-578, on [B][T][1][256], in three
         launches: in_conv (+ statistics of both branch PReLUs) -> left*sigmoid(right) in ONE
         dual-transform gated conv -> out_conv + residual.  T/64 tiles per utterance are few, so
-        each consumer reduces the InstanceNorm partials itself (no finalize launches)."""
+        each consumer reduces the InstanceNorm partials itself (no finalize launches).
+        Small-tile kernel, exact fp32: nothing but the residual stream lies between this block's out_conv and the NEXT
+        block's in_conv (`next_pre`), so the two run as one launch (eab_conv_desc.f2_*); the next call then gets the
+        finished in_conv as `have_in`.  Returns (output, have_in for the next block or None)."""
         if self.cln:
-            return self.tcm_cln(pre, x, dilation, x_acc, perm)
+            return self.tcm_cln(pre, x, dilation, x_acc, perm), None
         cfg, T, B = self.cfg, self.T, self.B
         D, cd, kd = cfg.d_feat, cfg.cd1, cfg.kd1
         bn = self.bn                                   # BatchNorm eval: static tables, no statistics at all
@@ -866,19 +880,28 @@ class Lowering:
             mt = None if bn else 64
             bm_in, bm_lr, bm_out = (self.pick_st_bm(1, cd, D, max_tiles=mt), self.pick_st_bm(1, 2 * cd, Kd, dual=True, max_tiles=mt),
                                     self.pick_st_bm(1, D, cd))
+            # the branch pair keeps 160 registers of weights per wave, i.e. one workgroup per CU: 16-row tiles only while
+            # they fit the chip in one round (measured at B = 16, T = 401: 416 tiles of 16 rows 22 us, 208 of 32 rows 16 us)
+            if B * conv_tiles(T, 1, 16) > CUS and (bn or conv_tiles(T, 1, 32) <= 64):
+                bm_lr = 32
+            if os.environ.get("EAB_ST_BM_LR"):           # tuning knob
+                bm_lr = int(os.environ["EAB_ST_BM_LR"])
         else:
             bm_in = bm_lr = bm_out = 64
         tiles, tiles_lr = conv_tiles(T, 1, bm_in), conv_tiles(T, 1, bm_lr)
-        assert bn or max(tiles, tiles_lr) <= 64, "in-kernel finalisation is sized for <= 64 partial tiles per utterance"
         nL, nR, nO = f"{pre}.left_conv.1", f"{pre}.right_conv.1", f"{pre}.out_conv.1"
-        # in_conv 1x1 (no bias); statistics of BOTH branch PReLUs of its output
-        w_in = self.P[f"{pre}.in_conv.weight"][:, perm, :]               # (cd, D, 1)
-        wref = self.W.add(f"{pre}.in_conv.weight#packed", pack_taps(w_in, [0]))
-        y = self.alloc_act(1, cd)
-        st = None if bn else self.alloc(B * tiles * 2 * cd * 4)
         slL, slR = self.vec(f"{pre}.left_conv.0.weight"), self.vec(f"{pre}.right_conv.0.weight")
-        self.emit_conv(f"{pre}.in_conv", [x], wref, None, cd, D, 1, 1, 1, 0, 1, [0], [0], EPI_LINEAR, y,
-                       st, 0 if bn else 2, (None, None) if bn else (slL, slR), 0 if bn else tiles, 0, bm_in, st=use_st)
+        if have_in is not None:                         # produced by the previous block's fused out_conv launch
+            y, st, tiles = have_in["y"], have_in["st"], have_in["tiles"]
+        else:
+            # in_conv 1x1 (no bias); statistics of BOTH branch PReLUs of its output
+            w_in = self.P[f"{pre}.in_conv.weight"][:, perm, :]               # (cd, D, 1)
+            wref = self.W.add(f"{pre}.in_conv.weight#packed", pack_taps(w_in, [0]))
+            y = self.alloc_act(1, cd)
+            st = None if bn else self.alloc(B * tiles * 2 * cd * 4)
+            self.emit_conv(f"{pre}.in_conv", [x], wref, None, cd, D, 1, 1, 1, 0, 1, [0], [0], EPI_LINEAR, y,
+                           st, 0 if bn else 2, (None, None) if bn else (slL, slR), 0 if bn else tiles, 0, bm_in, st=use_st)
+        assert bn or max(tiles, tiles_lr) <= 64, "in-kernel finalisation is sized for <= 64 partial tiles per utterance"
         # z = left(y) * sigmoid(right(y)): columns [0,cd) see PReLU_L/IN_L(y), columns [cd,2cd) PReLU_R/IN_R(y)
         # taps (EaBNet.py:550-553): all in the past when causal, centred otherwise
         span = (kd - 1) * dilation
@@ -900,10 +923,24 @@ class Lowering:
         w_out = self.P[f"{pre}.out_conv.2.weight"][perm]                  # (D, cd, 1), rows permuted
         wo = self.W.add(f"{pre}.out_conv.2.weight#packed", pack_taps(w_out, [0]))
         xn = self.alloc_act(1, D)
-        self.emit_conv(f"{pre}.out_conv", [Act(z, 1, cd, self.bn_xf(nO) if bn else None, slO, XF_PRELU_NORM)], wo, None,
-                       D, cd, 1, 1, 1, 0, 1, [0], [0], EPI_ADD, xn, bm=bm_out, aux=x.ref, dst_acc=x_acc,
-                       fin=None if bn else dict(stats=st2, tiles=tiles_lr, nsets=1, count=T, norms=[nO]), st=use_st)
-        return Act(xn, 1, D)
+        op = self.emit_conv(f"{pre}.out_conv", [Act(z, 1, cd, self.bn_xf(nO) if bn else None, slO, XF_PRELU_NORM)], wo, None,
+                            D, cd, 1, 1, 1, 0, 1, [0], [0], EPI_ADD, xn, bm=bm_out, aux=x.ref, dst_acc=x_acc,
+                            fin=None if bn else dict(stats=st2, tiles=tiles_lr, nsets=1, count=T, norms=[nO]), st=use_st)
+        nxt = None
+        if use_st and next_pre is not None and self.precision == "f32" and self.fuse_out_in:
+            # ... + the next block's in_conv on the rows just produced (one launch instead of two)
+            tiles_n = conv_tiles(T, 1, bm_out)
+            w_in_n = self.P[f"{next_pre}.in_conv.weight"][:, perm, :]
+            op.f2_w = self.W.add(f"{next_pre}.in_conv.weight#frag2", pack_frag(pack_taps(w_in_n, [0])))
+            op.f2_dst, op.f2_N = self.alloc_act(1, cd), cd
+            if not bn:
+                op.f2_stats, op.f2_nsets, op.f2_stat_tiles = self.alloc(B * tiles_n * 2 * cd * 4), 2, tiles_n
+                op.f2_stat_slope0 = self.vec(f"{next_pre}.left_conv.0.weight")
+                op.f2_stat_slope1 = self.vec(f"{next_pre}.right_conv.0.weight")
+            op.name = f"{pre}.out_conv+{next_pre}.in_conv"
+            self.flops += 2 * B * T * cd * D
+            nxt = dict(y=op.f2_dst, st=op.f2_stats, tiles=tiles_n)
+        return Act(xn, 1, D), nxt
 
     def tcm_cln(self, pre: str, x: Act, dilation: int, x_acc: Optional[Ref], perm: np.ndarray) -> Act:
         """SqueezedTCM.forward (EaBNet.py:572-578) with cumulative LayerNorms: every normalised tensor is materialised
@@ -975,11 +1012,13 @@ class Lowering:
         x_acc = self.alloc_act(1, cfg.d_feat)
         self.ops.append(MemsetOp(x_acc, B * T * cfg.d_feat, B=B, T=T, row=cfg.d_feat, win=bool(self.chunk),
                                  name="stcns.acc0"))
-        for gi in range(cfg.q):
-            for i in range(cfg.p):
-                xt = self.tcm(f"stcns.{gi}.tcm_list.{i}", xt, 2 ** i, x_acc if i == cfg.p - 1 else None, perm)
-                if gi == 0 and i == 0:
-                    self.taps["stcns.0.0"] = xt
+        names = [(gi, i) for gi in range(cfg.q) for i in range(cfg.p)]
+        have_in = None
+        for k, (gi, i) in enumerate(names):
+            nxt = f"stcns.{names[k + 1][0]}.tcm_list.{names[k + 1][1]}" if k + 1 < len(names) else None
+            xt, have_in = self.tcm(f"stcns.{gi}.tcm_list.{i}", xt, 2 ** i, x_acc if i == cfg.p - 1 else None, perm, nxt, have_in)
+            if gi == 0 and i == 0:
+                self.taps["stcns.0.0"] = xt
         x = Act(x_acc, Fb, c)
         self.taps["stcns"] = x
 

@@ -267,6 +267,18 @@ typedef struct eab_conv_desc {
     int32_t ph1_No, ph1_ophase, ph1_ntaps, ph1_Kpad;
     int32_t ph1_dt[EAB_MAX_TAPS];
     int32_t ph1_ioff[EAB_MAX_TAPS];
+    /* EAB_KORDER_FRAG, EAB_PREC_F32, 1-D launches (No = Fin = Fout = 1) with N = 256 only: a SECOND 1x1 convolution applied
+     * to the rows this launch has just produced, in the same kernel -- the out_conv of one S-TCM and the in_conv of the next
+     * (EaBNet.py:575-577 then :572-573 of the following block): nothing but the residual stream lies between them.
+     *   f2_dst[b][t][n2] = sum_c f2_w[n2][c] * dst[b][t][c]     (dst = this launch's output after its epilogue)
+     * f2_w: fragment-order weights [f2_N = 64][256]; f2_stats / f2_nsets / f2_stat_slope*: InstanceNorm partials of f2_dst
+     * exactly like `stats` (tile index = this launch's tile index, f2_stat_tiles tiles per batch element).  NULL f2_w = none. */
+    const float* f2_w;
+    float* f2_dst;
+    float* f2_stats;
+    const float* f2_stat_slope0;
+    const float* f2_stat_slope1;
+    int32_t f2_N, f2_nsets, f2_stat_tiles;
 } eab_conv_desc;
 
 #define EAB_PREC_F32   0

@@ -95,7 +95,16 @@ class Emulator:
             for wref, K, No_, oph, dt, ioff, st0 in passes:
                 self.arena["tmp"] = prg.unpack_frag(self.v(wref, (op.N * K,)), op.N, K, dual)[order].reshape(-1)
                 self.conv(dataclasses.replace(op, korder=prg.KORDER_TAP, w=prg.Ref("tmp", 0), Kpad=K, No=No_, ophase=oph, dt=list(dt),
-                                              ioff=list(ioff), stat_tile0=st0, ph1_w=None, ph1_No=0, ph1_dt=[], ph1_ioff=[]))
+                                              ioff=list(ioff), stat_tile0=st0, ph1_w=None, ph1_No=0, ph1_dt=[], ph1_ioff=[], f2_w=None))
+            if op.f2_w is not None:
+                # fused second 1x1 convolution on the rows just written: as its own launch on this launch's output
+                self.arena["tmp"] = prg.unpack_frag(self.v(op.f2_w, (op.f2_N * op.N,)), op.f2_N, op.N).reshape(-1)
+                self.conv(prg.ConvOp(src0=op.dst, src1=None, xf0=None, xf1=None, slope0=None, slope1=None, C0=op.N, C1=0,
+                                     xf_mode=prg.XF_NONE, w=prg.Ref("tmp", 0), bias=None, N=op.f2_N, Kpad=op.N, B=op.B, T=op.T, Fin=1,
+                                     Fout=1, No=1, ostride=1, ophase=0, istride=1, dt=[0], ioff=[0], epi=prg.EPI_LINEAR, aux=None,
+                                     dst=op.f2_dst, dst_acc=None, Cout=op.f2_N, stats=op.f2_stats, nsets=op.f2_nsets,
+                                     stat_slope0=op.f2_stat_slope0, stat_slope1=op.f2_stat_slope1, stat_tiles=op.f2_stat_tiles,
+                                     stat_tile0=0, bm=op.bm, win=op.win, name=op.name + ".f2"))
             return
         B, T, Fin, No = op.B, op.T, op.Fin, op.No
         def xform(x, tab, a):
