@@ -106,8 +106,8 @@ __global__ __launch_bounds__(ST_THREADS, MODE == ST_DUAL ? 1 : 2) void conv_st_k
     constexpr int NA = DUAL ? 2 : 1;
     // ALL of this wave's B operands are fetched up front and stay in registers (K/16 x NCB b128 loads in flight at once: one
     // L2 round trip, overlapped with the A burst).  These launches run one or two waves per SIMD, so registers are free;
-    // U bounds the K extent a variant accepts (host check): 256 for N = 64, 320 for N = 128 (the S-TCM branch pair), 64 for 256.
-    constexpr int U = NCB == 1 ? 16 : NCB == 2 ? 20 : 4;
+    // U bounds the K extent a variant accepts (host check): 320 for N = 64 and 128 (a five-tap S-TCM branch), 64 for N = 256.
+    constexpr int U = NCB <= 2 ? 20 : 4;
     static_assert(!DUAL || NCB == 2, "dual gate: one value and one gate block per wave");
     extern __shared__ __attribute__((aligned(16))) float st_lds[];
 
@@ -810,7 +810,7 @@ int eab_conv_st(const eab_conv_desc* d, hipStream_t s) {
     if (xf != EAB_XF_NONE) EAB_CHECK_ARG(d->C0 <= ST_XFC && d->C1 <= ST_XFC);
     if (d->fin_stats) EAB_CHECK_ARG(d->fin_nsets * d->C0 <= ST_THREADS);
     // the whole K extent of a wave's weights is held in registers
-    if (d->Kpad > (d->N == 64 ? 256 : d->N == 128 ? 320 : 64)) return EAB_EUNSUPPORTED;
+    if (d->Kpad > (d->N == 256 ? 64 : 320)) return EAB_EUNSUPPORTED;
     if (d->N == 128 && d->bm == 64) return EAB_EUNSUPPORTED;
     if (dual) {
         if (d->N != 128 || xf != EAB_XF_PRELU_NORM) return EAB_EUNSUPPORTED;

@@ -250,7 +250,7 @@ class _Bound:
         branches (prog.sync) fork onto side streams with events -- inside a hipGraph capture these become
         graph edges, so the branches replay concurrently."""
         n = len(self.prog.ops) - first if count is None else count
-        if not self.prog.sync or count is not None:
+        if not self.prog.sync or count is not None or not graph_branches_allowed():
             return self._launch(stream, first, n)         # single lane (or a single-op debug launch)
         main = torch.cuda.current_stream()
         assert main.cuda_stream == stream, "multi-lane programs run on torch's current stream"
@@ -290,6 +290,20 @@ class _Bound:
 # ----------------------------------------------------------------------------
 # the module
 # ----------------------------------------------------------------------------
+def graph_branches_allowed() -> bool:
+    """Parallel branches (side streams -> branches of the captured hipGraph) for programs that mark independent chains?
+    EAB_GRAPH_BRANCHES=0 runs every program on one stream."""
+    import os
+    if os.environ.get("EAB_GRAPH_BRANCHES", "1") == "0":
+        return False
+    # With a torch.distributed process group alive in the process, replaying a multi-branch hipGraph has ended in a
+    # segmentation fault inside the HIP runtime (hip::Graph::UpdateStreams <- hip::GraphExec::Run <- hipGraphLaunch; ROCm 7.2,
+    # gpurun_out/r03_gdb.log: reproducible with the round-2 sources as well, never without graph branches): data-parallel
+    # jobs run their programs on one stream.
+    import torch.distributed as td
+    return not (td.is_available() and td.is_initialized())
+
+
 def _warn_operator_path(module: nn.Module, reason: str) -> None:
     """One warning per module when `use_hip_training` is on but a differentiable forward runs on PyTorch-ROCm operators
     (autograd_path.py, ~5x slower at the training benchmark's size): the switch must not be silent."""

@@ -625,7 +625,7 @@ class Lowering:
         ph1kw = {}
         if st:
             assert self.precision in ("f32", "bf16") and N in (64, 128, 256) and bm in (16, 32, 64)
-            assert Kpad <= {64: 256, 128: 320, 256: 64}[N], "small-tile kernel: the K extent must fit the wave's registers"
+            assert Kpad <= {64: 320, 128: 320, 256: 64}[N], "small-tile kernel: the K extent must fit the wave's registers"
             assert epi in (EPI_LINEAR, EPI_RELU, EPI_ADD, EPI_DUALGATE)
             korder = KORDER_FRAG
             dual = epi == EPI_DUALGATE

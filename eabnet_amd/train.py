@@ -542,7 +542,7 @@ class TrainLowering:
         def st_geometry(n, c, kp, epi_=prg.EPI_LINEAR):
             """rows per tile of a small-tile launch (csrc/conv_st.hip), 0 = conv_gemm_kernel"""
             if not (self.st and self.prec in (prg.PREC_F32, prg.PREC_BF16) and n in (64, 128, 256) and c in (64, 128, 256)
-                    and kp <= {64: 256, 128: 320, 256: 64}[n] and epi_ in (prg.EPI_LINEAR, prg.EPI_RELU, prg.EPI_ADD)):
+                    and kp <= {64: 320, 128: 320, 256: 64}[n] and epi_ in (prg.EPI_LINEAR, prg.EPI_RELU, prg.EPI_ADD)):
                 return 0
             return 32 if self.B * ((self.T + 31) // 32) >= 2 * prg.CUS else 16
         st_bm = st_geometry(N, Cc, wimg.shape[1], epi)
@@ -1011,7 +1011,8 @@ class TrainBound:
             for sd in used:
                 main.wait_stream(sd)
             return
-        sync = self.prog.sync.get(which) if self.parallel_branches else None
+        from .model import graph_branches_allowed
+        sync = self.prog.sync.get(which) if (self.parallel_branches and graph_branches_allowed()) else None
         if sync and first == 0 and count is None:
             # programs with parallel branches (the post-filter's three S-TCM chains): fork onto side streams with events --
             # inside a hipGraph capture these become graph edges, so the branches replay concurrently

@@ -18,3 +18,19 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _release_device_programs(request):
+    """After every GPU test: collect the modules the test dropped, so that their bound programs (arenas of several GB at the
+    full-size tests, captured hipGraphs) are released now and not at some later collection inside another test's timing."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import gc
+        gc.collect()
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except Exception:                                 # noqa: BLE001
+            pass
