@@ -590,6 +590,18 @@ def main():
                 nm = {prg.OP_CONV: "conv_gemm", prg.OP_IN_FINALIZE: "in_finalize", prg.OP_NORM_ACT: "norm_act",
                       prg.OP_LSTM64: "lstm64", prg.OP_BFW_FS: "bfw_filter_sum", prg.OP_MEMSET0: "memset"}[o.kind]
                 by_kind[nm] = by_kind.get(nm, 0.0) + float(ms[k])
+            # the convolution time by block (what VERDICT r02 asks for: S-TCN, 64-column unit convolutions, gated convolutions)
+            by_block = {}
+            for k in conv:
+                o = ops[k]
+                blk = ("stcn" if o.name.startswith("stcns.") else "gated_128col" if o.epi == prg.EPI_GLU else "unit_64col")
+                e = by_block.setdefault(blk, {"launches": 0, "ms": 0.0, "gflop": 0.0})
+                e["launches"] += 1
+                e["ms"] += float(ms[k])
+                e["gflop"] += valid_flop(o) * 1e-9 + (2e-9 * o.B * o.T * o.f2_N * o.N if o.f2_w is not None else 0.0)
+            for e in by_block.values():
+                e["tflops"] = e["gflop"] / max(e["ms"], 1e-9)
+                e["ms"], e["gflop"] = round(e["ms"], 4), round(e["gflop"], 2)
             peak = PEAK_FP32_MFMA_TFLOPS
             # HBM traffic of the dominant kernel from the committed PMC summary of the same command
             # (tools/prof.sh + tools/summarize_profiles.py; PMC passes are separate runs by necessity).
@@ -597,7 +609,7 @@ def main():
             # half of a wide coalesced read stream on gfx950.
             traffic = None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_final", "pmc_summary.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_final", "pmc_summary.json")))
                 if pmc.get("_meta", {}).get("kernel_source_sha16") != kernel_source_sha():
                     raise LookupError("the committed PMC summary was taken on other kernel sources")
                 tag = "conv_gemm_kernel<2, 2, 1, 1, 0, true, %d, true>" % (0 if a.precision == "f32" else 1)
@@ -612,16 +624,18 @@ def main():
                 "kernel": "conv_gemm_kernel<MI=2,NI=2,KU=1,GLU,XF=0,VEC," + ("f32" if a.precision == "f32" else "f16x3")
                           + "> (128x128-tile gated gather-GEMM convolution)",
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r02_final; null when that profile is of other kernel sources)",
+                "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r03_final; null when that profile is of other kernel sources)",
                 "launches_per_step": len(dom), "avg_launch_ms": dom_ms / max(len(dom), 1),
                 "algorithmic_gflop_per_launch": dom_flop / max(len(dom), 1) / 1e9,
                 "share_of_program_time": dom_ms / float(ms.sum()),
                 "all_conv_launches": {"launches_per_step": len(conv), "ms": conv_ms,
                                       "achieved_tflops": 2.0 * conv_kernel_mac_per_frame(MICS) * B_PER_GPU * T / (conv_ms * 1e-3) / 1e12},
                 "program_ms_by_kernel": {k: round(v, 4) for k, v in sorted(by_kind.items(), key=lambda kv: -kv[1])},
+                "conv_ms_by_block": by_block,
                 "program_ms_total": float(ms.sum()),
                 "note": "achieved = exact valid-tap FLOPs of the dominant instantiation's launches / their summed "
-                        "duration (HIP events per op on the launch stream, instrumented replay after the timed region); "
+                        "duration (HIP events per op on the launch stream, instrumented replay after the timed region: every "
+                        "op's figure includes ~5 us of event overhead, which inflates the many short launches of conv_ms_by_block); "
                         "peak = fp32 MFMA dense (MI355X_MICROARCH.md); traffic: see profiles/ (PMC passes are separate runs)",
             }
         if rank == 0 and not a.no_roofline:

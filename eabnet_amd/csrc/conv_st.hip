@@ -48,13 +48,13 @@ __device__ __forceinline__ int st_div(int q, int n, float inv_n) {
 
 // Welford/Chan merge, (0,*,*) neutral
 __device__ __forceinline__ void st_merge(float& n, float& mean, float& m2, float nb, float meanb, float m2b) {
+    // branch-free; counts are small integers, so rcp (1 ulp) instead of an IEEE division chain is exact enough for a
+    // quantity that only feeds a normalisation -- and the same bits in every workgroup, which is what matters
     const float nt = n + nb;
-    if (nt > 0.0f) {
-        const float delta = meanb - mean;
-        const float fb = nb / nt;
-        mean = fmaf(delta, fb, mean);
-        m2 = m2 + m2b + delta * delta * n * fb;
-    }
+    const float fb = nt > 0.0f ? nb * __builtin_amdgcn_rcpf(nt) : 0.0f;
+    const float delta = meanb - mean;
+    mean = fmaf(delta, fb, mean);
+    m2 = m2 + m2b + delta * delta * n * fb;
     n = nt;
 }
 
@@ -586,6 +586,8 @@ __global__ __launch_bounds__(ST_THREADS, MODE == ST_DUAL ? 1 : 2) void conv_st_k
     const bool two_sets = d.nsets == 2;
     constexpr int LD2 = 256 + 4;                         // fused second convolution: its A tile [BM][256 + 4] behind the tables
     float* const t2 = reinterpret_cast<float*>(&tb + 1);
+    auto epi_loop = [&](auto with_stats) {
+        constexpr bool STATS = decltype(with_stats)::value;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -593,7 +595,7 @@ __global__ __launch_bounds__(ST_THREADS, MODE == ST_DUAL ? 1 : 2) void conv_st_k
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 float v;
-                if (DUAL) {
+                if constexpr (DUAL) {
                     v = (acc[0][rb][0][r] + bias_v[0]) * st_sigmoid(acc[0][rb][1][r] + bias_v[1]);
                 } else {
                     v = acc[0][rb][c][r] + bias_v[c];
@@ -605,45 +607,63 @@ __global__ __launch_bounds__(ST_THREADS, MODE == ST_DUAL ? 1 : 2) void conv_st_k
                 if (F2OK && f2) t2[(rb * 16 + 4 * kq + r) * LD2 + ch[c]] = v;      // A operand of the fused second convolution
                 if (d.dst_acc)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + accv[rb][r][c]), r_acc, o4, 0, 0);
-                if (d.stats && rowok[rb][r]) {
-                    const bool first = scount == 0.0f;
+                if constexpr (STATS) {   // statistics (selects, no branches: the shift is the lane's first valid value)
+                    const bool ok = rowok[rb][r], first = ok && scount == 0.0f;
                     const float g0 = eab_prelu(v, st_slope[0][c]);
-                    if (first) skk[0][c] = g0;
-                    const float e0 = g0 - skk[0][c];
+                    skk[0][c] = first ? g0 : skk[0][c];
+                    const float e0 = ok ? g0 - skk[0][c] : 0.0f;
                     ssum[0][c] += e0;
                     ssq[0][c] = fmaf(e0, e0, ssq[0][c]);
-                    if (two_sets) {
-                        const float g1 = eab_prelu(v, st_slope[1][c]);
-                        if (first) skk[1][c] = g1;
-                        const float e1 = g1 - skk[1][c];
-                        ssum[1][c] += e1;
-                        ssq[1][c] = fmaf(e1, e1, ssq[1][c]);
-                    }
+                    const float g1 = eab_prelu(v, st_slope[1][c]);
+                    skk[1][c] = first ? g1 : skk[1][c];
+                    const float e1 = ok ? g1 - skk[1][c] : 0.0f;
+                    ssum[1][c] += e1;
+                    ssq[1][c] = fmaf(e1, e1, ssq[1][c]);
                 }
             }
-            if (rowok[rb][r]) scount += 1.0f;
+            scount += rowok[rb][r] ? 1.0f : 0.0f;
         }
+    };
+    if (d.stats) epi_loop(std::true_type{});
+    else epi_loop(std::false_type{});
     if (d.stats) {
-        const float inv_n = scount > 0.0f ? 1.0f / scount : 0.0f;
+        const float inv_n = scount > 0.0f ? __builtin_amdgcn_rcpf(scount) : 0.0f;
         const size_t tbase = ((size_t)b * d.stat_tiles + d.stat_tile0 + stat_tile) * d.nsets;
+        // (n, mean, M2) of every (set, column block), then the two merge steps over the lanes kq that hold the same column:
+        // pairs (0,1) and (2,3), then (0,2); all exchanges of a step are issued together, every lane merges (only kq = 0 is
+        // kept) -- the same order everywhere
+        float sn[2][NC], smu[2][NC], sm2[2][NC];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            if (s >= d.nsets) break;
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                float n = scount;
-                float mean = fmaf(ssum[s][c], inv_n, skk[s][c]);
-                float m2 = fmaxf(ssq[s][c] - ssum[s][c] * ssum[s][c] * inv_n, 0.0f);
-                // kq pairs (0,1) and (2,3), then (0,2): the lower lane merges, in this order everywhere
-                float no = __shfl_xor(n, 16), mo = __shfl_xor(mean, 16), qo = __shfl_xor(m2, 16);
-                if ((kq & 1) == 0) st_merge(n, mean, m2, no, mo, qo);
-                no = __shfl_xor(n, 32);
-                mo = __shfl_xor(mean, 32);
-                qo = __shfl_xor(m2, 32);
-                if (kq == 0) {
-                    st_merge(n, mean, m2, no, mo, qo);
-                    *reinterpret_cast<f32x4*>(&d.stats[((tbase + s) * Cout + ch[c]) * 4]) = f32x4{n, mean, m2, 0.0f};
+                sn[s][c] = scount;
+                smu[s][c] = fmaf(ssum[s][c], inv_n, skk[s][c]);
+                sm2[s][c] = fmaxf(ssq[s][c] - ssum[s][c] * ssum[s][c] * inv_n, 0.0f);
+            }
+#pragma unroll
+        for (int step = 16; step <= 32; step <<= 1) {
+            float on[2][NC], omu[2][NC], om2[2][NC];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    on[s][c] = __shfl_xor(sn[s][c], step);
+                    omu[s][c] = __shfl_xor(smu[s][c], step);
+                    om2[s][c] = __shfl_xor(sm2[s][c], step);
                 }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) st_merge(sn[s][c], smu[s][c], sm2[s][c], on[s][c], omu[s][c], om2[s][c]);
+        }
+        if (kq == 0) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (s >= d.nsets) break;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    *reinterpret_cast<f32x4*>(&d.stats[((tbase + s) * Cout + ch[c]) * 4]) = f32x4{sn[s][c], smu[s][c], sm2[s][c], 0.0f};
             }
         }
     }

@@ -3,13 +3,13 @@
 //   esti.permute(0,3,2,1) -> view_as_complex -> torch.istft(n_fft=320, hop=160, win=320, hann)
 // i.e. (torch.istft defaults: center, onesided, not normalized, length=None)
 //   frame_t = irfft(X[:, t]) * w;   y = overlap_add(frame) / overlap_add(w^2);   trim n_fft/2 per side.
-// Implemented for hop = n_fft/2 (the reference's 320/160): after the centre trim EVERY output sample
-// is covered by exactly two frames, so there is no scatter and no envelope buffer --
-//   y[hop k + n] = (w[n+hop] x_k[n+hop] + w[n] x_{k+1}[n]) / (w[n+hop]^2 + w[n]^2),  k < T-1, n < hop.
+// Any hop that divides n_fft with R = n_fft/hop <= 8 frames per sample (the reference: 320/160, R = 2): a hop-long segment of
+// the output is covered by R consecutive frames, so there is no scatter and no envelope buffer --
+//   y[p] = sum_r w[r hop + n] x_{s-r}[r hop + n] / sum_r w[r hop + n]^2,   p = s hop + n, frames outside [0, T) skipped.
 //
 // One workgroup inverts FFT_SIGS consecutive frames of one utterance in LDS and emits the
-// FFT_SIGS-1 segments between them (the next workgroup re-inverts the shared frame: 1/7 extra
-// reads, no inter-workgroup dependency).  Real inverse FFT by the even/odd split: with
+// FFT_SIGS-(R-1) segments they cover completely (the next workgroup re-inverts the R-1 shared frames:
+// no inter-workgroup dependency).  Real inverse FFT by the even/odd split: with
 // E = (X[k] + conj X[N/2-k])/2 and O = (X[k] - conj X[N/2-k])/2 * e^{+2 pi i k/N},
 // z = IDFT_{N/2}(E + iO) holds x[2n] + i x[2n+1]; the inverse transform runs as
 // conj(FFT(conj .)) on the forward Stockham passes of fft_lds.h.  As in a C2R transform the
@@ -24,9 +24,10 @@
 
 __global__ __launch_bounds__(ISTFT_THREADS) void istft_kernel(const float* __restrict__ spec, const float* __restrict__ window,
                                                               const float* __restrict__ twiddle, float* __restrict__ wav,
-                                                              int T, int n_fft, int chunks, FftPlan plan) {
+                                                              int T, int n_fft, int hop, int chunks, FftPlan plan) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int NH = n_fft / 2, F = NH + 1;
+    const int R = n_fft / hop;                                    // frames that cover one output sample (2 for the reference)
     float2* tw = reinterpret_cast<float2*>(smem);                 // [n_fft] exp(-2 pi i j / n_fft)
     float2* buf0 = tw + n_fft;                                    // [FFT_SIGS][NH]
     float2* buf1 = buf0 + FFT_SIGS * NH;
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(ISTFT_THREADS) void istft_kernel(const float* __res
     float* xs = win + n_fft;                                      // [FFT_SIGS][2][F] staged spectrum rows
     const int tid = threadIdx.x;
     const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
-    const int t0 = chunk * (FFT_SIGS - 1);
+    const int t0 = chunk * (FFT_SIGS - (R - 1));                  // consecutive workgroups share R-1 frames
 
     for (int k = tid; k < n_fft; k += ISTFT_THREADS) {
         const float2 cs = reinterpret_cast<const float2*>(twiddle)[k];     // (cos, sin)(+theta)
@@ -67,31 +68,47 @@ __global__ __launch_bounds__(ISTFT_THREADS) void istft_kernel(const float* __res
     // x_c[2j] = Re y_c[j] / NH,  x_c[2j+1] = -Im y_c[j] / NH
     const float inv = 1.0f / (float)NH;
     const float* yf = reinterpret_cast<const float*>(y);
-    for (int e = tid; e < (FFT_SIGS - 1) * NH; e += ISTFT_THREADS) {
-        const int c = e / NH, n = e - c * NH;
-        const int k = t0 + c;
-        if (k + 1 >= T) break;                                     // e grows with c: nothing further is live
-        const int p0 = n + NH;                                     // sample of frame k; float index = p (re/im interleave)
-        float a0 = yf[c * n_fft + p0], a1 = yf[(c + 1) * n_fft + n];
-        if (p0 & 1) a0 = -a0;
-        if (n & 1) a1 = -a1;
-        const float w0 = win[p0], w1 = win[n];
-        wav[(size_t)b * NH * (T - 1) + (size_t)k * NH + n] = (w0 * (a0 * inv) + w1 * (a1 * inv)) / (w0 * w0 + w1 * w1);
+    // Overlap-add over the R frames that cover a sample, divided by the squared-window envelope of the frames that exist
+    // (torch.istft), then the centre trim: segment s = padded positions [s hop, (s+1) hop) is covered by frames s-R+1 .. s.
+    // This workgroup holds frames t0 .. t0+7 and emits the segments whose frames it holds completely (the first one: from 0).
+    const int s_lo = chunk == 0 ? 0 : t0 + R - 1;
+    const int out_len = hop * (T - 1);
+    for (int e = tid; e < (t0 + FFT_SIGS - s_lo) * hop; e += ISTFT_THREADS) {
+        const int sg = e / hop, n = e - sg * hop;
+        const int sI = s_lo + sg;
+        const int j = sI * hop + n - NH;                           // output sample (centre trim of n_fft/2)
+        if (j < 0 || j >= out_len) continue;
+        float acc = 0.0f, env = 0.0f;
+        for (int r = 0; r < R; ++r) {
+            const int t = sI - r;
+            if (t < 0 || t >= T) continue;
+            const int idx = r * hop + n;                           // sample of frame t; float index = idx (re/im interleave)
+            float a = yf[(t - t0) * n_fft + idx];
+            if (idx & 1) a = -a;
+            const float w = win[idx];
+            acc = fmaf(w, a * inv, acc);
+            env = fmaf(w, w, env);
+        }
+        wav[(size_t)b * out_len + j] = acc / env;
     }
 }
 
 extern "C" int eab_istft_f32(const float* spec, const float* window, const float* twiddle, float* wav, int B, int T,
                              int n_fft, int hop, eab_stream_t stream) {
     EAB_CHECK_ARG(spec && window && twiddle && wav);
-    EAB_CHECK_ARG(B > 0 && T >= 2);
+    EAB_CHECK_ARG(B > 0 && T >= 2 && hop > 0);
     EAB_CHECK_ARG(n_fft >= 4 && n_fft <= ISTFT_MAX_NFFT && (n_fft % 2) == 0);
-    if (hop * 2 != n_fft) return EAB_EUNSUPPORTED;                  // the two-frame closed form needs hop = n_fft/2
+    // hop must divide n_fft and at most FFT_SIGS frames may cover a sample (R = n_fft / hop <= 8: 87.5 % overlap)
+    if (n_fft % hop != 0 || n_fft / hop > FFT_SIGS) return EAB_EUNSUPPORTED;
     FftPlan plan;
     if (!fft_plan(n_fft / 2, &plan)) return EAB_EUNSUPPORTED;
-    const int chunks = (T - 1 + FFT_SIGS - 2) / (FFT_SIGS - 1);
+    const int R = n_fft / hop, per = FFT_SIGS - (R - 1);
+    // segments [0, s_max) carry the trimmed output; the workgroup of chunk c ends at segment c*per + FFT_SIGS
+    const int s_max = (n_fft / 2 + hop * (T - 1) + hop - 1) / hop;
+    const int chunks = s_max <= FFT_SIGS ? 1 : 1 + (s_max - FFT_SIGS + per - 1) / per;
     EAB_CHECK_ARG((long long)B * chunks < (1ll << 31));
     const size_t sh = (size_t)(2 * n_fft + 2 * FFT_SIGS * n_fft + n_fft + FFT_SIGS * 2 * (n_fft / 2 + 1)) * sizeof(float);
     hipLaunchKernelGGL(istft_kernel, dim3(B * chunks), dim3(ISTFT_THREADS), sh, eab_stream(stream), spec, window, twiddle,
-                       wav, T, n_fft, chunks, plan);
+                       wav, T, n_fft, hop, chunks, plan);
     EAB_RETURN_LAUNCH_STATUS();
 }

@@ -1073,8 +1073,14 @@ def istft(esti_stft: torch.Tensor, fft_num: int, win_shift: int, window: torch.T
         raise _lib.EabError("istft needs a CUDA (ROCm) tensor; there is no CPU fallback by design.")
     if esti_stft.ndim != 4 or esti_stft.shape[1] != 2 or esti_stft.shape[3] != fft_num // 2 + 1:
         raise ValueError(f"expected (B,2,T,{fft_num // 2 + 1}), got {tuple(esti_stft.shape)}")
-    if window.numel() != fft_num or 2 * win_shift != fft_num:
-        raise NotImplementedError("the HIP back end implements win_size == fft_num == 2*win_shift (the reference's 320/160)")
+    if window.numel() > fft_num:
+        raise RuntimeError(f"window ({window.numel()} samples) must not exceed fft_num ({fft_num}), as in torch.istft")
+    if window.numel() < fft_num:                  # torch.istft(win_length < n_fft): zero-padded on both sides, centred
+        left = (fft_num - window.numel()) // 2
+        window = torch.nn.functional.pad(window, (left, fft_num - window.numel() - left))
+    if win_shift <= 0 or fft_num % win_shift != 0 or fft_num // win_shift > 8:
+        raise NotImplementedError("the HIP back end implements hops that divide fft_num with at most 8 overlapping frames "
+                                  "(fft_num / win_shift in 1..8; the reference's 320/160 is 2)")
     lib = _lib.load()
     B, _, T, _ = esti_stft.shape
     x = esti_stft.detach().to(torch.float32).contiguous()

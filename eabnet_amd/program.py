@@ -879,7 +879,7 @@ class Lowering:
             # small-tile kernel: 16- or 32-row tiles (2-4 x the workgroups of a 64-row launch, one memory round trip each)
             mt = None if bn else 64
             bm_in, bm_lr, bm_out = (self.pick_st_bm(1, cd, D, max_tiles=mt), self.pick_st_bm(1, 2 * cd, Kd, dual=True, max_tiles=mt),
-                                    self.pick_st_bm(1, D, cd))
+                                    self.pick_st_bm(1, D, cd, max_tiles=mt))     # (fused with the next in_conv: its tiles carry partials)
             # the branch pair keeps 160 registers of weights per wave, i.e. one workgroup per CU: 16-row tiles only while
             # they fit the chip in one round (measured at B = 16, T = 401: 416 tiles of 16 rows 22 us, 208 of 32 rows 16 us)
             if B * conv_tiles(T, 1, 16) > CUS and (bn or conv_tiles(T, 1, 32) <= 64):

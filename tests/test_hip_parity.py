@@ -102,8 +102,8 @@ def test_istft_full_size_vs_oracle_and_properties(dev):
     yc = eabnet_amd.istft(c.to(dev), 320, 160, win)
     changed = (yc != ya).any(0).nonzero().flatten()
     assert changed.min() >= 160 * 199 and changed.max() < 160 * 201
-    with pytest.raises(NotImplementedError):
-        eabnet_amd.istft(a.to(dev), 320, 80, win)
+    with pytest.raises(NotImplementedError):              # a hop that does not divide fft_num (other hops: see
+        eabnet_amd.istft(a.to(dev), 320, 100, win)        # test_istft_other_hops_and_windows_vs_torch)
 
 
 def test_filter_sum_vs_oracle_and_linearity(dev):
@@ -1593,3 +1593,19 @@ def test_prepare_data_is_done_with_a_pinned_source_when_it_returns(dev, stage):
             assert torch.equal(noisy, want_n) and torch.equal(tgt, want_t)
     finally:
         mdl._HostStager.always_stage = saved
+
+
+@pytest.mark.parametrize("n_fft,hop,win", [(320, 80, 320), (256, 64, 256), (512, 128, 400), (320, 40, 320), (320, 160, 200), (256, 256, 256)])
+def test_istft_other_hops_and_windows_vs_torch(dev, n_fft, hop, win):
+    """The back end for any hop that divides fft_num (up to 8 overlapping frames) and any win_length <= fft_num, against
+    torch.istft called as enhance.py:59-62 calls it (the reference only ever passes 320/160/320; test.py / enhance.py take
+    the three numbers from args).  Rectangular window for the hop == n_fft case (a Hann window has no valid envelope there)."""
+    import eabnet_amd
+    torch.manual_seed(n_fft + hop)
+    B, T, F = 2, 11, n_fft // 2 + 1
+    esti = torch.randn(B, 2, T, F)
+    window = torch.ones(win) if hop == n_fft else torch.hann_window(win)
+    want = torch.istft(torch.view_as_complex(esti.permute(0, 3, 2, 1).contiguous()), n_fft, hop, win, window)
+    got = eabnet_amd.istft(esti.to(dev), n_fft, hop, window)
+    assert got.shape == want.shape == (B, hop * (T - 1))
+    assert_close(got.cpu().numpy(), want.numpy(), 1e-5, f"istft {n_fft}/{hop}/{win}")
