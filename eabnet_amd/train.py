@@ -1099,20 +1099,27 @@ class _EaBNetTrainFn(torch.autograd.Function):
             bound.run("bwd", st)
         gflat = torch.empty(prog.n_params, dtype=torch.float32, device=bound.device)     # fresh per call: .grad may keep views of it
         bound.unpack_grads(gflat, st)
-        if ctx.sync_group is not None:
-            # data-parallel training: the whole gradient is ONE contiguous buffer, so the reference's DDP bucket
-            # all-reduce (train_distributed.py:198,228) is a single RCCL all-reduce of n_params floats -- the "one flat
-            # bucket" SURVEY §5 asks for, without per-parameter hooks or bucket copies
-            import torch.distributed as td
-            td.all_reduce(gflat, group=ctx.sync_group if ctx.sync_group is not True else None)
-            gflat.div_(td.get_world_size(ctx.sync_group if ctx.sync_group is not True else None))
-        # one split call + a view per parameter (the Python loop over ~500-800 parameters is on the step's critical path)
-        sizes = [int(np.prod(shp)) if len(shp) else 1 for shp in ctx.shapes]
-        grads = [g.view(shp) if dt == torch.float32 else g.view(shp).to(dt)
-                 for g, shp, dt in zip(gflat.split(sizes), ctx.shapes, ctx.dtypes)]
-        if not all(ctx.needs_input_grad[3:]):
-            grads = [g if need else None for g, need in zip(grads, ctx.needs_input_grad[3:])]
+        grads = finish_flat_gradient(gflat, ctx.sync_group, ctx.shapes, ctx.dtypes, ctx.needs_input_grad[3:])
         return (None, None, None, *grads)
+
+
+def finish_flat_gradient(gflat: torch.Tensor, sync_group, shapes, dtypes, needs) -> list:
+    """What a training autograd node does with the flat gradient its backward program produced: average it over the ranks
+    (ONE all-reduce of the contiguous buffer -- the reference's DDP bucket all-reduce, train_distributed.py:198,228, without
+    per-parameter hooks or bucket copies; sync_group None = no synchronisation, True = the default process group) and hand it
+    back as one view per parameter (None for parameters that need no gradient).  Device-agnostic: tests/test_dist_gloo.py runs
+    it on two gloo ranks."""
+    if sync_group is not None:
+        import torch.distributed as td
+        grp = sync_group if sync_group is not True else None
+        td.all_reduce(gflat, group=grp)
+        gflat.div_(td.get_world_size(grp))
+    # one split call + a view per parameter (a Python loop over ~500-800 parameters is on the step's critical path)
+    sizes = [int(np.prod(shp)) if len(shp) else 1 for shp in shapes]
+    grads = [g.view(shp) if dt == torch.float32 else g.view(shp).to(dt) for g, shp, dt in zip(gflat.split(sizes), shapes, dtypes)]
+    if not all(needs):
+        grads = [g if need else None for g, need in zip(grads, needs)]
+    return grads
 
 
 def forward_train(module, inpt: torch.Tensor) -> torch.Tensor:

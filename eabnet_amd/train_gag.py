@@ -236,17 +236,7 @@ class _GagTrainFn(torch.autograd.Function):
             bound.run("bwd", st)
         gflat = torch.empty(prog.n_params, dtype=torch.float32, device=bound.device)
         bound.unpack_grads(gflat, st)
-        sync = getattr(ctx.bound, "sync_group", None)
-        if sync is not None:
-            import torch.distributed as td
-            td.all_reduce(gflat, group=sync if sync is not True else None)
-            gflat.div_(td.get_world_size(sync if sync is not True else None))
-        # one split call + a view per parameter (the Python loop over ~500-800 parameters is on the step's critical path)
-        sizes = [int(np.prod(shp)) if len(shp) else 1 for shp in ctx.shapes]
-        grads = [g.view(shp) if dt == torch.float32 else g.view(shp).to(dt)
-                 for g, shp, dt in zip(gflat.split(sizes), ctx.shapes, ctx.dtypes)]
-        if not all(ctx.needs_input_grad[3:]):
-            grads = [g if need else None for g, need in zip(grads, ctx.needs_input_grad[3:])]
+        grads = tr.finish_flat_gradient(gflat, getattr(ctx.bound, "sync_group", None), ctx.shapes, ctx.dtypes, ctx.needs_input_grad[3:])
         return (None, None, None, *grads)
 
 

@@ -142,3 +142,59 @@ def test_self_launcher_two_ranks():
     assert out == {"world": 2, "local": 0, "per_rank": [10.0, 11.0], "max": 11.0, "master": "127.0.0.1"}
     r = subprocess.run([sys.executable, "-c", code, "fail"], capture_output=True, text=True, env=env, timeout=280)
     assert r.returncode == 3 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def _flat_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    assert dist.init("gloo")
+    from eabnet_amd.train import finish_flat_gradient
+    shapes = [(3, 2), (), (4,), (2, 1, 2)]
+    dtypes = [torch.float32, torch.float32, torch.float64, torch.float32]
+    needs = [True, True, True, False]                      # a frozen parameter gets None
+    n = sum(int(np.prod(s)) if s else 1 for s in shapes)
+    g = torch.arange(n, dtype=torch.float32) * (rank + 1) + 100.0 * rank     # known per-rank gradient
+    plain = finish_flat_gradient(g.clone(), None, shapes, dtypes, needs)     # no synchronisation: the rank's own values
+    synced = finish_flat_gradient(g.clone(), True, shapes, dtypes, needs)    # default group: the mean over the ranks
+    q.put((rank, [None if t is None else t.double().numpy() for t in plain],
+           [None if t is None else (t.double().numpy(), str(t.dtype)) for t in synced]))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_flat_gradient_allreduce_on_two_gloo_ranks():
+    """The post-processing of the training autograd nodes (eabnet_amd.train.finish_flat_gradient: one all-reduce of the flat
+    gradient, average, one view per parameter, None for frozen parameters) on two CPU ranks with known per-rank values."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flat_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=240)
+        res[r[0]] = r
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    shapes = [(3, 2), (), (4,), (2, 1, 2)]
+    n = 6 + 1 + 4 + 4
+    per_rank = [np.arange(n, dtype=np.float64) * (r + 1) + 100.0 * r for r in range(world)]
+    mean = sum(per_rank) / world
+    for r in range(world):
+        _, plain, synced = res[r]
+        off = 0
+        for k, shp in enumerate(shapes):
+            cnt = int(np.prod(shp)) if shp else 1
+            if k == 3:
+                assert plain[k] is None and synced[k] is None
+            else:
+                assert np.array_equal(plain[k].reshape(-1), per_rank[r][off:off + cnt]) and plain[k].shape == shp
+                val, dt = synced[k]
+                assert np.allclose(val.reshape(-1), mean[off:off + cnt], rtol=0, atol=1e-5) and val.shape == shp
+                assert dt == ("torch.float64" if k == 2 else "torch.float32")
+            off += cnt
+    assert all(np.array_equal(a[0], b[0]) for a, b in zip(res[0][2][:3], res[1][2][:3]))     # identical on both ranks

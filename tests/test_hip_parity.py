@@ -632,7 +632,7 @@ def test_config4_two_stage_ddp_bf16_training_step(dev):
     if dist.is_initialized():
         pytest.skip("a process group already exists in this process")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ["MASTER_PORT"] = str(_free_port())        # (a fixed port can collide on a shared box)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         args = _postnet_args(4, p=1, q=1, gagnet_p=1, gagnet_q=2, gagnet_dilas=[1, 2], freeze_eabnet=True)
@@ -698,7 +698,7 @@ def test_two_stage_training_step_with_flat_allreduce(dev):
     if dist.is_initialized():
         pytest.skip("a process group already exists in this process")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29535")
+    os.environ["MASTER_PORT"] = str(_free_port())        # (a fixed port can collide on a shared box)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         args = _postnet_args(4, p=1, q=1, gagnet_p=1, gagnet_q=2, gagnet_dilas=[1, 2])
@@ -729,6 +729,11 @@ def test_two_stage_training_step_with_flat_allreduce(dev):
         assert rel <= 1e-5, rel                      # (atomics order in the weight gradients)
     finally:
         dist.destroy_process_group()
+
+
+def _free_port() -> int:
+    from eabnet_amd import dist as ed
+    return ed.free_port()
 
 
 # ------------------------------------------------------------------ streaming (BASELINE config 5)
@@ -1457,7 +1462,7 @@ def test_config4_ddp_training_on_the_hip_programs(dev):
     if dist.is_initialized():
         pytest.skip("a process group already exists in this process")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29534")
+    os.environ["MASTER_PORT"] = str(_free_port())        # (a fixed port can collide on a shared box)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         x = torch.from_numpy(paramgen.make_spec_input(2, 24, 161, 4, 170)).to(dev)
