@@ -664,14 +664,37 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
         }
         }
     };
-    // (a second register set for a two-stage prefetch costs a wave of occupancy -- 195 vs 154
-    // registers -- and measured slower in both precisions)
+    // (a second register set for a two-stage prefetch costs the 128x128 tiles a wave of occupancy -- 195 vs 154
+    // registers -- and measured slower there in both precisions)
+    constexpr bool PF2 = MI * NI <= 2 && KU == 1 && MODE == CG_PLAIN;
+    if constexpr (PF2) {
+        // The 64-column unit convolutions (and the dgrads of the training programs): 16 MFMAs per stage are ~1,000 cycles
+        // against a gather round trip of 2,000+, so the loads of stage s+2 are issued before stage s is multiplied
+        // (two register sets, still four waves per SIMD).  Same stage order, same arithmetic.
+        Stage sb;
+        if (NS > 1) fetch(1, sb);
+        for (int s = 0; s < NS; s += 2) {
+            // even stage s: multiply LDS[0]; sb holds stage s+1 (in flight since the previous iteration); sa <- stage s+2
+            if (s + 2 < NS) fetch(s + 2, sa);
+            compute(0);
+            if (s + 1 < NS) stash(1, sb);
+            lds_barrier();
+            if (s + 1 < NS) {
+                // odd stage s+1: multiply LDS[1]; sa holds stage s+2; sb <- stage s+3
+                if (s + 3 < NS) fetch(s + 3, sb);
+                compute(1);
+                if (s + 2 < NS) stash(0, sa);
+                lds_barrier();
+            }
+        }
+    } else {
     for (int s = 0; s < NS; ++s) {
         const int cur = s & 1;
         if (s + 1 < NS) fetch(s + 1, sa);
         compute(cur);
         if (s + 1 < NS) stash(cur ^ 1, sa);
         lds_barrier();
+    }
     }
 
     }
