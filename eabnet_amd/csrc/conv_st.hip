@@ -32,6 +32,7 @@
 #define ST_XFC 128          // max channels of a source that carries a fused transform
 #define ST_PLAIN 0
 #define ST_DUAL 1           // EAB_EPI_DUALGATE: value / gate columns see the same source through two transforms
+#define ST_GLU 2            // EAB_EPI_GLU: value / gate columns of ONE convolution (GateConv2d / GateConvTranspose2d)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -102,13 +103,14 @@ __global__ __launch_bounds__(ST_THREADS, MODE == ST_DUAL ? 1 : 2) void conv_st_k
     // BF = EAB_PREC_BF16: tensors and weights stay fp32 in memory (the same fragment-order `w`); A is rounded to bf16 on
     // its way into LDS, B in registers, products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation
     constexpr bool DUAL = MODE == ST_DUAL;
+    constexpr bool GATED = MODE != ST_PLAIN;             // a wave owns value and gate of the same 16 channels (NCB = 2)
     constexpr int BM = 16 * RB;
     constexpr int NA = DUAL ? 2 : 1;
     // ALL of this wave's B operands are fetched up front and stay in registers (K/16 x NCB b128 loads in flight at once: one
     // L2 round trip, overlapped with the A burst).  These launches run one or two waves per SIMD, so registers are free;
     // U bounds the K extent a variant accepts (host check): 320 for N = 64 and 128 (a five-tap S-TCM branch), 64 for N = 256.
     constexpr int U = NCB <= 2 ? 20 : 4;
-    static_assert(!DUAL || NCB == 2, "dual gate: one value and one gate block per wave");
+    static_assert(!GATED || NCB == 2, "gated forms: one value and one gate block per wave");
     extern __shared__ __attribute__((aligned(16))) float st_lds[];
 
     const int tid = threadIdx.x;
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(ST_THREADS, MODE == ST_DUAL ? 1 : 2) void conv_st_k
     }
 
     // fused second convolution (eab_conv_desc.f2_*; N = 256 launches only): its 64 x 256 weights, 16 columns per wave
-    constexpr bool F2OK = NCB == 4 && !DUAL && !BF;
+    constexpr bool F2OK = NCB == 4 && !GATED && !BF;
     const bool f2 = F2OK && d.f2_w != nullptr;
     f32x4 bq2[F2OK ? 16 : 1];
     if (f2) {
@@ -460,13 +462,25 @@ __global__ __launch_bounds__(ST_THREADS, MODE == ST_DUAL ? 1 : 2) void conv_st_k
         }
     } else {
     const float* a_lane = sa + li * LD + 2 * kq;
+    // (K extents beyond U steps -- the gated convolutions of the decoder, up to 768 deep -- take further passes: the weights of
+    // the next U steps are fetched when a pass ends; single-pass launches never enter the reload)
+    constexpr bool MP = MODE == ST_GLU && !BF;
+    for (int mp = 0; mp < (MP ? M2 : 1); mp += U) {
+    if (MP && mp > 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m2 = mp + u < M2 ? mp + u : mp;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) bq[u][cb] = *reinterpret_cast<const f32x4*>(wb[cb] + (size_t)m2 * 256);
+        }
+    }
 #pragma unroll
     for (int ua = 0; ua < U; ua += UA) {
-        if (ua < M2) {                                   // workgroup-uniform
+        if (mp + ua < M2) {                              // workgroup-uniform
             f32x2 af[UA][2][NA][RB];
 #pragma unroll
             for (int sI = 0; sI < UA; ++sI) {
-                const int m2c = ua + sI < M2 ? ua + sI : M2 - 1;
+                const int m2c = mp + ua + sI < M2 ? mp + ua + sI : M2 - 1;
 #pragma unroll
                 for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
@@ -479,7 +493,7 @@ __global__ __launch_bounds__(ST_THREADS, MODE == ST_DUAL ? 1 : 2) void conv_st_k
 #pragma unroll
             for (int sI = 0; sI < UA; ++sI) {
                 const int u = ua + sI;
-                if (u < U && u < M2) {
+                if (u < U && mp + u < M2) {
 #pragma unroll
                     for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
@@ -495,6 +509,7 @@ __global__ __launch_bounds__(ST_THREADS, MODE == ST_DUAL ? 1 : 2) void conv_st_k
         }
     }
     }
+    }
     if (NACC == 2) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
@@ -504,13 +519,14 @@ __global__ __launch_bounds__(ST_THREADS, MODE == ST_DUAL ? 1 : 2) void conv_st_k
     stamp(4);
     // ---- epilogue -------------------------------------------------------------------------------------------------------------
     // lane holds, per (rb, cb): column (wave*NCB + cb)*16 + li (DUAL: channel wave*16 + li), rows rb*16 + 4*kq + r
-    constexpr int NC = DUAL ? 1 : NCB;                   // output-channel blocks held by this lane
+    constexpr int NC = GATED ? 1 : NCB;                  // output-channel blocks held by this lane
     const int Cout = d.Cout;
     int ch[NC];
     float bias_v[NCB];
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) bias_v[cb] = d.bias ? d.bias[(wave * NCB + cb) * 16 + li] : 0.0f;
-    if (DUAL) {
+    for (int cb = 0; cb < NCB; ++cb)      // gated: bias in the convolution's own order (value rows, then gate rows)
+        bias_v[cb] = d.bias ? d.bias[GATED ? cb * d.Cout + wave * 16 + li : (wave * NCB + cb) * 16 + li] : 0.0f;
+    if (GATED) {
         ch[0] = wave * 16 + li;
     } else {
 #pragma unroll
@@ -595,7 +611,7 @@ __global__ __launch_bounds__(ST_THREADS, MODE == ST_DUAL ? 1 : 2) void conv_st_k
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 float v;
-                if constexpr (DUAL) {
+                if constexpr (GATED) {
                     v = (acc[0][rb][0][r] + bias_v[0]) * st_sigmoid(acc[0][rb][1][r] + bias_v[1]);
                 } else {
                     v = acc[0][rb][c][r] + bias_v[c];
@@ -805,7 +821,8 @@ int eab_conv_st(const eab_conv_desc* d, hipStream_t s) {
     EAB_CHECK_ARG(d->precision == EAB_PREC_F32 || (d->Kpad % 32 == 0 && (d->ph1_No == 0 || d->ph1_Kpad % 32 == 0)));
     EAB_CHECK_ARG(d->bm == 16 || d->bm == 32 || d->bm == 64);
     EAB_CHECK_ARG((d->C0 == 64 || d->C0 == 128 || d->C0 == 256) && (d->C1 == 0 || d->C1 == 64 || d->C1 == 128 || d->C1 == 256));
-    EAB_CHECK_ARG(d->epi == EAB_EPI_LINEAR || d->epi == EAB_EPI_RELU || d->epi == EAB_EPI_ADD || d->epi == EAB_EPI_DUALGATE);
+    EAB_CHECK_ARG(d->epi == EAB_EPI_LINEAR || d->epi == EAB_EPI_RELU || d->epi == EAB_EPI_ADD || d->epi == EAB_EPI_DUALGATE ||
+                  d->epi == EAB_EPI_GLU);
     EAB_CHECK_ARG(d->fz_counter == nullptr);          // (glu_dump: diagnostic stamp buffer or NULL)
     const bool dual = d->epi == EAB_EPI_DUALGATE;
     if (d->ph1_No > 0) {                                 // second output-column phase of a transposed convolution
@@ -829,12 +846,17 @@ int eab_conv_st(const eab_conv_desc* d, hipStream_t s) {
     const int xf = has_xf ? d->xf_mode : EAB_XF_NONE;
     if (xf != EAB_XF_NONE) EAB_CHECK_ARG(d->C0 <= ST_XFC && d->C1 <= ST_XFC);
     if (d->fin_stats) EAB_CHECK_ARG(d->fin_nsets * d->C0 <= ST_THREADS);
-    // the whole K extent of a wave's weights is held in registers
-    if (d->Kpad > (d->N == 256 ? 64 : 320)) return EAB_EUNSUPPORTED;
+    // a wave's weights are held in registers: the whole K extent (bf16 form, N = 256) or passes of 320
+    const bool glu = d->epi == EAB_EPI_GLU;
+    if (d->Kpad > (d->N == 256 ? 64 : (glu && d->precision == EAB_PREC_F32) ? 1024 : 320)) return EAB_EUNSUPPORTED;
     if (d->N == 128 && d->bm == 64) return EAB_EUNSUPPORTED;
     if (dual) {
         if (d->N != 128 || xf != EAB_XF_PRELU_NORM) return EAB_EUNSUPPORTED;
         return st_pick_rb<2, ST_DUAL, EAB_XF_PRELU_NORM>(d, s);
+    }
+    if (glu) {                                           // gated convolution on materialised sources, exact fp32
+        if (d->N != 128 || xf != EAB_XF_NONE || d->precision != EAB_PREC_F32) return EAB_EUNSUPPORTED;
+        return st_pick_rb<2, ST_GLU, EAB_XF_NONE>(d, s);
     }
 #define ST_DISPATCH_XF(NCB_)                                                   \
     (xf == EAB_XF_NONE        ? st_pick_rb<NCB_, ST_PLAIN, EAB_XF_NONE>(d, s) \

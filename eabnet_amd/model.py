@@ -448,14 +448,18 @@ class EaBNet(_HipModule):
             # constructor branches, BatchNorm in train mode, CPU tensors and a differentiable INPUT still take the
             # PyTorch-ROCm operator path (autograd_path.py)
             from . import train
+            # (BatchNorm: the HIP programs implement train mode -- batch statistics; a differentiable eval-mode pass with the
+            # running statistics stays on the operator path)
+            bn_eval = self.norm_type == "BN" and not self.training
             if self.use_hip_training and inpt.is_cuda and not inpt.requires_grad and torch.is_grad_enabled() \
-                    and train.supported(self.cfg) and next(self.parameters()).is_cuda:
+                    and train.supported(self.cfg) and not bn_eval and next(self.parameters()).is_cuda:
                 self.training_backend = "hip"
                 return train.forward_train(self, inpt)
             from .autograd_path import forward_autograd
             self.training_backend = "operators"
             if self.use_hip_training and inpt.is_cuda:
                 _warn_operator_path(self, "input requires grad" if inpt.requires_grad else
+                                    "BatchNorm in eval mode under autograd" if bn_eval and train.supported(self.cfg) else
                                     f"topology outside train.supported(): {train.unsupported_reason(self.cfg)}")
             return forward_autograd(self, inpt)
         if not inpt.is_cuda:

@@ -39,6 +39,9 @@ GAG_LIN_LD = 192   # 161 linear outputs padded to three 64-column tiles
 PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 PREC_CODE = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16": PREC_BF16}
 KORDER_TAP, KORDER_CHUNK, KORDER_FRAG = 0, 1, 2
+# deepest gated launch sent to the small-tile kernel (csrc/conv_st.hip takes up to 1024, weights in passes of 320): the
+# 768-deep first phase of the last decoder measured slower there than on 128-row tiles (C1: 2.89 vs 2.75 ms per utterance)
+ST_GLU_KMAX = 512
 PATCH_MAX = 352    # CG_PMAX in csrc/conv_gemm.hip
 MAX_TAPS = 16
 EPS_IN = 1e-5      # nn.InstanceNorm*d default (reference EaBNet.py:684,686)
@@ -477,6 +480,8 @@ class Lowering:
         # small-tile kernel (csrc/conv_st.hip; exact fp32 or bf16 products) for the latency-bound launches: the S-TCN and the 64-column unit
         # convolutions with at most `st_maxno` output columns; EAB_ST=0 puts everything back on conv_gemm_kernel
         self.st = os.environ.get("EAB_ST", "1") != "0" and precision in ("f32", "bf16")
+        self.st_glu = os.environ.get("EAB_ST_GLU", "1") != "0"            # gated convolutions of latency-bound layers too
+        self.st_glu_tiles = int(os.environ.get("EAB_ST_GLU_TILES", str(2 * CUS)))
         self.st_maxno = int(os.environ.get("EAB_ST_MAXNO", "5"))
         self.fuse_out_in = os.environ.get("EAB_ST_FUSE", "1") != "0"      # out_conv of one S-TCM + in_conv of the next in one launch
         specs = self.spec_fn(cfg)
@@ -625,10 +630,13 @@ class Lowering:
         ph1kw = {}
         if st:
             assert self.precision in ("f32", "bf16") and N in (64, 128, 256) and bm in (16, 32, 64)
-            assert Kpad <= {64: 320, 128: 320, 256: 64}[N], "small-tile kernel: the K extent must fit the wave's registers"
-            assert epi in (EPI_LINEAR, EPI_RELU, EPI_ADD, EPI_DUALGATE)
+            glu_st = epi == EPI_GLU                       # exact fp32 only; weights in passes of 320, not all resident
+            assert Kpad <= (ST_GLU_KMAX if glu_st else {64: 320, 128: 320, 256: 64}[N]), \
+                "small-tile kernel: the K extent must fit the wave's registers"
+            assert epi in (EPI_LINEAR, EPI_RELU, EPI_ADD, EPI_DUALGATE, EPI_GLU)
+            assert not glu_st or (self.precision == "f32" and N == 128 and mode == XF_NONE and fin is None)
             korder = KORDER_FRAG
-            dual = epi == EPI_DUALGATE
+            dual = epi in (EPI_DUALGATE, EPI_GLU)         # a wave owns value and gate of the same 16 channels
 
             def frag(ref: Ref, K: int) -> Ref:
                 key = next(k for k, r in self.W.index.items() if r == ref)
@@ -710,18 +718,23 @@ class Lowering:
                                    xf1=xfs[1] if nsets == 2 else None, name=name))
         return xfs
 
-    def st_small(self, No: int) -> bool:
+    def st_small(self, No: int, glu: bool = False) -> bool:
         """Is a launch with `No` output columns per frame latency-bound?  Yes when 64-row tiles would give the chip fewer
         than two workgroups per CU (one utterance, a streaming chunk, the deepest U-Net levels of a batch) or when the
         layer has at most `st_maxno` columns; those go to the small-tile kernel."""
         # (T, not the streaming chunk: a streamed program must pick the kernel its offline twin of the same (B, T) picks --
         # the two kernels sum in different orders, and streamed frames are promised bit-identical to the offline pass)
         rows = self.T * No
+        if glu:      # deep-K gated launches: only where 64-row tiles leave CUs idle (measured: the wide-tile kernel wins above)
+            return self.B * ((rows + 63) // 64) < self.st_glu_tiles
         return No <= self.st_maxno or self.B * ((rows + 63) // 64) < 2 * CUS
 
     def st_ok(self, srcs: Sequence[Act], N: int, glu: bool) -> bool:
-        """the small-tile kernel's domain: exact fp32, plain 64/128/256-column launches, source channels 4 * 2^k"""
-        return (self.st and not glu and not self.cln and N in (64, 128, 256) and all(a.C in (64, 128, 256) for a in srcs)
+        """the small-tile kernel's domain: plain 64/128/256-column launches, source channels 4 * 2^k; gated (GLU) launches
+        in exact fp32 on materialised sources"""
+        if glu and not (self.st_glu and self.precision == "f32" and N == 128 and all(a.xf is None for a in srcs)):
+            return False
+        return (self.st and not self.cln and N in (64, 128, 256) and all(a.C in (64, 128, 256) for a in srcs)
                 and not any(a.raw or a.ref.arena == "in" for a in srcs)
                 and all(a.C <= 128 for a in srcs if a.xf is not None))
 
@@ -737,14 +750,16 @@ class Lowering:
             w = w[:, in_perm]
         Fin = srcs[0].F
         Fout = (Fin - kf) // 2 + 1
-        order = glu_row_order(N) if glu else np.arange(N)
         taps = [(a, c) for a in range(kt) for c in range(kf)]
+        st = (self.st_ok(srcs, N, glu) and kt * kf * ((Cin + 15) // 16) * 16 <= (ST_GLU_KMAX if glu else 256)
+              and self.st_small(Fout, glu))
+        # (small-tile kernel: rows stay in the convolution's own order, emit_conv packs them in fragment order)
+        order, tag = (glu_row_order(N), "packed") if glu and not st else (np.arange(N), "rows" if glu else "packed")
         wp = pack_taps(w.reshape(N, Cin, kt * kf)[order], [a * kf + c for a, c in taps])
-        wref = self.W.add(f"{wkey}.weight#packed", wp)
-        bref = self.W.add(f"{wkey}.bias#packed", self.P[f"{wkey}.bias"][order])
+        wref = self.W.add(f"{wkey}.weight#{tag}", wp)
+        bref = self.W.add(f"{wkey}.bias#{tag}", self.P[f"{wkey}.bias"][order])
         Cout = N // 2 if glu else N
         dst = self.alloc_act(Fout, Cout)
-        st = self.st_ok(srcs, N, glu) and wp.shape[1] <= 256 and self.st_small(Fout)
         bm = self.pick_st_bm(Fout, N, wp.shape[1]) if st else self.pick_bm(Fout)
         tiles = conv_tiles(self.T, Fout, bm)
         cln = self.cln and norm is not None
@@ -779,14 +794,15 @@ class Lowering:
         assert Cin == sum(s.C for s in srcs)
         Fin = srcs[0].F
         Fout = (Fin - 1) * 2 + kf
-        order = glu_row_order(N) if glu else np.arange(N)
-        wn = np.ascontiguousarray(w.transpose(1, 0, 2, 3)).reshape(N, Cin, kt * kf)[order]
-        bref = self.W.add(f"{wkey}.bias#packed", self.P[f"{wkey}.bias"][order])
-        Cout = N // 2 if glu else N
-        dst = self.alloc_act(Fout, Cout)
         No = [(Fout + 1) // 2, Fout // 2]
         upt = (Cin + 15) // 16
-        st = self.st_ok(srcs, N, glu) and len(range(0, kf, 2)) * kt * upt * 16 <= 256 and self.st_small(No[0])
+        st = (self.st_ok(srcs, N, glu) and len(range(0, kf, 2)) * kt * upt * 16 <= (ST_GLU_KMAX if glu else 256)
+              and self.st_small(No[0], glu))
+        order, tag = (glu_row_order(N), "packed") if glu and not st else (np.arange(N), "rows" if glu else "packed")
+        wn = np.ascontiguousarray(w.transpose(1, 0, 2, 3)).reshape(N, Cin, kt * kf)[order]
+        bref = self.W.add(f"{wkey}.bias#{tag}", self.P[f"{wkey}.bias"][order])
+        Cout = N // 2 if glu else N
+        dst = self.alloc_act(Fout, Cout)
         bm = self.pick_st_bm(No[0] + No[1], N, len(range(0, kf, 2)) * kt * upt * 16) if st else self.pick_bm(No[0])
         tiles = [conv_tiles(self.T, n, bm) for n in No]
         cln = self.cln
@@ -797,14 +813,14 @@ class Lowering:
         for ph in (0, 1):
             taps = [(a, c) for a in range(kt) for c in range(ph, kf, 2)]
             wp = pack_taps(wn, [a * kf + c for a, c in taps])
-            wref = self.W.add(f"{wkey}.weight#packed.ph{ph}", wp)
+            wref = self.W.add(f"{wkey}.weight#{tag}.ph{ph}", wp)
             phases.append(dict(w=wref, Kpad=wp.shape[1], No=No[ph], ophase=ph, dt=[-a for a, _ in taps],
                                ioff=[-(c - ph) // 2 for _, c in taps]))
         if st:
             # small-tile kernel: both output-column phases in ONE launch (tiles of phase 0, then of phase 1, per utterance)
             p0, p1 = phases
             phase_ops.append(self.emit_conv(name, srcs, p0["w"], bref, N, p0["Kpad"], Fout, No[0], 2, 0, 1, p0["dt"], p0["ioff"],
-                                            EPI_LINEAR, dst, stats, 1 if stats else 0, (None, None),
+                                            EPI_GLU if glu else EPI_LINEAR, dst, stats, 1 if stats else 0, (None, None),
                                             sum(tiles) if stats else 0, 0, bm, st=True, ph1=p1))
         else:
             for ph, q in enumerate(phases):

@@ -49,7 +49,7 @@ TRAIN_BOUND_CACHE = 3   # bound training programs kept per module (LRU over (B, 
 
 def supported(cfg: NetConfig) -> bool:
     return (cfg.is_u2 and cfg.bf_type in ("lstm", "cnn") and cfg.topo_type == "mimo" and cfg.intra_connect in ("cat", "add")
-            and cfg.norm_type == "IN" and 2 * cfg.M <= MLP_LD)
+            and cfg.norm_type in ("IN", "BN") and 2 * cfg.M <= MLP_LD)
 
 
 def unsupported_reason(cfg: NetConfig) -> str:
@@ -63,7 +63,7 @@ def unsupported_reason(cfg: NetConfig) -> str:
         why.append(f"topo_type={cfg.topo_type!r}")
     if cfg.intra_connect not in ("cat", "add"):
         why.append(f"intra_connect={cfg.intra_connect!r}")
-    if cfg.norm_type != "IN":
+    if cfg.norm_type not in ("IN", "BN"):
         why.append(f"norm_type={cfg.norm_type!r}")
     if 2 * cfg.M > MLP_LD:
         why.append(f"M={cfg.M} > {MLP_LD // 2}")
@@ -176,7 +176,15 @@ class TrainLowering:
             raise NotImplementedError("the HIP training path covers the default topology with InstanceNorm")
         cfg.check_supported()
         self.cfg, self.B, self.T, self.F = cfg, B, T, F
-        self.specs = {k: s for k, s in self.spec_fn(cfg).items() if s.kind != "bn_count"}
+        # (the BatchNorm buffers are not parameters of the programs: train mode normalises with batch statistics)
+        self.specs = {k: s for k, s in self.spec_fn(cfg).items() if s.kind not in ("bn_count", "bn_mean", "bn_var")}
+        # BatchNorm in train mode (NormSwitch BN branch, EaBNet.py:677-681; nn.BatchNorm{1,2}d): statistics per channel over
+        # the whole batch.  Every tensor is [B][positions][C], channels-last and contiguous, so the batch is ONE virtual
+        # utterance of B * positions rows: the InstanceNorm kernels (statistics merge, apply, both backward launches) run
+        # unchanged with (B, P) -> (1, B * P).  bn_layers: (norm key, offset of its (mean, rstd) table, C, samples per channel)
+        self.bn = getattr(cfg, "norm_type", "IN") == "BN"
+        self.nB, self.nP = (1, B * T) if self.bn else (B, T)
+        self.bn_layers: List[Tuple[str, int, int, int]] = []
         self.poff: Dict[str, int] = {}
         n = 0
         for k, s in self.specs.items():
@@ -355,9 +363,9 @@ class TrainLowering:
     def norm_act(self, name: str, raw: TVar, norm: str, act: str, mode: int, xf: Ref, mr: Ref, add: Optional[TVar] = None) -> TVar:
         """a = f(raw) [+ add]; records the backward (norm/PReLU gradients, dparams)"""
         out = self.act(raw.F, raw.C)
-        P = self.T * raw.F
+        P = self.nP * raw.F
         gam, bet, slp = self.vec(f"{norm}.norm.weight"), self.vec(f"{norm}.norm.bias"), self.vec(f"{act}.weight")
-        self.fwd.append(GenOp(OP_TR_NORM_ACT, [raw.ref, xf, slp, add.ref if add else None, out.ref], [self.B, P, raw.C, mode],
+        self.fwd.append(GenOp(OP_TR_NORM_ACT, [raw.ref, xf, slp, add.ref if add else None, out.ref], [self.nB, P, raw.C, mode],
                               name=name))
 
         self.tape.append(self._norm_back(name, raw, out, add, norm, act, mode, mr, gam, bet, slp, P))
@@ -373,19 +381,28 @@ class TrainLowering:
             # reduction scratch in the gradient arena: that arena is zero-filled once before every backward run, so the
             # kernel needs no zero-fill launch of its own (EAB_NB_SUMS_ZEROED)
             sums = Ref("g", self.g_size)
-            self.g_size += self.B * raw.C * 4 + ((-self.B * raw.C * 4) % ALIGN)
+            self.g_size += self.nB * raw.C * 4 + ((-self.nB * raw.C * 4) % ALIGN)
             self.bwd.append(GenOp(OP_NORM_BWD, [d, raw.ref, mr, gam, bet, slp, sums, aux, dst, self.gvec(f"{norm}.norm.weight"),
                                                 self.gvec(f"{norm}.norm.bias"), self.gvec(f"{act}.weight")],
-                                  [self.B, P, raw.C, mode | NB_SUMS_ZEROED], name=name + ".bwd"))
+                                  [self.nB, P, raw.C, mode | NB_SUMS_ZEROED], name=name + ".bwd"))
         return back
 
     def finalize(self, name: str, stats: Ref, C: int, tiles: int, count: int, norm: str) -> Tuple[Ref, Ref]:
-        xf, mr = self.alloc(self.B * C * 2), self.alloc(self.B * C * 2)
-        op = prg.FinalizeOp(stats=stats, B=self.B, C=C, nsets=1, stat_tiles=tiles, count=count, eps=EPS_IN,
+        xf, mr = self.alloc(self.nB * C * 2), self.alloc(self.nB * C * 2)
+        # BatchNorm in train mode: the partials are [b][tile][C][4] back to back, so the batch statistics are the same
+        # merge over B * tiles partials of ONE virtual utterance (see __init__)
+        bt = self.B // self.nB
+        op = prg.FinalizeOp(stats=stats, B=self.nB, C=C, nsets=1, stat_tiles=tiles * bt, count=count * bt, eps=EPS_IN,
                             gamma0=self.vec(f"{norm}.norm.weight"), beta0=self.vec(f"{norm}.norm.bias"), xf0=xf, name=name)
         op.mr0 = mr
         self.fwd.append(op)
+        self.note_bn(norm, mr, 0, C, count * bt)
         return xf, mr
+
+    def note_bn(self, norm: str, mr: Ref, c0: int, C: int, n: int) -> None:
+        """BatchNorm: where this layer's batch (mean, rstd) table lies, for the update of its running buffers"""
+        if self.bn:
+            self.bn_layers.append((norm, mr.off + 2 * c0, C, n))
 
     # ---- 2-D units -----------------------------------------------------------------------------------------
     def conv2d_fwd(self, name: str, srcs: Sequence[TVar], wkey: str, glu: bool, norm: str, act: str,
@@ -564,11 +581,12 @@ class TrainLowering:
     def in1d(self, name: str, raw: TVar, norm: str, act: str) -> TVar:
         """prelu -> InstanceNorm1d (S-TCM order, EaBNet.py:545-547) as ONE launch: statistics, (xf, mr) and the normalised
         tensor (eab_train_in1d_f32); backward = the norm backward of the PRELU_NORM form"""
-        xf, mr = self.alloc(self.B * raw.C * 2), self.alloc(self.B * raw.C * 2)
+        xf, mr = self.alloc(self.nB * raw.C * 2), self.alloc(self.nB * raw.C * 2)
         out = self.act(raw.F, raw.C)
-        P = self.T * raw.F
+        P = self.nP * raw.F
         gam, bet, slp = self.vec(f"{norm}.norm.weight"), self.vec(f"{norm}.norm.bias"), self.vec(f"{act}.weight")
-        self.fwd.append(GenOp(OP_IN_STATS, [raw.ref, slp, gam, bet, xf, mr, out.ref], [self.B, P, raw.C], [EPS_IN], name=name))
+        self.fwd.append(GenOp(OP_IN_STATS, [raw.ref, slp, gam, bet, xf, mr, out.ref], [self.nB, P, raw.C], [EPS_IN], name=name))
+        self.note_bn(norm, mr, 0, raw.C, P)
         self.tape.append(self._norm_back(name, raw, out, None, norm, act, XF_PRELU_NORM, mr, gam, bet, slp, P))
         return out
 
@@ -577,25 +595,27 @@ class TrainLowering:
         contiguous tensors, one two-launch backward that sums both input gradients"""
         assert len(norms) == 2 and len(acts) == 2
         C = raw.C * 2
-        P = self.T * raw.F
-        n = self.B * P * raw.C
-        xf, mr = self.alloc(self.B * C * 2), self.alloc(self.B * C * 2)
+        P = self.nP * raw.F
+        n = self.nB * P * raw.C
+        xf, mr = self.alloc(self.nB * C * 2), self.alloc(self.nB * C * 2)
+        for v, k in enumerate(norms):
+            self.note_bn(k, mr, v * raw.C, raw.C, P)
         base = self.alloc(2 * n)                                            # view v at base + v * n
         outs = [TVar(Ref("a", base.off + v * n), raw.F, raw.C) for v in range(2)]
         img_g = np.concatenate([self.idx(f"{k}.norm.weight") for k in norms])
         img_b = np.concatenate([self.idx(f"{k}.norm.bias") for k in norms])
         img_s = np.concatenate([self.idx(f"{k}.weight") for k in acts])
         gam, bet, slp = self.wadd(name + ".gamma", img_g), self.wadd(name + ".beta", img_b), self.wadd(name + ".slope", img_s)
-        self.fwd.append(GenOp(OP_IN_STATS, [raw.ref, slp, gam, bet, xf, mr, base], [self.B, P, C, raw.C], [EPS_IN], name=name))
+        self.fwd.append(GenOp(OP_IN_STATS, [raw.ref, slp, gam, bet, xf, mr, base], [self.nB, P, C, raw.C], [EPS_IN], name=name))
 
         def back():
             d0, d1 = self.grad_of(outs[0]), self.grad_of(outs[1])
             dst, aux = self.grad_target(raw)
             sums = Ref("g", self.g_size)                                     # zero-filled with the gradient arena
-            self.g_size += self.B * C * 4 + ((-self.B * C * 4) % ALIGN)
+            self.g_size += self.nB * C * 4 + ((-self.nB * C * 4) % ALIGN)
             # (p[4], beta in the one-view form, carries the second view's gradient here: the PRELU_NORM backward never reads beta)
             self.bwd.append(GenOp(OP_NORM_BWD, [d0, raw.ref, mr, gam, d1, slp, sums, aux, dst, self.gadd([img_g]), self.gadd([img_b]),
-                                                self.gadd([img_s])], [self.B, P, C, XF_PRELU_NORM | NB_SUMS_ZEROED, raw.C],
+                                                self.gadd([img_s])], [self.nB, P, C, XF_PRELU_NORM | NB_SUMS_ZEROED, raw.C],
                                   name=name + ".bwd"))
         self.tape.append(back)
         return outs
@@ -815,7 +835,8 @@ class TrainLowering:
                             n_params=self.n_params, keys=list(self.specs), shapes=[tuple(s.shape) for s in self.specs.values()],
                             flops_fwd=self.flops_fwd, flops_bwd=self.flops_bwd,
                             grad_taps={k: (v.slot.ref, v.F, v.C) for k, v in self.gtaps.items() if v.slot.ref is not None},
-                            lanes={"fwd": [o.lane for o in self.fwd], "bwd": [o.lane for o in self.bwd]}, sync=self.sync)
+                            lanes={"fwd": [o.lane for o in self.fwd], "bwd": [o.lane for o in self.bwd]}, sync=self.sync,
+                            bn_layers=list(self.bn_layers))
 
 
 @dataclass
@@ -842,6 +863,8 @@ class TrainProgram:
     has_in2: bool = False                    # a second input arena 'in2' (the post-filter's previous estimate)
     lanes: Dict[str, list] = field(default_factory=dict)          # per program: lane of every op (0 = the caller's stream)
     sync: Dict[str, dict] = field(default_factory=dict)           # per program: op index -> [("fork" | "join", lanes)]
+    # BatchNorm (train mode): (norm key, offset of the layer's batch (mean, rstd) table in the activation arena, C, samples)
+    bn_layers: List[tuple] = field(default_factory=list)
 
 
 def lower_train(cfg: NetConfig, B: int, T: int, F: int = 161, precision: str = "f32") -> TrainProgram:
@@ -1044,6 +1067,30 @@ class TrainBound:
         ops = C.cast(C.byref(arr, first * C.sizeof(_lib.Op)), C.POINTER(_lib.Op))
         _lib.check(_lib.load().eab_run_program(ops, n, C.c_void_p(stream)), f"eab_run_program({which})")
 
+    def update_bn_buffers(self, module, momentum: float = 0.1) -> None:
+        """nn.BatchNorm's train-mode side effect (NormSwitch BN branch, EaBNet.py:677-681): running_mean / running_var move
+        by `momentum` towards the batch mean / UNBIASED batch variance, num_batches_tracked counts the step.  The batch
+        statistics are read back from the (mean, rstd) tables the forward program just wrote -- a handful of torch
+        foreach launches on the caller's stream for all norms of the network."""
+        L = self.prog.bn_layers
+        if not L:
+            return
+        if getattr(self, "_bn_idx", None) is None:
+            idx = np.concatenate([off + 2 * np.arange(C, dtype=np.int64) for _, off, C, _ in L])
+            unb = np.concatenate([np.full(C, n / max(n - 1, 1), np.float32) for _, _, C, n in L])
+            self._bn_idx = torch.from_numpy(idx).to(self.acts.device)
+            self._bn_unb = torch.from_numpy(unb).to(self.acts.device)
+            self._bn_split = [C for _, _, C, _ in L]
+        with torch.no_grad():
+            mean = self.acts[self._bn_idx]
+            rstd = self.acts[self._bn_idx + 1]
+            var = (1.0 / (rstd * rstd) - EPS_IN).clamp_min_(0.0) * self._bn_unb
+            rm = [module.get_buffer(f"{k}.norm.running_mean") for k, *_ in L]
+            rv = [module.get_buffer(f"{k}.norm.running_var") for k, *_ in L]
+            torch._foreach_lerp_(rm, list(mean.split(self._bn_split)), momentum)
+            torch._foreach_lerp_(rv, list(var.split(self._bn_split)), momentum)
+            torch._foreach_add_([module.get_buffer(f"{k}.norm.num_batches_tracked") for k, *_ in L], 1)
+
     def pack(self, flat: torch.Tensor, stream: int) -> None:
         _lib.check(_lib.load().eab_gather_f32(flat.data_ptr(), self.ia.data_ptr(), self.ib.data_ptr() if self.ib is not None else None,
                                               self.w.data_ptr(), self.prog.w_floats, C.c_void_p(stream)), "eab_gather_f32")
@@ -1147,6 +1194,7 @@ def forward_train(module, inpt: torch.Tensor) -> torch.Tensor:
     sync = module.__dict__.get("grad_allreduce", None)          # None | True (default group) | a process group
     with torch.cuda.device(x.device):
         out = _EaBNetTrainFn.apply(bound, sync, x, *params)
+        bound.update_bn_buffers(module)
     return out.to(inpt.dtype)
 
 

@@ -144,6 +144,16 @@ def _norm(x, P: Params, norm_prefix: str, bn=False):
     if isinstance(bn, str) and bn == "cLN":
         return cumulative_layer_norm(x, P[f"{norm_prefix}.norm.gain"], P[f"{norm_prefix}.norm.bias"])
     w, b = P[f"{norm_prefix}.norm.weight"], P[f"{norm_prefix}.norm.bias"]
+    if isinstance(bn, str) and bn == "train":
+        # nn.BatchNorm{1,2}d in train mode (the reference trains with module.train(), train_distributed.py:212): batch
+        # statistics, and the momentum-0.1 update of the running buffers (unbiased variance).  The updated buffers are
+        # left in P["__bn_updates__"] (when the caller provides that dict) -- P's own entries are not modified.
+        rm = P[f"{norm_prefix}.norm.running_mean"].detach().clone()
+        rv = P[f"{norm_prefix}.norm.running_var"].detach().clone()
+        y = F.batch_norm(x, rm, rv, w, b, training=True, momentum=0.1, eps=EPS_IN)
+        if "__bn_updates__" in P:
+            P["__bn_updates__"][norm_prefix] = (rm, rv)
+        return y
     if bn:
         return F.batch_norm(x, P[f"{norm_prefix}.norm.running_mean"], P[f"{norm_prefix}.norm.running_var"], w, b,
                             training=False, eps=EPS_IN)
@@ -286,14 +296,15 @@ def unet_decoder(x, skips, P: Params, bn: bool):
 def eabnet_forward(P: Params, inpt: torch.Tensor, p: int = 6, q: int = 3, kd: int = 5,
                    fast_lstm: bool = False, taps: Optional[dict] = None, *, is_causal: bool = True,
                    is_u2: bool = True, bf_type: str = "lstm", topo_type: str = "mimo",
-                   intra_connect: str = "cat", norm_type: str = "IN") -> torch.Tensor:
+                   intra_connect: str = "cat", norm_type: str = "IN", bn_train: bool = False) -> torch.Tensor:
     """EaBNet.forward (EaBNet.py:88-125).
-    inpt (B,T,F,M,2) [or (B,T,F,2)] -> (B,2,T,F)  [(B,2,T) for topo_type="miso", as the reference]."""
+    inpt (B,T,F,M,2) [or (B,T,F,2)] -> (B,2,T,F)  [(B,2,T) for topo_type="miso", as the reference].
+    bn_train: norm_type="BN" with the module in train mode (batch statistics; see _norm)."""
     if inpt.ndim == 4:
         inpt = inpt.unsqueeze(-2)
     B, T, Fq, M, _ = inpt.shape
     assert norm_type in ("IN", "BN", "cLN") and intra_connect in ("cat", "add")
-    bn, add = {"BN": True, "IN": False, "cLN": "cLN"}[norm_type], intra_connect == "add"
+    bn, add = {"BN": "train" if bn_train else True, "IN": False, "cLN": "cLN"}[norm_type], intra_connect == "add"
     # (B,T,F,M,2) -> (B,2M,T,F), channel = ri*M + m   (EaBNet.py:96-97)
     x = inpt.transpose(-2, -1).contiguous().view(B, T, Fq, 2 * M).permute(0, 3, 1, 2)
 

@@ -86,15 +86,20 @@ class Emulator:
             # small-tile kernel: weights in MFMA-fragment order, optionally two output-column phases in one launch.
             # Interpreted as one or two launches of the tap-ordered form (what the fragment layout encodes).
             import dataclasses
-            dual = op.epi == prg.EPI_DUALGATE
+            dual = op.epi in (prg.EPI_DUALGATE, prg.EPI_GLU)
             order = prg.glu_row_order(op.N) if dual else np.arange(op.N)
+            bias = op.bias
+            if op.epi == prg.EPI_GLU and op.bias is not None:
+                # the small-tile kernel reads the bias in the convolution's own row order; the tap-ordered form interleaves
+                self.arena["tmpb"] = self.v(op.bias, (op.N,))[order].copy()
+                bias = prg.Ref("tmpb", 0)
             passes = [(op.w, op.Kpad, op.No, op.ophase, op.dt, op.ioff, op.stat_tile0)]
             if op.ph1_No > 0:
                 passes.append((op.ph1_w, op.ph1_Kpad, op.ph1_No, op.ph1_ophase, op.ph1_dt, op.ph1_ioff,
                                op.stat_tile0 + prg.conv_tiles(op.T, op.No, op.bm)))
             for wref, K, No_, oph, dt, ioff, st0 in passes:
                 self.arena["tmp"] = prg.unpack_frag(self.v(wref, (op.N * K,)), op.N, K, dual)[order].reshape(-1)
-                self.conv(dataclasses.replace(op, korder=prg.KORDER_TAP, w=prg.Ref("tmp", 0), Kpad=K, No=No_, ophase=oph, dt=list(dt),
+                self.conv(dataclasses.replace(op, korder=prg.KORDER_TAP, w=prg.Ref("tmp", 0), bias=bias, Kpad=K, No=No_, ophase=oph, dt=list(dt),
                                               ioff=list(ioff), stat_tile0=st0, ph1_w=None, ph1_No=0, ph1_dt=[], ph1_ioff=[], f2_w=None))
             if op.f2_w is not None:
                 # fused second 1x1 convolution on the rows just written: as its own launch on this launch's output
