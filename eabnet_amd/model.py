@@ -760,14 +760,15 @@ class GaGNet(_HipModule):
             from . import train_gag
             if self.use_hip_training and inpt.is_cuda and pre_x.is_cuda and not inpt.requires_grad and not pre_x.requires_grad \
                     and torch.is_grad_enabled() and train_gag.supported(self.cfg) and next(self.parameters()).is_cuda \
-                    and not (self.norm_type == "BN" and self.training):
+                    and not (self.norm_type == "BN" and not self.training):       # (BatchNorm: train mode only, as EaBNet)
                 self.training_backend = "hip"
                 return train_gag.forward_train(self, inpt, pre_x)
             from .autograd_path import forward_gagnet
             self.training_backend = "operators"
             if self.use_hip_training and inpt.is_cuda:
                 _warn_operator_path(self, "an input requires grad" if (inpt.requires_grad or pre_x.requires_grad) else
-                                    "post-filter topology outside train_gag.supported() (default U2 / IN / cat / causal only)")
+                                    "BatchNorm in eval mode under autograd" if self.norm_type == "BN" and not self.training else
+                                    "post-filter topology outside train_gag.supported() (U2 / IN or BN / cat / causal only)")
             return forward_gagnet(self, inpt, pre_x)
         if not (inpt.is_cuda and pre_x.is_cuda):
             raise _lib.EabError("eabnet_amd.GaGNet inference runs on MI355X only: move the inputs (and module) to "

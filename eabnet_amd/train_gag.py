@@ -35,7 +35,7 @@ LIN_LD = prg.GAG_LIN_LD
 
 
 def supported(cfg: GagConfig) -> bool:
-    return (cfg.is_u2 and not cfg.is_squeezed and cfg.intra_connect == "cat" and cfg.norm_type == "IN" and cfg.is_causal
+    return (cfg.is_u2 and not cfg.is_squeezed and cfg.intra_connect == "cat" and cfg.norm_type in ("IN", "BN") and cfg.is_causal
             and cfg.cin == 2 and 2 * cfg.freq <= PRE_LD)
 
 
@@ -266,5 +266,6 @@ def forward_train(module, inpt: torch.Tensor, pre_x: torch.Tensor) -> List[torch
     params = [sd[k] for k in bound.prog.keys]
     with torch.cuda.device(a.device):
         out = _GagTrainFn.apply(bound, a, b, *params)
+        bound.update_bn_buffers(module)
     out = out.to(inpt.dtype)
     return [out[j].permute(0, 1, 3, 2) for j in range(out.shape[0])]

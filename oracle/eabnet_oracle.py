@@ -401,10 +401,12 @@ def gag_chain(x, P: Params, pre: str, p: int, dilas, kd, bn, causal):
 
 def gagnet_forward(P: Params, inpt: torch.Tensor, pre_x: torch.Tensor, *, kd1: int = 3, p: int = 2, q: int = 3,
                    dilas=(1, 2, 5, 9), is_u2: bool = True, is_causal: bool = True, is_squeezed: bool = False,
-                   acti_type: str = "sigmoid", intra_connect: str = "cat", norm_type: str = "IN") -> List[torch.Tensor]:
-    """GaGNet.forward (GaGNet.py:76-90): inpt, pre_x (B,2,T,F) -> q stage outputs (B,2,F,T)."""
+                   acti_type: str = "sigmoid", intra_connect: str = "cat", norm_type: str = "IN",
+                   bn_train: bool = False) -> List[torch.Tensor]:
+    """GaGNet.forward (GaGNet.py:76-90): inpt, pre_x (B,2,T,F) -> q stage outputs (B,2,F,T).
+    bn_train: norm_type="BN" with the module in train mode (batch statistics; see _norm)."""
     B, _, T, Fq = inpt.shape
-    bn, add = norm_type == "BN", intra_connect == "add"
+    bn, add = ("train" if bn_train else True) if norm_type == "BN" else False, intra_connect == "add"
     x = torch.cat([inpt, pre_x], dim=1)
     if is_u2:
         for i in range(4):

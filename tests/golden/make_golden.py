@@ -202,6 +202,19 @@ def main_variants(only=None):
         json.dump(inventory, f)
 
 
+def main_bn_train():
+    """norm_type="BN" with the module in TRAIN mode (the mode the reference's trainer runs in): batch statistics in the
+    forward, and the running buffers after that one forward (momentum 0.1, unbiased variance)."""
+    M, kw = 4, dict(norm_type="BN", p=2, q=2)
+    net, specs = ref_model(M, seed=260, **kw)
+    net.train()
+    x = torch.from_numpy(paramgen.make_spec_input(3, 20, 161, M, seed=360))
+    y = net(x)
+    sd = net.state_dict()
+    arrs = {k: v.numpy() for k, v in sd.items() if k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
+    save("bn_train.npz", out=y.numpy(), param_seed=260, input_seed=360, M=M, p=2, q=2, B=3, T=20, **arrs)
+
+
 def main_istft():
     """Back end: the reference's call (enhance.py:59-62) on seeded (B,2,T,F) estimates; the inputs
     carry non-zero imaginary DC/Nyquist bins, which torch.istft ignores."""
@@ -360,6 +373,8 @@ if __name__ == "__main__":
             main_variants()
         elif sys.argv[1:] == ["istft"]:
             main_istft()
+        elif sys.argv[1:] == ["bn_train"]:
+            main_bn_train()
         else:
             main()
             main_variants()
@@ -367,3 +382,4 @@ if __name__ == "__main__":
             main_gagnet()
             main_blocks()
             main_losses()
+            main_bn_train()

@@ -1206,6 +1206,62 @@ def test_hip_training_gradients_cnn_head_vs_oracle_autograd(dev):
     _check_training_gradients(dev, 4, 2, 30, (2, 2), True, bf_type="cnn", taps=("bf_w", "de.4", "de.0", "stcns", "en.4", "en.0"))
 
 
+@pytest.mark.parametrize("M,B,T,pq", [(4, 3, 22, (2, 2)), (8, 2, 40, (6, 3))])
+def test_hip_training_batchnorm_train_mode_vs_oracle_autograd(dev, M, B, T, pq):
+    """norm_type="BN" with the module in train mode (NormSwitch BN branch, EaBNet.py:677-681 = nn.BatchNorm{1,2}d: batch
+    statistics over (B, T[, F]), momentum-0.1 update of the running buffers with the unbiased variance) on the HIP training
+    programs: output, every parameter gradient and the updated buffers against fp64 autograd through the oracle.
+    PReLU slopes are 1 (smooth network, see _check_training_gradients): the bar is 1e-4 per tensor."""
+    import eabnet_amd
+    from eabnet_amd.spec import NetConfig, param_specs
+    from oracle import eabnet_oracle as orc
+    p, q = pq
+    kw = dict(p=p, q=q, norm_type="BN")
+    P = torch_params(M, 930 + M, **kw)
+    specs = param_specs(NetConfig(M=M, **kw))
+    for k, sp in specs.items():
+        if sp.kind == "prelu":
+            P[k] = torch.ones_like(P[k])
+    net = eabnet_amd.EaBNet(M=M, **kw)
+    net.load_state_dict(P, strict=True)
+    net = net.to(dev).train()
+    x = torch.from_numpy(paramgen.make_spec_input(B, T, 161, M, 940))
+    label = torch.from_numpy(paramgen.make_spec_input(B, T, 161, 1, 941)[..., 0, :]).permute(0, 3, 1, 2).contiguous()
+    frames = [T] * B
+    y = net(x.to(dev))
+    assert y.requires_grad and net.training_backend == "hip" and getattr(net, "_train_bound", None), "the HIP path did not engage"
+    loss = eabnet_amd.com_mag_mse_loss(y, label.to(dev), frames)
+    loss.backward()
+    # oracle: fp64, train-mode BatchNorm
+    is_param = {k for k, sp in specs.items() if not sp.kind.startswith("bn_")}
+    Pd = {k: (v.double().requires_grad_(True) if k in is_param else v.double()) for k, v in P.items()}
+    Pd["__bn_updates__"] = {}
+    y_ref = orc.eabnet_forward(Pd, x.double(), bn_train=True, **kw)
+    ref_loss = orc.com_mag_mse_loss(y_ref, label.double(), frames)
+    ref_loss.backward()
+    assert_close(y.detach().cpu().numpy(), y_ref.detach().numpy(), 1e-5, "train-mode BatchNorm forward")
+    assert abs(float(loss) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
+    ref = {k: Pd[k].grad for k in is_param}
+    got = {k: net.get_parameter(k).grad.cpu().double() for k in ref}
+    assert all(torch.isfinite(g).all() for g in got.values())
+    total, per = _grad_errors(got, ref)
+    bad = sorted(((e, k) for k, e in per.items() if e > 1e-4), reverse=True)
+    print(f"BatchNorm train mode: parameter gradients global l2-rel {total:.2e}, worst tensor {max(per.values()):.2e}")
+    assert total <= 1e-4 and not bad, f"global l2-rel {total:.3e}; tensors over 1e-4: {bad[:8]}"
+    # running buffers after one step
+    upd = Pd["__bn_updates__"]
+    assert len(upd) == sum(1 for sp in specs.values() if sp.kind == "bn_mean")
+    for k, (rm, rv) in upd.items():
+        np.testing.assert_allclose(net.get_buffer(f"{k}.norm.running_mean").cpu().numpy(), rm.numpy(), rtol=2e-5, atol=1e-6, err_msg=k)
+        np.testing.assert_allclose(net.get_buffer(f"{k}.norm.running_var").cpu().numpy(), rv.numpy(), rtol=2e-5, atol=1e-6, err_msg=k)
+        assert int(net.get_buffer(f"{k}.norm.num_batches_tracked")) == int(P[f"{k}.norm.num_batches_tracked"]) + 1
+    # eval mode under autograd keeps the operator path (running statistics), with a warning
+    net.eval()
+    with pytest.warns(RuntimeWarning):
+        y2 = net(x.to(dev))
+    assert y2.requires_grad and net.training_backend == "operators"
+
+
 def _check_training_gradients(dev, M, B, T, pq, smooth, taps=None, **extra):
     """net(x) under autograd runs the two HIP training programs (eabnet_amd/train.py): the forward equals the
     inference program's output, and loss.backward() gives every parameter the gradient fp64 autograd through the
@@ -1317,6 +1373,49 @@ def test_hip_training_of_the_post_filter_vs_oracle_autograd(dev, smooth):
         floor, _ = _grad_errors(g32, ref)
         print(f"   reference fp32 autograd vs fp64: global l2-rel {floor:.2e}")
         assert total <= max(1e-4, 4.0 * floor), f"global l2-rel {total:.3e} vs the reference's own fp32 floor {floor:.3e}"
+
+
+def test_hip_training_of_the_post_filter_batchnorm_train_mode_vs_oracle_autograd(dev):
+    """the post-filter with norm_type="BN" in train mode (GaGNet.py's NormSwitch BN branch = nn.BatchNorm{1,2}d) on the HIP
+    training programs: outputs, parameter gradients and the updated running buffers against fp64 autograd through the oracle"""
+    import eabnet_amd
+    from oracle import eabnet_oracle as orc
+    kw = dict(p=1, q=2, dilas=[1, 2], norm_type="BN")
+    net, P = _gag_model(kw, 970, dev)
+    specs = eabnet_amd.gag_param_specs(net.cfg)
+    for k, sp in specs.items():
+        if sp.kind == "prelu":
+            P[k] = torch.ones_like(P[k])
+    net.load_state_dict(P, strict=True)
+    B, T = 3, 22
+    inpt, pre_x = _planar(B, T, 971), _planar(B, T, 972)
+    label = _planar(B, T, 973).permute(0, 1, 3, 2).contiguous()              # (B,2,F,T)
+    frames = [T] * B
+    net.train()
+    outs = net(inpt.to(dev), pre_x.to(dev))
+    assert outs[0].requires_grad and net.training_backend == "hip" and getattr(net, "_train_bound", None)
+    loss = eabnet_amd.stagewise_com_mag_mse_loss(outs, label.to(dev), frames)
+    loss.backward()
+    is_param = {k for k, sp in specs.items() if not sp.kind.startswith("bn_")}
+    Pd = {k: (v.double().requires_grad_(True) if k in is_param else v.double()) for k, v in P.items()}
+    Pd["__bn_updates__"] = {}
+    ref_outs = orc.gagnet_forward(Pd, inpt.double(), pre_x.double(), kd1=3, bn_train=True, **kw)
+    lo = orc.stagewise_com_mag_mse_loss(ref_outs, label.double(), frames)
+    lo.backward()
+    for a, b in zip(outs, ref_outs):
+        assert_close(a.detach().cpu().numpy(), b.detach().numpy(), 1e-5, "train-mode BatchNorm forward (post-filter)")
+    assert abs(float(loss) - float(lo)) <= 1e-5 * abs(float(lo))
+    ref = {k: Pd[k].grad for k in is_param}
+    got = {k: net.get_parameter(k).grad.cpu().double() for k in ref}
+    total, per = _grad_errors(got, ref)
+    bad = sorted(((e, k) for k, e in per.items() if e > 1e-4), reverse=True)
+    print(f"post-filter, BatchNorm train mode: parameter gradients global l2-rel {total:.2e}, worst tensor {max(per.values()):.2e}")
+    assert total <= 1e-4 and not bad, f"global l2-rel {total:.3e}; tensors over 1e-4: {bad[:8]}"
+    upd = Pd["__bn_updates__"]
+    assert len(upd) == sum(1 for sp in specs.values() if sp.kind == "bn_mean")
+    for k, (rm, rv) in upd.items():
+        np.testing.assert_allclose(net.get_buffer(f"{k}.norm.running_mean").cpu().numpy(), rm.numpy(), rtol=2e-5, atol=1e-6, err_msg=k)
+        np.testing.assert_allclose(net.get_buffer(f"{k}.norm.running_var").cpu().numpy(), rv.numpy(), rtol=2e-5, atol=1e-6, err_msg=k)
 
 
 def test_hip_training_step_matches_operator_path(dev):

@@ -188,6 +188,26 @@ def test_oracle_constructor_variants_match_reference(name):
     assert_close(y.numpy(), g["out"], TOL_ORACLE, name)
 
 
+def test_oracle_batchnorm_train_mode_matches_reference():
+    """norm_type="BN" in TRAIN mode (what the reference's trainer runs): the oracle's batch-statistics branch and its
+    running-buffer update against the reference module's forward and state after one step (tests/golden/bn_train.npz)."""
+    g = load("bn_train.npz")
+    kw = dict(norm_type="BN", p=int(g["p"]), q=int(g["q"]))
+    M = int(g["M"])
+    P = torch_params(M, int(g["param_seed"]), **kw)
+    P["__bn_updates__"] = {}
+    x = torch.from_numpy(paramgen.make_spec_input(int(g["B"]), int(g["T"]), 161, M, int(g["input_seed"])))
+    with torch.no_grad():
+        y = orc.eabnet_forward(P, x, bn_train=True, **kw)
+    assert_close(y.numpy(), g["out"], TOL_ORACLE, "train-mode BatchNorm forward")
+    upd = P["__bn_updates__"]
+    assert len(upd) == sum(1 for k in g.files if k.endswith("running_mean")) > 50
+    for k, (rm, rv) in upd.items():
+        np.testing.assert_allclose(rm.numpy(), g[f"{k}.norm.running_mean"], rtol=1e-5, atol=1e-6, err_msg=k)
+        np.testing.assert_allclose(rv.numpy(), g[f"{k}.norm.running_var"], rtol=1e-5, atol=1e-6, err_msg=k)
+        assert int(g[f"{k}.norm.num_batches_tracked"]) == int(P[f"{k}.norm.num_batches_tracked"]) + 1
+
+
 @pytest.mark.parametrize("B,T", [(1, 2), (2, 9), (3, 40)])
 def test_istft_oracle_matches_reference_call(B, T):
     """Back end: the spelled-out irfft / window / overlap-add / envelope / trim
