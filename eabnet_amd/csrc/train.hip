@@ -211,8 +211,10 @@ __global__ __launch_bounds__(TR_THREADS) void tr_norm_act_kernel(const float* __
     for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < n4; r += gridDim.x * blockDim.x) {
         const int c = (int)(r % C4) * 4;
         const f32x4 v = reinterpret_cast<const f32x4*>(x)[base + r];
+        // xf == NULL: no norm in front of the PReLU (the plain U-Net's middle encoder layers, EaBNet.py:219-226)
+        const f32x4 one0 = {1.f, 0.f, 1.f, 0.f};
         const float* xp = xf + ((size_t)b * C + c) * 2;
-        const f32x4 s01 = *reinterpret_cast<const f32x4*>(xp), s23 = *reinterpret_cast<const f32x4*>(xp + 4);
+        const f32x4 s01 = xf ? *reinterpret_cast<const f32x4*>(xp) : one0, s23 = xf ? *reinterpret_cast<const f32x4*>(xp + 4) : one0;
         const f32x4 sl = *reinterpret_cast<const f32x4*>(slope + c);
         const float sc[4] = {s01[0], s01[2], s23[0], s23[2]}, sh[4] = {s01[1], s01[3], s23[1], s23[3]};
         f32x4 o;
@@ -236,8 +238,9 @@ static inline unsigned tr_grid_x(long long n4, int B) {
 
 extern "C" int eab_train_norm_act_f32(const float* x, const float* xf, const float* slope, const float* add, float* y, int B,
                                       int P, int C, int mode, eab_stream_t stream) {
-    EAB_CHECK_ARG(x && xf && slope && y && B > 0 && P > 0 && C > 0 && (C % 4) == 0 && B <= 65535);
+    EAB_CHECK_ARG(x && slope && y && B > 0 && P > 0 && C > 0 && (C % 4) == 0 && B <= 65535);
     EAB_CHECK_ARG(mode == EAB_XF_NORM_PRELU || mode == EAB_XF_PRELU_NORM);
+    EAB_CHECK_ARG(xf || mode == EAB_XF_NORM_PRELU);                  // xf == NULL: y = prelu(x) [+ add]
     EAB_CHECK_ARG((long long)P * (C / 4) < (1ll << 31));
     hipLaunchKernelGGL(tr_norm_act_kernel, dim3(tr_grid_x((long long)P * (C / 4), B), B), dim3(TR_THREADS), 0, eab_stream(stream),
                        x, xf, slope, add, y, P, C, mode);
@@ -273,10 +276,12 @@ __global__ __launch_bounds__(TR_THREADS) void norm_bwd_reduce_kernel(const float
     const int c = blockIdx.y * 64 + cl * 4;
     f32x4 A = {0.f, 0.f, 0.f, 0.f}, Q = A, S = A;
     if (c < C) {
+        // mr == NULL: no norm (u = x): only the slope sum S is needed
+        const f32x4 zero_one = {0.f, 1.f, 0.f, 1.f}, ones = {1.f, 1.f, 1.f, 1.f}, zeros = {0.f, 0.f, 0.f, 0.f};
         const float* mp = &mr[((size_t)b * C + c) * 2];
-        const f32x4 m01 = *reinterpret_cast<const f32x4*>(mp), m23 = *reinterpret_cast<const f32x4*>(mp + 4);
+        const f32x4 m01 = mr ? *reinterpret_cast<const f32x4*>(mp) : zero_one, m23 = mr ? *reinterpret_cast<const f32x4*>(mp + 4) : zero_one;
         const float mean[4] = {m01[0], m01[2], m23[0], m23[2]}, rstd[4] = {m01[1], m01[3], m23[1], m23[3]};
-        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c),
+        const f32x4 g = mr ? *reinterpret_cast<const f32x4*>(gamma + c) : ones, be = mr ? *reinterpret_cast<const f32x4*>(beta + c) : zeros,
                     a = *reinterpret_cast<const f32x4*>(slope + c);
         const int p0 = blockIdx.x * chunk, p1 = p0 + chunk < P ? p0 + chunk : P;
         // xC < C: views (see in_stats_kernel): view v's output gradient is its own [B][P][xC] tensor (dy, dy1)
@@ -308,6 +313,7 @@ __global__ __launch_bounds__(TR_THREADS) void norm_bwd_reduce_kernel(const float
     __syncthreads();
     if (pl < 3 && c < C) {       // pl = which of (A, Q, S); fixed-order sum over the 16 position lanes, then one atomic per value
         if (pl == 2 && mode != EAB_XF_NORM_PRELU) return;
+        if (pl < 2 && !mr) return;
         f32x4 t = red[pl][0][cl];
 #pragma unroll
         for (int k = 1; k < NB_ROWS; ++k) t += red[pl][k][cl];
@@ -327,24 +333,28 @@ __global__ __launch_bounds__(TR_THREADS) void norm_bwd_apply_kernel(const float*
     const int b = blockIdx.z, cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int c = blockIdx.y * 64 + cl * 4;
     f32x4 S = {0.f, 0.f, 0.f, 0.f};
-    if (dgamma && blockIdx.x == 0 && pl == 0 && c < C) {
+    if ((dgamma || !mr) && blockIdx.x == 0 && pl == 0 && c < C) {
         // the sums A, Q (and S for NORM_PRELU) of (b, c) are final after the reduce pass -> the parameter gradients ride
         // along here (one workgroup per (b, channel group); B atomics per address)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(&sums[((size_t)b * C + c + j) * 4]);
-            atomicAdd(&dbeta[c + j], v[0]);
-            atomicAdd(&dgamma[c + j], v[1]);
+            if (mr) {
+                atomicAdd(&dbeta[c + j], v[0]);
+                atomicAdd(&dgamma[c + j], v[1]);
+            }
             if (mode == EAB_XF_NORM_PRELU) atomicAdd(&dslope[c + j], v[2]);
         }
     }
     if (c < C) {
+        // mr == NULL: no norm -- dx = dy * prelu'(x), no projection
+        const f32x4 zero_one = {0.f, 1.f, 0.f, 1.f}, ones = {1.f, 1.f, 1.f, 1.f}, zeros = {0.f, 0.f, 0.f, 0.f};
         const float* mp = &mr[((size_t)b * C + c) * 2];
-        const f32x4 m01 = *reinterpret_cast<const f32x4*>(mp), m23 = *reinterpret_cast<const f32x4*>(mp + 4);
+        const f32x4 m01 = mr ? *reinterpret_cast<const f32x4*>(mp) : zero_one, m23 = mr ? *reinterpret_cast<const f32x4*>(mp + 4) : zero_one;
         const float mean[4] = {m01[0], m01[2], m23[0], m23[2]}, rstd[4] = {m01[1], m01[3], m23[1], m23[3]};
-        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c),
+        const f32x4 g = mr ? *reinterpret_cast<const f32x4*>(gamma + c) : ones, be = mr ? *reinterpret_cast<const f32x4*>(beta + c) : zeros,
                     a = *reinterpret_cast<const f32x4*>(slope + c);
-        const float inv_p = 1.0f / (float)P;
+        const float inv_p = mr ? 1.0f / (float)P : 0.0f;
         float Am[4], Qm[4], k[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -489,9 +499,13 @@ static inline int nb_chunk(int P, int B, int C) {
 extern "C" int eab_train_norm_bwd_f32(const float* dy, const float* x, const float* mr, const float* gamma, const float* beta,
                                       const float* slope, float* sums, const float* acc_in, float* dx, float* dgamma,
                                       float* dbeta, float* dslope, int B, int P, int C, int mode, eab_stream_t stream) {
-    EAB_CHECK_ARG(dy && x && mr && gamma && beta && slope && sums && dx && dgamma && dbeta && dslope);
+    // mr == NULL (then gamma, beta, dgamma, dbeta are not touched): no norm in front of the PReLU, NORM_PRELU order only
+    EAB_CHECK_ARG(dy && x && slope && sums && dx && dslope);
+    EAB_CHECK_ARG(mr ? (gamma && beta && dgamma && dbeta) : true);
     const bool zeroed = (mode & EAB_NB_SUMS_ZEROED) != 0;          // the caller guarantees sums == 0 on entry
     mode &= ~EAB_NB_SUMS_ZEROED;
+    EAB_CHECK_ARG(mr || mode == EAB_XF_NORM_PRELU);
+    if (!mr) dgamma = dbeta = nullptr;
     EAB_CHECK_ARG(B > 0 && P > 0 && C > 0 && (C % 4) == 0 && B <= 65535 && (mode == EAB_XF_NORM_PRELU || mode == EAB_XF_PRELU_NORM));
     hipStream_t s = eab_stream(stream);
     const int chunk = nb_chunk(P, B, C);

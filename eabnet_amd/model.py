@@ -454,7 +454,8 @@ class EaBNet(_HipModule):
             if self.use_hip_training and inpt.is_cuda and not inpt.requires_grad and torch.is_grad_enabled() \
                     and train.supported(self.cfg) and not bn_eval and next(self.parameters()).is_cuda:
                 self.training_backend = "hip"
-                return train.forward_train(self, inpt)
+                out = train.forward_train(self, inpt)
+                return out.sum(dim=-1) if self.topo_type == "miso" else out      # (EaBNet.py:122-123, as in inference below)
             from .autograd_path import forward_autograd
             self.training_backend = "operators"
             if self.use_hip_training and inpt.is_cuda:

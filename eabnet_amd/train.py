@@ -48,18 +48,16 @@ TRAIN_BOUND_CACHE = 3   # bound training programs kept per module (LRU over (B, 
 
 
 def supported(cfg: NetConfig) -> bool:
-    return (cfg.is_u2 and cfg.bf_type in ("lstm", "cnn") and cfg.topo_type == "mimo" and cfg.intra_connect in ("cat", "add")
+    return (cfg.bf_type in ("lstm", "cnn") and cfg.topo_type in ("mimo", "miso") and cfg.intra_connect in ("cat", "add")
             and cfg.norm_type in ("IN", "BN") and 2 * cfg.M <= MLP_LD)
 
 
 def unsupported_reason(cfg: NetConfig) -> str:
     """which constructor switch keeps a configuration off the HIP training programs ('' when supported)"""
     why = []
-    if not cfg.is_u2:
-        why.append("is_u2=False")
     if cfg.bf_type not in ("lstm", "cnn"):
         why.append(f"bf_type={cfg.bf_type!r}")
-    if cfg.topo_type != "mimo":
+    if cfg.topo_type not in ("mimo", "miso"):
         why.append(f"topo_type={cfg.topo_type!r}")
     if cfg.intra_connect not in ("cat", "add"):
         why.append(f"intra_connect={cfg.intra_connect!r}")
@@ -173,7 +171,7 @@ class TrainLowering:
         # small-tile kernel (csrc/conv_st.hip) for the 1-D convolutions of the S-TCMs and their dgrads
         self.st = os.environ.get("EAB_ST", "1") != "0"
         if not self.supports(cfg):
-            raise NotImplementedError("the HIP training path covers the default topology with InstanceNorm")
+            raise NotImplementedError("the HIP training path does not cover this configuration: " + (unsupported_reason(cfg) if self.supports is supported else "post-filter topology"))
         cfg.check_supported()
         self.cfg, self.B, self.T, self.F = cfg, B, T, F
         # (the BatchNorm buffers are not parameters of the programs: train mode normalises with batch statistics)
@@ -364,7 +362,9 @@ class TrainLowering:
         """a = f(raw) [+ add]; records the backward (norm/PReLU gradients, dparams)"""
         out = self.act(raw.F, raw.C)
         P = self.nP * raw.F
-        gam, bet, slp = self.vec(f"{norm}.norm.weight"), self.vec(f"{norm}.norm.bias"), self.vec(f"{act}.weight")
+        slp = self.vec(f"{act}.weight")
+        # norm None: PReLU only (xf / mr NULL -- the kernels' no-norm form; the plain U-Net's middle encoder layers)
+        gam, bet = (self.vec(f"{norm}.norm.weight"), self.vec(f"{norm}.norm.bias")) if norm else (None, None)
         self.fwd.append(GenOp(OP_TR_NORM_ACT, [raw.ref, xf, slp, add.ref if add else None, out.ref], [self.nB, P, raw.C, mode],
                               name=name))
 
@@ -382,8 +382,9 @@ class TrainLowering:
             # kernel needs no zero-fill launch of its own (EAB_NB_SUMS_ZEROED)
             sums = Ref("g", self.g_size)
             self.g_size += self.nB * raw.C * 4 + ((-self.nB * raw.C * 4) % ALIGN)
-            self.bwd.append(GenOp(OP_NORM_BWD, [d, raw.ref, mr, gam, bet, slp, sums, aux, dst, self.gvec(f"{norm}.norm.weight"),
-                                                self.gvec(f"{norm}.norm.bias"), self.gvec(f"{act}.weight")],
+            self.bwd.append(GenOp(OP_NORM_BWD, [d, raw.ref, mr, gam, bet, slp, sums, aux, dst,
+                                                self.gvec(f"{norm}.norm.weight") if norm else None,
+                                                self.gvec(f"{norm}.norm.bias") if norm else None, self.gvec(f"{act}.weight")],
                                   [self.nB, P, raw.C, mode | NB_SUMS_ZEROED], name=name + ".bwd"))
         return back
 
@@ -422,12 +423,13 @@ class TrainLowering:
         raw = self.act(Fout, Cout)
         bm = self.pick_bm(Fout)
         tiles = conv_tiles(self.T, Fout, bm)
-        stats = self.alloc(self.B * tiles * Cout * 4)
+        stats = self.alloc(self.B * tiles * Cout * 4) if norm else None
         dump = self.alloc(self.B * self.T * Fout * N) if glu else None
         dts, ios = [a - (kt - 1) for a, _ in taps], [c for _, c in taps]
         self.conv_op(name, srcs, self.wadd(f"{wkey}.w", wimg), self.wadd(f"{wkey}.b", bimg), N, wimg.shape[1], Fin, Fout, Fout, 1, 0,
-                     2, dts, ios, prg.EPI_GLU if glu else prg.EPI_LINEAR, raw.ref, Cout, stats, tiles, 0, bm, glu_dump=dump)
-        xf, mr = self.finalize(name + ".in", stats, Cout, tiles, self.T * Fout, norm)
+                     2, dts, ios, prg.EPI_GLU if glu else prg.EPI_LINEAR, raw.ref, Cout, stats, tiles if stats else 0, 0, bm,
+                     glu_dump=dump)
+        xf, mr = self.finalize(name + ".in", stats, Cout, tiles, self.T * Fout, norm) if norm else (None, None)
         rows = self.B * self.T * Fout
 
         def back():
@@ -670,13 +672,23 @@ class TrainLowering:
         in_perm = (mem % 2) * M + mem // 2                                   # memory channel m*2+ri <- reference ri*M+m
         skips: List[TVar] = []
         x = x_in
-        for i in range(4):
-            x = self.unet_module(f"en.meta_unet_list.{i}", [x], 4 - i, False, in_perm if i == 0 else None)
+        if cfg.is_u2:
+            for i in range(4):
+                x = self.unet_module(f"en.meta_unet_list.{i}", [x], 4 - i, False, in_perm if i == 0 else None)
+                skips.append(x)
+                self.gtaps[f"en.{i}"] = x
+            x = self.conv2d_fwd("en.last_conv", [x], "en.last_conv.0.conv.1", True, "en.last_conv.1", "en.last_conv.2")
             skips.append(x)
-            self.gtaps[f"en.{i}"] = x
-        x = self.conv2d_fwd("en.last_conv", [x], "en.last_conv.0.conv.1", True, "en.last_conv.1", "en.last_conv.2")
-        skips.append(x)
-        self.gtaps["en.4"] = x
+            self.gtaps["en.4"] = x
+        else:
+            # UNet_Encoder (EaBNet.py:213-239): five gated convolutions; layers 1 and 2 have no norm in front of their PReLU
+            from .spec import unet_encoder_layers
+            for i, (_, _, _, has_norm) in enumerate(unet_encoder_layers(cfg)):
+                q = f"en.unet_list.{i}"
+                x = self.conv2d_fwd(q, [x], f"{q}.0.conv.1", True, f"{q}.1" if has_norm else None,
+                                    f"{q}.2" if has_norm else f"{q}.1", in_perm if i == 0 else None)
+                skips.append(x)
+                self.gtaps[f"en.{i}"] = x
         Fb = x.F
         assert Fb * x.C == cfg.d_feat
         k = np.arange(cfg.d_feat)
@@ -699,21 +711,31 @@ class TrainLowering:
         self.tape.append(back_acc)
         x = x_acc.view(Fb, c)
         self.gtaps["stcns"] = x
-        for i in range(4):
-            x = self.unet_module(f"de.meta_unet_list.{i}", [x, skips[-(i + 1)]], i + 1, True)
-            self.gtaps[f"de.{i}"] = x
-        e = self.conv2d_transposed("de.last_conv", [x, skips[0]], "de.last_conv.0.conv.0", True, "de.last_conv.1", "de.last_conv.2")
+        if cfg.is_u2:
+            for i in range(4):
+                x = self.unet_module(f"de.meta_unet_list.{i}", [x, skips[-(i + 1)]], i + 1, True)
+                self.gtaps[f"de.{i}"] = x
+            e = self.conv2d_transposed("de.last_conv", [x, skips[0]], "de.last_conv.0.conv.0", True, "de.last_conv.1",
+                                       "de.last_conv.2")
+        else:
+            for i in range(5):                        # UNet_Decoder (EaBNet.py:297-328)
+                q = f"de.unet_list.{i}"
+                x = e = self.conv2d_transposed(q, [x, skips[-(i + 1)]], f"{q}.0.conv.0", True, f"{q}.1", f"{q}.2")
+                self.gtaps[f"de.{i}"] = x
         assert e.F == F and e.C == 64
         self.gtaps["de.4"] = e
 
         rows = B * T * F
-        if cfg.bf_type == "cnn":
+        if cfg.bf_type == "cnn" or cfg.topo_type == "miso":
             # ---- pointwise head (EaBNet.py:80-81,111-113): Conv2d(64 -> 2M, 1x1); output plane m*2+ri is the column order the
-            # filter-and-sum kernels read (rows padded to one 64-column tile)
+            # filter-and-sum kernels read (rows padded to one 64-column tile).  miso (EaBNet.py:78-79,118-125): Conv2d(64 -> 2),
+            # one complex mask on microphone 0 = the same head with zero rows for the other microphones; the caller sums the
+            # (B,2,T,F) result over frequency, as the reference does
+            wk = self.idx("bf_map.weight").reshape(-1, 64)
             wc = np.full((MLP_LD, 64, 1), -1, np.int64)
-            wc[:2 * M] = self.idx("bf_map.weight").reshape(2 * M, 64)[:, :, None]
+            wc[:wk.shape[0]] = wk[:, :, None]
             bcimg = np.full(MLP_LD, -1, np.int64)
-            bcimg[:2 * M] = self.idx("bf_map.bias")
+            bcimg[:wk.shape[0]] = self.idx("bf_map.bias")
             wcimg = self.pack_taps_idx(wc, [0])
             bw = self.act(F, MLP_LD)
             self.conv_op("bf_map", [e], self.wadd("bf_map.w", wcimg), self.wadd("bf_map.b", bcimg), MLP_LD, 64, F, F, F, 1, 0, 1,

@@ -477,6 +477,8 @@ int eab_train_norm_act_f32(const float* x, const float* xf, const float* slope, 
 /* Backward of y = f(x) through the InstanceNorm statistics (per (b, c) over P) and the PReLU:
  *   dx = (acc_in ? acc_in : 0) + d loss / d x;   dgamma[c], dbeta[c], dslope[c] += their gradients.
  * sums: scratch [B][C][4]; OR-ing EAB_NB_SUMS_ZEROED into `mode` promises it is zero on entry (saves the zero-fill launch).
+ * mr == NULL (EAB_XF_NORM_PRELU only; eab_train_norm_act_f32: xf == NULL): no norm in front of the PReLU -- y = prelu(x),
+ * dx = dy * prelu'(x), only dslope is accumulated (the plain U-Net's middle encoder layers, EaBNet.py:219-226).
  * Two launches (reduce, apply; the parameter gradients ride in the apply pass).  Reference: autograd of EaBNet.py:684-686 + nn.PReLU. */
 #define EAB_NB_SUMS_ZEROED 0x100
 int eab_train_norm_bwd_f32(const float* dy, const float* x, const float* mr, const float* gamma, const float* beta,

@@ -1262,6 +1262,64 @@ def test_hip_training_batchnorm_train_mode_vs_oracle_autograd(dev, M, B, T, pq):
     assert y2.requires_grad and net.training_backend == "operators"
 
 
+def _train_variants():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "keys_variants.json")) as f:
+        return {k: v for k, v in json.load(f).items()}
+
+
+@pytest.mark.parametrize("name", sorted(_train_variants()))
+def test_hip_training_of_every_constructor_variant_vs_oracle_autograd(dev, name):
+    """Every constructor branch of tests/golden/keys_variants.json (plain U-Net, cnn / miso heads, add skips, BatchNorm --
+    in train mode, as the reference's trainer runs it --, non-causal S-TCMs and their combinations) trains on the HIP
+    programs: output, loss and every parameter gradient against fp64 autograd through the oracle (smooth network: PReLU
+    slopes 1, bar 1e-4 per tensor).  cLN is the one branch left on PyTorch-ROCm operators: it must say so."""
+    import eabnet_amd
+    from eabnet_amd.spec import NetConfig, param_specs
+    from oracle import eabnet_oracle as orc
+    e = _train_variants()[name]
+    kw, M = dict(e["kwargs"], p=2, q=2), e["M"]
+    # (B, T) = (3, 21) puts one pre-activation of the head's ReLU (EaBNet.py:594) within fp32 rounding of zero for the "unet"
+    # entry: the one flipped derivative is a 1e-3 gradient error on its own (tools/diag_variant_grads.py) -- see
+    # _check_training_gradients on smooth instances
+    B, T = 3, 20
+    P = torch_params(M, 980, **kw)
+    specs = param_specs(NetConfig(M=M, **kw))
+    for k, sp in specs.items():
+        if sp.kind == "prelu":
+            P[k] = torch.ones_like(P[k])
+    net = eabnet_amd.EaBNet(M=M, **kw)
+    net.load_state_dict(P, strict=True)
+    net = net.to(dev).train()
+    x = torch.from_numpy(paramgen.make_spec_input(B, T, 161, M, 981))
+    if kw.get("norm_type") == "cLN":
+        with pytest.warns(RuntimeWarning, match="cLN"):
+            y = net(x.to(dev))
+        assert net.training_backend == "operators"
+        return
+    y = net(x.to(dev))
+    assert y.requires_grad and net.training_backend == "hip" and getattr(net, "_train_bound", None), "the HIP path did not engage"
+    label = torch.from_numpy(np.random.default_rng(982).standard_normal(tuple(y.shape)).astype(np.float32))
+    loss = ((y - label.to(dev)) ** 2).mean()
+    loss.backward()
+    is_param = {k for k, sp in specs.items() if not sp.kind.startswith("bn_")}
+    Pd = {k: (v.double().requires_grad_(True) if k in is_param else v.double()) for k, v in P.items()}
+    y_ref = orc.eabnet_forward(Pd, x.double(), bn_train=kw.get("norm_type") == "BN", **kw)
+    assert tuple(y_ref.shape) == tuple(y.shape)
+    ref_loss = ((y_ref - label.double()) ** 2).mean()
+    ref_loss.backward()
+    assert_close(y.detach().cpu().numpy(), y_ref.detach().numpy(), 1e-5, f"{name}: training forward")
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-5 * abs(float(ref_loss.detach()))
+    ref = {k: Pd[k].grad for k in is_param}
+    got = {k: net.get_parameter(k).grad.cpu().double() for k in ref}
+    assert all(torch.isfinite(g).all() for g in got.values())
+    total, per = _grad_errors(got, ref)
+    bad = sorted(((err, k) for k, err in per.items() if err > 1e-4), reverse=True)
+    print(f"{name}: parameter gradients global l2-rel {total:.2e}, worst tensor {max(per.values()):.2e}")
+    assert total <= 1e-4 and not bad, f"global l2-rel {total:.3e}; tensors over 1e-4: {bad[:8]}"
+
+
 def _check_training_gradients(dev, M, B, T, pq, smooth, taps=None, **extra):
     """net(x) under autograd runs the two HIP training programs (eabnet_amd/train.py): the forward equals the
     inference program's output, and loss.backward() gives every parameter the gradient fp64 autograd through the
