@@ -35,8 +35,7 @@ LIN_LD = prg.GAG_LIN_LD
 
 
 def supported(cfg: GagConfig) -> bool:
-    return (cfg.is_u2 and not cfg.is_squeezed and cfg.intra_connect == "cat" and cfg.norm_type in ("IN", "BN") and cfg.is_causal
-            and cfg.cin == 2 and 2 * cfg.freq <= PRE_LD)
+    return (cfg.intra_connect in ("cat", "add") and cfg.norm_type in ("IN", "BN") and cfg.cin == 2 and 2 * cfg.freq <= PRE_LD)
 
 
 class GagTrainLowering(TrainLowering):
@@ -124,9 +123,14 @@ class GagTrainLowering(TrainLowering):
         pre = TVar(self.alloc(B * T * PRE_LD), 1, PRE_LD, tr.Slot(), needs_grad=False)
         self.fwd.append(GenOp(OP_GAG_PACK, [Ref("in"), Ref("in2"), enc_in.ref, pre.ref], [B, T, F, PRE_LD], name="pack"))
         x = enc_in
-        for i in range(4):
-            x = self.unet_module(f"en.meta_unet_list.{i}", [x], 4 - i, False)
-        x = self.conv2d_fwd("en.last_conv", [x], "en.last_conv.0.conv.1", True, "en.last_conv.1", "en.last_conv.2")
+        if cfg.is_u2:
+            for i in range(4):
+                x = self.unet_module(f"en.meta_unet_list.{i}", [x], 4 - i, False)
+            x = self.conv2d_fwd("en.last_conv", [x], "en.last_conv.0.conv.1", True, "en.last_conv.1", "en.last_conv.2")
+        else:
+            for i in range(5):                          # GaGNet's UNet_Encoder (GaGNet.py:417-452): every layer normed
+                q = f"en.unet_list.{i}"
+                x = self.conv2d_fwd(q, [x], f"{q}.0.conv.1", True, f"{q}.1", f"{q}.2")
         assert x.F * x.C == cfg.d_feat
         k = np.arange(cfg.d_feat)
         feat_perm = (k % c) * x.F + k // c                 # memory channel f*64+c <- reference c*4+f (GaGNet.py:83-84)
@@ -147,14 +151,20 @@ class GagTrainLowering(TrainLowering):
             def join_back(xz=xz, xz_r=xz_r, xz_i=xz_i):
                 self.mark("bwd", "join", [1, 2])
                 self.contribute(xz, self.grad_of(xz_r))
-                self.contribute(xz, self.grad_of(xz_i))
+                if not cfg.is_squeezed:
+                    self.contribute(xz, self.grad_of(xz_i))
             self.tape.append(join_back)                 # replayed after the chains' closures, before the gated in-convs'
             self.mark("fwd", "fork", [1, 2])
             gain, back_g = self.linear(f"{gl}.linear_g.0", self.chain(f"{gl}.tcn_g", xg0))
             self.cur_lane = 1
-            lr, back_r = self.linear(f"{gz}.linear_r", self.chain(f"{gz}.tcm_r", xz_r))
-            self.cur_lane = 2
-            li, back_i = self.linear(f"{gz}.linear_i", self.chain(f"{gz}.tcm_i", xz_i))
+            if cfg.is_squeezed:                         # one chain feeds both linear maps (GaGNet.py:236-237,255)
+                ri = self.chain(f"{gz}.tcm_ri", xz_r)
+                lr, back_r = self.linear(f"{gz}.linear_r", ri)
+                li, back_i = self.linear(f"{gz}.linear_i", ri)
+            else:
+                lr, back_r = self.linear(f"{gz}.linear_r", self.chain(f"{gz}.tcm_r", xz_r))
+                self.cur_lane = 2
+                li, back_i = self.linear(f"{gz}.linear_i", self.chain(f"{gz}.tcm_i", xz_i))
             self.cur_lane = 0
             self.mark("fwd", "join", [1, 2])
             nxt = TVar(self.alloc(B * T * PRE_LD), 1, PRE_LD, tr.Slot(), needs_grad=gi + 1 < cfg.q)
@@ -171,7 +181,7 @@ class GagTrainLowering(TrainLowering):
                 back_g(dg)
                 self.cur_lane = 1
                 back_r(dr)
-                self.cur_lane = 2
+                self.cur_lane = 1 if cfg.is_squeezed else 2
                 back_i(di)
                 self.cur_lane = 0
             self.tape.append(back)

@@ -1476,6 +1476,49 @@ def test_hip_training_of_the_post_filter_batchnorm_train_mode_vs_oracle_autograd
         np.testing.assert_allclose(net.get_buffer(f"{k}.norm.running_var").cpu().numpy(), rv.numpy(), rtol=2e-5, atol=1e-6, err_msg=k)
 
 
+@pytest.mark.parametrize("name", sorted(_gag_variants()))
+def test_hip_training_of_every_post_filter_variant_vs_oracle_autograd(dev, name):
+    """Every GaGNet constructor variant of tests/golden/keys_gagnet.json (BatchNorm -- train mode --, squeezed gaze block, tanh /
+    relu gain, plain U-Net encoder, add skips, non-causal S-TCMs) trains on the HIP programs: stage outputs, loss and parameter
+    gradients against fp64 autograd through the oracle (smooth network, 1e-4 per tensor)."""
+    import eabnet_amd
+    from oracle import eabnet_oracle as orc
+    kw = dict(_gag_variants()[name]["kwargs"])
+    if name == "default":
+        kw.update(p=1, q=2, dilas=[1, 2])                # (the full-size default is covered by the tests above)
+    net, P = _gag_model(kw, 990, dev)
+    specs = eabnet_amd.gag_param_specs(net.cfg)
+    for k, sp in specs.items():
+        if sp.kind == "prelu":
+            P[k] = torch.ones_like(P[k])
+    net.load_state_dict(P, strict=True)
+    B, T = 3, 20
+    inpt, pre_x = _planar(B, T, 991), _planar(B, T, 992)
+    label = _planar(B, T, 993).permute(0, 1, 3, 2).contiguous()              # (B,2,F,T)
+    frames = [T] * B
+    net.train()
+    outs = net(inpt.to(dev), pre_x.to(dev))
+    assert outs[0].requires_grad and net.training_backend == "hip" and getattr(net, "_train_bound", None)
+    loss = eabnet_amd.stagewise_com_mag_mse_loss(outs, label.to(dev), frames)
+    loss.backward()
+    is_param = {k for k, sp in specs.items() if not sp.kind.startswith("bn_")}
+    Pd = {k: (v.double().requires_grad_(True) if k in is_param else v.double()) for k, v in P.items()}
+    okw = {k: v for k, v in kw.items() if k not in ("kd1",)}
+    ref_outs = orc.gagnet_forward(Pd, inpt.double(), pre_x.double(), kd1=kw.get("kd1", 3), bn_train=kw.get("norm_type") == "BN", **okw)
+    lo = orc.stagewise_com_mag_mse_loss(ref_outs, label.double(), frames)
+    lo.backward()
+    for a, b in zip(outs, ref_outs):
+        assert_close(a.detach().cpu().numpy(), b.detach().numpy(), 1e-5, f"{name}: training forward (post-filter)")
+    assert abs(float(loss.detach()) - float(lo.detach())) <= 1e-5 * abs(float(lo.detach()))
+    ref = {k: Pd[k].grad for k in is_param}
+    got = {k: net.get_parameter(k).grad.cpu().double() for k in ref}
+    assert all(torch.isfinite(g).all() for g in got.values())
+    total, per = _grad_errors(got, ref)
+    bad = sorted(((err, k) for k, err in per.items() if err > 1e-4), reverse=True)
+    print(f"post-filter {name}: parameter gradients global l2-rel {total:.2e}, worst tensor {max(per.values()):.2e}")
+    assert total <= 1e-4 and not bad, f"global l2-rel {total:.3e}; tensors over 1e-4: {bad[:8]}"
+
+
 def test_hip_training_step_matches_operator_path(dev):
     """One optimiser step of the reference's loop (train_distributed.py:218-230: forward, loss, backward, clip, Adam)
     on the HIP training programs against the same step on the PyTorch-ROCm operator path (autograd_path.py): same
