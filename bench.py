@@ -47,7 +47,8 @@ def kernel_source_sha() -> str:
     import glob
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "eabnet_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "eabnet_amd", "csrc", "*.h"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "eabnet_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "eabnet_amd", "csrc", "*.h"))
+                  + glob.glob(os.path.join(ROOT, "eabnet_amd", "csrc", "*.inc"))):
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 

@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libeabnet_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_TAPS = 16
 _fp = C.POINTER(C.c_float)
 
@@ -93,6 +93,8 @@ _SIGS = {
     "eab_gag_crm_bwd_f32": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 6 + [C.c_void_p]),
     "eab_conv_tiles": (C.c_int, [C.c_int] * 3),
     "eab_conv_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "eab_conv_st_chain_plan": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "eab_conv_st_chain_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "eab_conv_bf16": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "eab_lstm64_bf16": (C.c_int, [C.c_void_p] * 3 + [C.c_float] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
     "eab_in_finalize_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_float] + [C.c_void_p] * 6 + [C.c_void_p]),

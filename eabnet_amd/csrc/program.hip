@@ -61,6 +61,9 @@ extern "C" int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream
             case EAB_OP_CONV:
                 rc = eab_conv_f32(&o.conv, stream);
                 break;
+            case EAB_OP_CONV_CHAIN:
+                rc = eab_conv_st_chain_run((const eab_conv_desc*)o.p[0], (const int*)o.p[1], o.i[0], o.i[1], o.i[2], o.i[3], stream);
+                break;
             case EAB_OP_IN_FINALIZE:
                 rc = eab_in_finalize_mr_f32((const float*)o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.f[0],
                                             (const float*)o.p[1], (const float*)o.p[2], (float*)o.p[3],

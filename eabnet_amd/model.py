@@ -240,8 +240,72 @@ class _Bound:
             else:
                 raise ValueError(op.kind)
         self._in_ptr, self._out_ptr = (in_ptr, out_ptr, in2_ptr), None
+        self._plan_chains()
+
+    def _plan_chains(self) -> None:
+        """Streaming programs: runs of consecutive small-tile convolutions that give every utterance ONE tile (the S-TCN of a
+        frame-synchronous step) are executed by ONE launch (eab_conv_st_chain_run, csrc/conv_st.hip): one workgroup per
+        utterance walks the run's descriptors, which are uploaded to device memory here.  self.exec_ops = the op array of a
+        whole-program run with every such run replaced by its chain op (self.ops keeps one entry per program op for
+        single-op debug launches).  EAB_ST_CHAIN=0 keeps separate launches."""
+        import os
+        self.exec_ops, self.n_exec, self.chains = None, 0, []
+        if not self.prog.chunk or os.environ.get("EAB_ST_CHAIN", "1") == "0":
+            return
+        lib = _lib.load()
+        ops = self.prog.ops
+        n = len(ops)
+        def plan(first, cnt):
+            descs = (_lib.ConvDesc * cnt)(*[self.ops[first + t].conv for t in range(cnt)])
+            codes = (C.c_int * cnt)()
+            lds, bf = C.c_int(0), C.c_int(0)
+            if lib.eab_conv_st_chain_plan(descs, cnt, codes, C.byref(lds), C.byref(bf)) != 0:
+                return None
+            return first, cnt, descs, codes, lds.value, bf.value
+        # every op on its own first (is it a single-tile launch of a form the chain kernel carries, and in which precision),
+        # then maximal runs of such ops, planned as a whole
+        single = [plan(k, 1) if (ops[k].kind == prg.OP_CONV and ops[k].korder == prg.KORDER_FRAG) else None for k in range(n)]
+        runs = []                                       # (first, count, descs, codes, lds, bf)
+        k = 0
+        while k < n:
+            if single[k] is None:
+                k += 1
+                continue
+            j = k
+            while j < n and single[j] is not None and single[j][5] == single[k][5]:
+                j += 1
+            got = plan(k, j - k) if j - k >= 2 else None
+            if got:
+                runs.append(got)
+            k = j
+        if not runs:
+            return
+        exec_list = []
+        k = 0
+        ri = 0
+        while k < n:
+            if ri < len(runs) and runs[ri][0] == k:
+                first, cnt, descs, codes, lds, bf = runs[ri]
+                raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.device)
+                dev_codes = torch.tensor(list(codes), dtype=torch.int32, device=self.device)
+                self.chains.append((first, cnt, raw, dev_codes))          # keep the device copies alive
+                o = _lib.Op()
+                o.kind = prg.OP_CONV_CHAIN
+                o.p[0], o.p[1] = raw.data_ptr(), dev_codes.data_ptr()
+                o.i[0:4] = [cnt, int(self.prog.B), lds, bf]
+                exec_list.append(o)
+                k += cnt
+                ri += 1
+            else:
+                exec_list.append(self.ops[k])
+                k += 1
+        self.exec_ops = (_lib.Op * len(exec_list))(*exec_list)
+        self.n_exec = len(exec_list)
 
     def _launch(self, stream: int, first: int, n: int) -> None:
+        if first == 0 and n == len(self.prog.ops) and getattr(self, "exec_ops", None) is not None:
+            _lib.check(_lib.load().eab_run_program(self.exec_ops, self.n_exec, C.c_void_p(stream)), "eab_run_program")
+            return
         ops = C.cast(C.byref(self.ops, first * C.sizeof(_lib.Op)), C.POINTER(_lib.Op))
         _lib.check(_lib.load().eab_run_program(ops, n, C.c_void_p(stream)), "eab_run_program")
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EAB_ABI_VERSION 5
+#define EAB_ABI_VERSION 6
 
 #define EAB_OK          0
 #define EAB_EINVAL      1   /* bad argument (shape, alignment, limit) */
@@ -380,6 +380,7 @@ int eab_bfw_filter_sum_f32(const float* y1, const float* w2, const float* b2, co
 #define EAB_OP_MEMSET0     6
 #define EAB_OP_GAG_PACK    7
 #define EAB_OP_GAG_CRM     8
+#define EAB_OP_CONV_CHAIN  9   /* eab_conv_st_chain_run: p = {dev_descs, dev_codes}, i = {n, B, lds_bytes, bf16} */
 
 /* geometry of a weight gradient (eab_wgrad_f32, documented with the training entry points below) */
 typedef struct eab_wgrad_desc {
@@ -417,6 +418,20 @@ typedef struct eab_op {
  *  GAG_CRM     i = {B, T, F, ld, lin_ld, act}  p = {pre, g, r, i, pre_out, planar}
  */
 int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream);
+
+/* A chain of small-tile launches (EAB_KORDER_FRAG) in ONE launch: the 1-D convolutions of the S-TCN in a frame-synchronous
+ * streaming step (reference SqueezedTCM chain, EaBNet.py:506-578, with BatchNorm in eval mode).  Every descriptor must give
+ * each utterance exactly one 16-row tile (win.count * No <= 16), carry no statistics of any kind, and launch k+1 may read, of
+ * launch k's output, only the rows of the same utterance.  One workgroup per utterance then runs the launches back to back
+ * (results bit-identical to eab_conv_f32 on each descriptor in turn).
+ *   eab_conv_st_chain_plan: host-side check of descs[0..n) (every argument check of eab_conv_f32, no launch);
+ *     codes[k] = the kernel form of launch k, *lds_bytes = dynamic LDS of the chain, *bf16 = its precision (uniform).
+ *     EAB_EUNSUPPORTED: not a chain -- launch the descriptors one by one.
+ *   eab_conv_st_chain_run: dev_descs / dev_codes = the same arrays in DEVICE memory (the caller uploads them once per
+ *     binding of the program); B = utterances = workgroups. */
+int eab_conv_st_chain_plan(const eab_conv_desc* descs, int n, int* codes, int* lds_bytes, int* bf16);
+int eab_conv_st_chain_run(const eab_conv_desc* dev_descs, const int* dev_codes, int n, int B, int lds_bytes, int bf16,
+                          eab_stream_t stream);
 
 /* Windowed twins of the non-conv ops (same semantics restricted to the rows of `win`; win.pos == NULL
  * = the whole utterance).  eab_lstm64_stream_f32 additionally carries the recurrent state: the hidden
