@@ -399,7 +399,7 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary f16x3 measurement")
     ap.add_argument("--no-c1", action="store_true", help="skip the single-utterance (B=1) latency measurement")
     ap.add_argument("--no-graph", action="store_true", help="direct kernel launches instead of hipGraph replay")
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--pipeline", type=int, default=3,
                     help="batches in flight on separate HIP streams (eabnet_amd.Pipeline); 1 = strictly one step after the other")
     ap.add_argument("--no-next", action="store_true", help="skip the next-row measurements (post-filter, ISTFT)")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step section of the next rows (BASELINE configs[3])")
