@@ -94,3 +94,53 @@ def test_weight_gradients_batch_into_few_launches():
     assert len(w) == 153 and runs == 38
     # every parameter element receives exactly one gradient entry (the inverse table is total on the trained parameters)
     assert (np.asarray(prog.inv) >= 0).all()
+
+
+def _variants(fname):
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", fname)) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", sorted(_variants("keys_variants.json")))
+def test_every_constructor_variant_lowers_to_training_programs(name):
+    """train.supported() is true for every constructor branch of tests/golden/keys_variants.json except cLN, and the lowering
+    of each holds the same invariants as the default topology: every trained parameter element gets exactly one gradient
+    entry, BatchNorm variants record one (mean, rstd) table per norm for the running-buffer update."""
+    e = _variants("keys_variants.json")[name]
+    cfg = spec.NetConfig(M=e["M"], **dict(e["kwargs"], p=2, q=2))
+    if cfg.norm_type == "cLN":
+        assert not train.supported(cfg) and "cLN" in train.unsupported_reason(cfg)
+        with pytest.raises(NotImplementedError):
+            train.lower_train(cfg, 2, 20)
+        return
+    assert train.supported(cfg) and train.unsupported_reason(cfg) == ""
+    prog = train.lower_train(cfg, 2, 20)
+    assert (np.asarray(prog.inv) >= 0).all()
+    specs = spec.param_specs(cfg)
+    assert set(prog.keys) == {k for k, s in specs.items() if not s.kind.startswith("bn_")}
+    n_bn = sum(1 for s in specs.values() if s.kind == "bn_mean")
+    assert len(prog.bn_layers) == n_bn and len({k for k, *_ in prog.bn_layers}) == n_bn
+    if n_bn:
+        # one virtual utterance: every norm-side op of the programs runs with B = 1
+        for o in list(prog.fwd) + list(prog.bwd):
+            if o.kind in (train.OP_IN_STATS, train.OP_TR_NORM_ACT, train.OP_NORM_BWD):
+                assert o.i[0] == 1
+            if o.kind == prg.OP_IN_FINALIZE:
+                assert o.B == 1
+
+
+@pytest.mark.parametrize("name", sorted(_variants("keys_gagnet.json")))
+def test_every_post_filter_variant_lowers_to_training_programs(name):
+    import eabnet_amd
+    from eabnet_amd import train_gag
+    kw = dict(_variants("keys_gagnet.json")[name]["kwargs"])
+    if name == "default":
+        kw.update(p=1, q=2, dilas=[1, 2])
+    cfg = eabnet_amd.GaGNet(**kw).cfg
+    assert train_gag.supported(cfg)
+    prog = train_gag.lower_train(cfg, 2, 14, 161, "f32")
+    assert (np.asarray(prog.inv) >= 0).all()
+    specs = eabnet_amd.gag_param_specs(cfg)
+    assert len(prog.bn_layers) == sum(1 for s in specs.values() if s.kind == "bn_mean")
