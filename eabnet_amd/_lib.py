@@ -93,6 +93,7 @@ _SIGS = {
     "eab_gag_crm_bwd_f32": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 6 + [C.c_void_p]),
     "eab_conv_tiles": (C.c_int, [C.c_int] * 3),
     "eab_conv_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "eab_train_cln_bwd_f32": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 5 + [C.c_void_p]),
     "eab_conv_st_chain_plan": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "eab_conv_st_chain_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "eab_conv_bf16": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),

@@ -165,3 +165,145 @@ extern "C" int eab_gate_rows_f32(const float* a, const float* r, float* z, int B
                        row_floats / 4, win.pos, win.count);
     EAB_RETURN_LAUNCH_STATUS();
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Backward of the cumulative LayerNorm unit (training; forward = eab_cln_stats_f32 + eab_cln_apply_f32 on the whole
+// utterance).  With v = x (NORM_PRELU) or prelu(x) (PRELU_NORM), n_t = P (t+1), S_t / Q_t the running sums of v / v^2,
+//   mu_t = S_t / n_t,  var_t = Q_t / n_t - mu_t^2,  r_t = (var_t + eps)^-1/2,  y = g_c (v - mu_t) r_t + be_c
+// and dh = (d loss / d y) g_c (NORM_PRELU: d loss / d u through the PReLU that follows):
+//   a_t = sum_p dh,   b_t = sum_p dh (v - mu_t),   c_t = -1/2 r_t^3 b_t                     (pass 1, fp64 per row)
+//   A_t = sum_{t' >= t} (-r a - 2 mu c)_{t'} / n_{t'},   Bq_t = sum_{t' >= t} c_{t'} / n_{t'}     (pass 2, reverse scan per b)
+//   dv[t][p] = dh r_t + A_t + 2 v Bq_t;   dx = dv (NORM_PRELU) or dv prelu'(x) (PRELU_NORM)       (pass 3)
+// Parameter gradients per row and channel (summed over the rows by eab_colsum_f32): part[row][0][c] = sum_f d xh (gain),
+// [1][c] = sum_f d (bias), [2][c] = the PReLU slope sum (NORM_PRELU: from pass 1; PRELU_NORM: from pass 3).
+// Reference: autograd of CumulativeLayerNorm1d / 2d (EaBNet.py:713-733, 752-769) + nn.PReLU.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cl_channel_reduce(f32x4 v, f32x4* red, int C, float* out) {
+    // threads tid, tid + C/4, tid + 2 C/4, ... hold the same four channels (the row is walked with a stride of 1024 values,
+    // 1024 % C == 0): fixed-order sum, one store per channel
+    __syncthreads();
+    red[threadIdx.x] = v;
+    __syncthreads();
+    const int G = C >> 2;
+    if ((int)threadIdx.x < G) {
+        f32x4 s = red[threadIdx.x];
+        for (int k = threadIdx.x + G; k < CL_THREADS; k += G) s += red[k];
+        *reinterpret_cast<f32x4*>(out + threadIdx.x * 4) = s;
+    }
+}
+
+__global__ __launch_bounds__(CL_THREADS) void cln_bwd_rows_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                  const float* __restrict__ mr, const float* __restrict__ gain,
+                                                                  const float* __restrict__ bias, const float* __restrict__ slope,
+                                                                  int P, int C, int mode, double* __restrict__ rs,
+                                                                  float* __restrict__ part) {
+    __shared__ double red[4];
+    __shared__ f32x4 cred[CL_THREADS];
+    const size_t row = blockIdx.x;
+    const float2 m = *reinterpret_cast<const float2*>(&mr[row * 2]);
+    double a = 0.0, bb = 0.0;
+    f32x4 G = {0.f, 0.f, 0.f, 0.f}, Bt = G, S = G;
+    for (int i = threadIdx.x * 4; i < P; i += CL_THREADS * 4) {
+        const int c = i % C;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * P + i), d = *reinterpret_cast<const f32x4*>(dy + row * P + i);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gain + c), be = *reinterpret_cast<const f32x4*>(bias + c),
+                    al = *reinterpret_cast<const f32x4*>(slope + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float dd, vv;
+            if (mode == EAB_XF_NORM_PRELU) {
+                const float u = fmaf((v[j] - m.x) * m.y, g[j], be[j]);
+                dd = u > 0.f ? d[j] : al[j] * d[j];
+                S[j] += u > 0.f ? 0.f : d[j] * u;
+                vv = v[j];
+            } else {
+                dd = d[j];
+                vv = eab_prelu(v[j], al[j]);
+            }
+            const float cen = vv - m.x;
+            G[j] = fmaf(dd, cen * m.y, G[j]);
+            Bt[j] += dd;
+            const double dh = (double)dd * (double)g[j];
+            a += dh;
+            bb += dh * (double)cen;
+        }
+    }
+    a = cl_block_sum(a, red);
+    bb = cl_block_sum(bb, red);
+    if (threadIdx.x == 0) {
+        rs[row * 2] = a;
+        rs[row * 2 + 1] = bb;
+    }
+    float* pr = part + row * 3 * C;
+    cl_channel_reduce(G, cred, C, pr);
+    cl_channel_reduce(Bt, cred, C, pr + C);
+    if (mode == EAB_XF_NORM_PRELU) cl_channel_reduce(S, cred, C, pr + 2 * C);
+}
+
+__global__ __launch_bounds__(64) void cln_bwd_scan_kernel(const double* __restrict__ rs, const float* __restrict__ mr, int T, int P,
+                                                          float* __restrict__ ab) {
+    if (threadIdx.x != 0) return;
+    const size_t base = (size_t)blockIdx.x * T;
+    double A = 0.0, Bq = 0.0;
+    for (int t = T - 1; t >= 0; --t) {
+        const double n = (double)P * (double)(t + 1);
+        const double mu = (double)mr[(base + t) * 2], r = (double)mr[(base + t) * 2 + 1];
+        const double c = -0.5 * r * r * r * rs[(base + t) * 2 + 1];
+        A += (-r * rs[(base + t) * 2] - 2.0 * mu * c) / n;
+        Bq += c / n;
+        *reinterpret_cast<float2*>(&ab[(base + t) * 2]) = make_float2((float)A, (float)(2.0 * Bq));
+    }
+}
+
+__global__ __launch_bounds__(CL_THREADS) void cln_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                   const float* __restrict__ mr, const float* __restrict__ ab,
+                                                                   const float* __restrict__ gain, const float* __restrict__ bias,
+                                                                   const float* __restrict__ slope, const float* __restrict__ acc_in,
+                                                                   float* __restrict__ dx, int P, int C, int mode,
+                                                                   float* __restrict__ part) {
+    __shared__ f32x4 cred[CL_THREADS];
+    const size_t row = blockIdx.x;
+    const float2 m = *reinterpret_cast<const float2*>(&mr[row * 2]);
+    const float2 q = *reinterpret_cast<const float2*>(&ab[row * 2]);
+    f32x4 S = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x * 4; i < P; i += CL_THREADS * 4) {
+        const int c = i % C;
+        const size_t e = row * P + i;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + e), d = *reinterpret_cast<const f32x4*>(dy + e);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gain + c), be = *reinterpret_cast<const f32x4*>(bias + c),
+                    al = *reinterpret_cast<const f32x4*>(slope + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (mode == EAB_XF_NORM_PRELU) {
+                const float u = fmaf((v[j] - m.x) * m.y, g[j], be[j]);
+                const float du = u > 0.f ? d[j] : al[j] * d[j];
+                o[j] = fmaf(du * g[j], m.y, fmaf(v[j], q.y, q.x));
+            } else {
+                const float pv = eab_prelu(v[j], al[j]);
+                const float dv = fmaf(d[j] * g[j], m.y, fmaf(pv, q.y, q.x));
+                o[j] = v[j] > 0.f ? dv : al[j] * dv;
+                S[j] += v[j] > 0.f ? 0.f : dv * v[j];
+            }
+        }
+        if (acc_in) o += *reinterpret_cast<const f32x4*>(acc_in + e);
+        *reinterpret_cast<f32x4*>(dx + e) = o;
+    }
+    if (mode == EAB_XF_PRELU_NORM) cl_channel_reduce(S, cred, C, part + row * 3 * C + 2 * C);
+}
+
+extern "C" int eab_train_cln_bwd_f32(const float* dy, const float* x, const float* mr, const float* gain, const float* bias,
+                                     const float* slope, double* rowsums, float* ab, float* part, const float* acc_in, float* dx,
+                                     int B, int T, int P, int C, int mode, eab_stream_t stream) {
+    EAB_CHECK_ARG(dy && x && mr && gain && bias && slope && rowsums && ab && part && dx);
+    EAB_CHECK_ARG(B > 0 && T > 0 && P > 0 && C > 0 && (P % C) == 0 && (mode == EAB_XF_NORM_PRELU || mode == EAB_XF_PRELU_NORM));
+    EAB_CHECK_ARG((long long)B * T < (1ll << 31) && (long long)B * T * P < (1ll << 40));
+    if ((CL_THREADS * 4) % C != 0) return EAB_EUNSUPPORTED;      // a thread keeps its four channels along the row
+    hipStream_t s = eab_stream(stream);
+    hipLaunchKernelGGL(cln_bwd_rows_kernel, dim3((unsigned)(B * T)), dim3(CL_THREADS), 0, s, dy, x, mr, gain, bias, slope, P, C, mode,
+                       rowsums, part);
+    hipLaunchKernelGGL(cln_bwd_scan_kernel, dim3((unsigned)B), dim3(64), 0, s, rowsums, mr, T, P, ab);
+    hipLaunchKernelGGL(cln_bwd_apply_kernel, dim3((unsigned)(B * T)), dim3(CL_THREADS), 0, s, dy, x, mr, ab, gain, bias, slope, acc_in,
+                       dx, P, C, mode, part);
+    EAB_RETURN_LAUNCH_STATUS();
+}

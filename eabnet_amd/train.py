@@ -42,6 +42,7 @@ from .spec import NetConfig, param_specs
 XF_NORM_PRELU, XF_PRELU_NORM = prg.XF_NORM_PRELU, prg.XF_PRELU_NORM
 (OP_GATHER, OP_IN_STATS, OP_TR_NORM_ACT, OP_NORM_BWD, OP_GLU_BWD, OP_GATE_FWD, OP_GATE_BWD, OP_ADD, OP_RELU_BWD, OP_COLSUM,
  OP_FILTER_SUM, OP_FS_BWD, OP_LN_FWD, OP_LN_BWD, OP_LSTM_TRAIN, OP_LSTM_BWD, OP_WGRAD) = range(16, 33)
+OP_CLN_STATS, OP_CLN_APPLY, OP_CLN_BWD = prg.OP_CLN_STATS, prg.OP_CLN_APPLY, 37      # include/eabnet_hip.h EAB_OP_CLN_*
 NB_SUMS_ZEROED = 0x100   # include/eabnet_hip.h EAB_NB_SUMS_ZEROED
 MLP_LD = 64          # the second Linear of w_dnn is run with its 2M rows padded to one 64-column tile
 TRAIN_BOUND_CACHE = 3   # bound training programs kept per module (LRU over (B, T, F, device, precision))
@@ -49,7 +50,7 @@ TRAIN_BOUND_CACHE = 3   # bound training programs kept per module (LRU over (B, 
 
 def supported(cfg: NetConfig) -> bool:
     return (cfg.bf_type in ("lstm", "cnn") and cfg.topo_type in ("mimo", "miso") and cfg.intra_connect in ("cat", "add")
-            and cfg.norm_type in ("IN", "BN") and 2 * cfg.M <= MLP_LD)
+            and cfg.norm_type in ("IN", "BN", "cLN") and 2 * cfg.M <= MLP_LD)
 
 
 def unsupported_reason(cfg: NetConfig) -> str:
@@ -61,7 +62,7 @@ def unsupported_reason(cfg: NetConfig) -> str:
         why.append(f"topo_type={cfg.topo_type!r}")
     if cfg.intra_connect not in ("cat", "add"):
         why.append(f"intra_connect={cfg.intra_connect!r}")
-    if cfg.norm_type not in ("IN", "BN"):
+    if cfg.norm_type not in ("IN", "BN", "cLN"):
         why.append(f"norm_type={cfg.norm_type!r}")
     if 2 * cfg.M > MLP_LD:
         why.append(f"M={cfg.M} > {MLP_LD // 2}")
@@ -180,6 +181,8 @@ class TrainLowering:
         # the whole batch.  Every tensor is [B][positions][C], channels-last and contiguous, so the batch is ONE virtual
         # utterance of B * positions rows: the InstanceNorm kernels (statistics merge, apply, both backward launches) run
         # unchanged with (B, P) -> (1, B * P).  bn_layers: (norm key, offset of its (mean, rstd) table, C, samples per channel)
+        # cLN (the cumulative LayerNorm NormSwitch means to build, EaBNet.py:696-769): its own statistics / apply / backward ops
+        self.cln = getattr(cfg, "norm_type", "IN") == "cLN"
         self.bn = getattr(cfg, "norm_type", "IN") == "BN"
         self.nB, self.nP = (1, B * T) if self.bn else (B, T)
         self.bn_layers: List[Tuple[str, int, int, int]] = []
@@ -400,6 +403,33 @@ class TrainLowering:
         self.note_bn(norm, mr, 0, C, count * bt)
         return xf, mr
 
+    def cln_unit(self, name: str, raw: TVar, norm: str, act: str, mode: int, add: Optional[TVar] = None) -> TVar:
+        """cumulative LayerNorm + PReLU (either order) [+ add] as statistics + apply ops (eab_cln_stats_f32 / eab_cln_apply_f32,
+        whole utterance) and ONE backward op (eab_train_cln_bwd_f32: row sums, reverse scan over t, apply) followed by the
+        column sum of its per-row parameter-gradient partials"""
+        B, T, C = self.B, self.T, raw.C
+        P = raw.F * C
+        out = self.act(raw.F, C)
+        sums, mr = self.alloc(B * T * 4), self.alloc(B * T * 2)              # [B][T][2] doubles | (cum_mean, rstd)
+        gimg, bimg, simg = self.idx(f"{norm}.norm.gain").reshape(C), self.idx(f"{norm}.norm.bias").reshape(C), self.idx(f"{act}.weight")
+        gain, bias, slp = self.wadd(f"{norm}.norm.gain", gimg), self.wadd(f"{norm}.norm.bias", bimg), self.vec(f"{act}.weight")
+        self.fwd.append(GenOp(OP_CLN_STATS, [raw.ref, slp if mode == XF_PRELU_NORM else None, sums, None, mr], [B, T, P, C], [EPS_IN],
+                              name=name + ".cln_stats"))
+        self.fwd.append(GenOp(OP_CLN_APPLY, [raw.ref, mr, gain, bias, slp, add.ref if add else None, out.ref], [B, T, P, C, mode],
+                              name=name + ".cln"))
+
+        def back():
+            d = self.grad_of(out)
+            if add is not None:
+                self.contribute(add, d)
+            dst, aux = self.grad_target(raw)
+            rs, ab, part = self.alloc(B * T * 4), self.alloc(B * T * 2), self.alloc(B * T * 3 * C)
+            self.bwd.append(GenOp(OP_CLN_BWD, [d, raw.ref, mr, gain, bias, slp, rs, ab, part, aux, dst], [B, T, P, C, mode],
+                                  name=name + ".cln_bwd"))
+            self.colsum(name + ".cln_dparams", part, B * T, 3 * C, [np.concatenate([gimg, bimg, simg.reshape(C)])])
+        self.tape.append(back)
+        return out
+
     def note_bn(self, norm: str, mr: Ref, c0: int, C: int, n: int) -> None:
         """BatchNorm: where this layer's batch (mean, rstd) table lies, for the update of its running buffers"""
         if self.bn:
@@ -423,13 +453,13 @@ class TrainLowering:
         raw = self.act(Fout, Cout)
         bm = self.pick_bm(Fout)
         tiles = conv_tiles(self.T, Fout, bm)
-        stats = self.alloc(self.B * tiles * Cout * 4) if norm else None
+        stats = self.alloc(self.B * tiles * Cout * 4) if (norm and not self.cln) else None
         dump = self.alloc(self.B * self.T * Fout * N) if glu else None
         dts, ios = [a - (kt - 1) for a, _ in taps], [c for _, c in taps]
         self.conv_op(name, srcs, self.wadd(f"{wkey}.w", wimg), self.wadd(f"{wkey}.b", bimg), N, wimg.shape[1], Fin, Fout, Fout, 1, 0,
                      2, dts, ios, prg.EPI_GLU if glu else prg.EPI_LINEAR, raw.ref, Cout, stats, tiles if stats else 0, 0, bm,
                      glu_dump=dump)
-        xf, mr = self.finalize(name + ".in", stats, Cout, tiles, self.T * Fout, norm) if norm else (None, None)
+        xf, mr = self.finalize(name + ".in", stats, Cout, tiles, self.T * Fout, norm) if stats is not None else (None, None)
         rows = self.B * self.T * Fout
 
         def back():
@@ -457,6 +487,8 @@ class TrainLowering:
                 self.dgrad(f"{name}.dgrad", s, dz, N, Fout, launches)
                 c_lo += s.C
         self.tape.append(back)          # before the norm/PReLU closure on the tape = after it in the backward
+        if self.cln and norm:
+            return self.cln_unit(name + ".act", raw, norm, act, XF_NORM_PRELU, add)
         return self.norm_act(name + ".act", raw, norm, act, XF_NORM_PRELU, xf, mr, add)
 
     def conv2d_transposed(self, name: str, srcs: Sequence[TVar], wkey: str, glu: bool, norm: str, act: str,
@@ -476,7 +508,7 @@ class TrainLowering:
         Nos = [(Fout + 1) // 2, Fout // 2]
         bm = self.pick_bm(Nos[0])
         tiles = [conv_tiles(self.T, n, bm) for n in Nos]
-        stats = self.alloc(self.B * sum(tiles) * Cout * 4)
+        stats = None if self.cln else self.alloc(self.B * sum(tiles) * Cout * 4)
         dump = self.alloc(self.B * self.T * Fout * N) if glu else None
         phases = []
         for ph in (0, 1):
@@ -484,10 +516,10 @@ class TrainLowering:
             wimg = self.pack_taps_idx(wn, [a * kf + c for a, c in tp])
             dts, ios = [-a for a, _ in tp], [-(c - ph) // 2 for _, c in tp]
             self.conv_op(f"{name}.ph{ph}", srcs, self.wadd(f"{wkey}.w.ph{ph}", wimg), bref, N, wimg.shape[1], Fin, Fout, Nos[ph], 2, ph,
-                         1, dts, ios, prg.EPI_GLU if glu else prg.EPI_LINEAR, raw.ref, Cout, stats, sum(tiles),
-                         0 if ph == 0 else tiles[0], bm, glu_dump=dump)
+                         1, dts, ios, prg.EPI_GLU if glu else prg.EPI_LINEAR, raw.ref, Cout, stats, sum(tiles) if stats else 0,
+                         (0 if ph == 0 else tiles[0]) if stats else 0, bm, glu_dump=dump)
             phases.append((ph, dts, ios, wimg))
-        xf, mr = self.finalize(name + ".in", stats, Cout, sum(tiles), self.T * Fout, norm)
+        xf, mr = self.finalize(name + ".in", stats, Cout, sum(tiles), self.T * Fout, norm) if stats is not None else (None, None)
         rows = self.B * self.T * Fout
 
         def back():
@@ -510,6 +542,8 @@ class TrainLowering:
                                                               [a for a, _ in taps], [c for _, c in taps])])
                 c_lo += s.C
         self.tape.append(back)
+        if self.cln:
+            return self.cln_unit(name + ".act", raw, norm, act, XF_NORM_PRELU, add)
         return self.norm_act(name + ".act", raw, norm, act, XF_NORM_PRELU, xf, mr, add)
 
     def unet_module(self, pre: str, srcs: Sequence[TVar], scale: int, transposed: bool, in_perm=None) -> TVar:
@@ -583,6 +617,8 @@ class TrainLowering:
     def in1d(self, name: str, raw: TVar, norm: str, act: str) -> TVar:
         """prelu -> InstanceNorm1d (S-TCM order, EaBNet.py:545-547) as ONE launch: statistics, (xf, mr) and the normalised
         tensor (eab_train_in1d_f32); backward = the norm backward of the PRELU_NORM form"""
+        if self.cln:
+            return self.cln_unit(name, raw, norm, act, XF_PRELU_NORM)
         xf, mr = self.alloc(self.nB * raw.C * 2), self.alloc(self.nB * raw.C * 2)
         out = self.act(raw.F, raw.C)
         P = self.nP * raw.F
@@ -596,6 +632,8 @@ class TrainLowering:
         """Two units prelu -> InstanceNorm1d on the SAME input (the branch norms of an S-TCM): one forward launch writing two
         contiguous tensors, one two-launch backward that sums both input gradients"""
         assert len(norms) == 2 and len(acts) == 2
+        if self.cln:      # two separate units on the same input: their input gradients add up through the gradient slot
+            return [self.cln_unit(f"{name}.{v}", raw, norms[v], acts[v], XF_PRELU_NORM) for v in range(2)]
         C = raw.C * 2
         P = self.nP * raw.F
         n = self.nB * P * raw.C

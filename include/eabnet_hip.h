@@ -598,6 +598,14 @@ int eab_wgrad_batch_f32(const eab_wgrad_desc* descs, int n, int stride_bytes, ea
  * ------------------------------------------------------------------------ */
 int eab_cln_stats_f32(const float* x, const float* slope, int B, int T, int P, int C, float eps, double* sums, double* state,
                       float* mr, eab_time_window win, eab_stream_t stream);
+/* Backward of the unit (training; whole utterance): dx = (acc_in ? acc_in : 0) + d loss / d x for y = eab_cln_apply_f32(x, mr,
+ * gain, bias, slope) in `mode`, dy = d loss / d y.  Scratch: rowsums [B][T][2] doubles, ab [B][T][2] floats; part [B*T][3][C]
+ * receives the per-row parameter-gradient sums (gain | bias | slope), to be summed over the rows by eab_colsum_f32 with
+ * N = 3 C.  Three launches (row sums, reverse scan over t, apply).  C must divide 1024.  Reference: autograd of
+ * CumulativeLayerNorm1d / 2d, EaBNet.py:713-733, 752-769. */
+int eab_train_cln_bwd_f32(const float* dy, const float* x, const float* mr, const float* gain, const float* bias,
+                          const float* slope, double* rowsums, float* ab, float* part, const float* acc_in, float* dx,
+                          int B, int T, int P, int C, int mode, eab_stream_t stream);
 int eab_cln_apply_f32(const float* x, const float* mr, const float* gain, const float* bias, const float* slope,
                       const float* add, float* y, int B, int T, int P, int C, int mode, eab_time_window win,
                       eab_stream_t stream);
@@ -610,6 +618,7 @@ int eab_gate_rows_f32(const float* a, const float* r, float* z, int B, int T, in
 #define EAB_OP_CLN_APPLY 34
 #define EAB_OP_GATE_ROWS 35
 #define EAB_OP_GAG_CRM_BWD 36
+#define EAB_OP_CLN_BWD 37   /* eab_train_cln_bwd_f32: p = {dy, x, mr, gain, bias, slope, rowsums, ab, part, acc_in, dx}, i = {B, T, P, C, mode} */
 
 /* struct-layout handshake for foreign-function mirrors of the structs above */
 int eab_sizeof_conv_desc(void);

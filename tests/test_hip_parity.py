@@ -1274,7 +1274,7 @@ def test_hip_training_of_every_constructor_variant_vs_oracle_autograd(dev, name)
     """Every constructor branch of tests/golden/keys_variants.json (plain U-Net, cnn / miso heads, add skips, BatchNorm --
     in train mode, as the reference's trainer runs it --, non-causal S-TCMs and their combinations) trains on the HIP
     programs: output, loss and every parameter gradient against fp64 autograd through the oracle (smooth network: PReLU
-    slopes 1, bar 1e-4 per tensor).  cLN is the one branch left on PyTorch-ROCm operators: it must say so."""
+    slopes 1, bar 1e-4 per tensor).  cLN (cumulative LayerNorm: reverse prefix-scan backward, csrc/cln.hip) included."""
     import eabnet_amd
     from eabnet_amd.spec import NetConfig, param_specs
     from oracle import eabnet_oracle as orc
@@ -1293,11 +1293,6 @@ def test_hip_training_of_every_constructor_variant_vs_oracle_autograd(dev, name)
     net.load_state_dict(P, strict=True)
     net = net.to(dev).train()
     x = torch.from_numpy(paramgen.make_spec_input(B, T, 161, M, 981))
-    if kw.get("norm_type") == "cLN":
-        with pytest.warns(RuntimeWarning, match="cLN"):
-            y = net(x.to(dev))
-        assert net.training_backend == "operators"
-        return
     y = net(x.to(dev))
     assert y.requires_grad and net.training_backend == "hip" and getattr(net, "_train_bound", None), "the HIP path did not engage"
     label = torch.from_numpy(np.random.default_rng(982).standard_normal(tuple(y.shape)).astype(np.float32))

@@ -105,16 +105,11 @@ def _variants(fname):
 
 @pytest.mark.parametrize("name", sorted(_variants("keys_variants.json")))
 def test_every_constructor_variant_lowers_to_training_programs(name):
-    """train.supported() is true for every constructor branch of tests/golden/keys_variants.json except cLN, and the lowering
+    """train.supported() is true for every constructor branch of tests/golden/keys_variants.json, and the lowering
     of each holds the same invariants as the default topology: every trained parameter element gets exactly one gradient
     entry, BatchNorm variants record one (mean, rstd) table per norm for the running-buffer update."""
     e = _variants("keys_variants.json")[name]
     cfg = spec.NetConfig(M=e["M"], **dict(e["kwargs"], p=2, q=2))
-    if cfg.norm_type == "cLN":
-        assert not train.supported(cfg) and "cLN" in train.unsupported_reason(cfg)
-        with pytest.raises(NotImplementedError):
-            train.lower_train(cfg, 2, 20)
-        return
     assert train.supported(cfg) and train.unsupported_reason(cfg) == ""
     prog = train.lower_train(cfg, 2, 20)
     assert (np.asarray(prog.inv) >= 0).all()
