@@ -523,6 +523,12 @@ def main():
                   "min": B_PER_GPU * T * a.steps / max(rank_elapsed), "max": B_PER_GPU * T * a.steps / min(rank_elapsed)},
         "gflop_per_step_algorithmic": 2e-9 * mac_per_frame(MICS) * B_PER_GPU * T,
     }
+    # whole path against the fp32 matrix peak (frames/s x FLOP/frame, summed over the ranks' GPUs)
+    ms_step = out["ms_per_step"]
+    out["whole_path"] = {"achieved_tflops": out["gflop_per_step_algorithmic"] * world / ms_step,
+                         "frac_of_fp32_mfma_peak": out["gflop_per_step_algorithmic"] / ms_step / PEAK_FP32_MFMA_TFLOPS,
+                         "one_step_at_a_time_frac": out["gflop_per_step_algorithmic"]
+                         / out["one_step_at_a_time"]["ms_per_step"] / PEAK_FP32_MFMA_TFLOPS}
 
     # secondary measurement: the same timed protocol with the f16x3 contraction mode
     # (DESIGN.md §4.4).  The headline `value` stays on exact-fp32 arithmetic.
