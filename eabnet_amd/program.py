@@ -1111,9 +1111,11 @@ class GagLowering(Lowering):
     spec_fn = staticmethod(gag_param_specs)
     parallel_chains = True        # False: the three S-TCM chains of a stage back to back (no graph branches)
 
-    def tcm1(self, pre: str, x: Act, dilation: int) -> Act:
+    def tcm1(self, pre: str, x: Act, dilation: int, next_pre: Optional[str] = None, have_in: Optional[dict] = None):
         """GaGNet's single-branch SqueezedTCM (GaGNet.py:303-327): in_conv -> PReLU/norm/dilated conv ->
-        PReLU/norm/out_conv + residual, three launches, InstanceNorm partials reduced by the consumer."""
+        PReLU/norm/out_conv + residual, three launches, InstanceNorm partials reduced by the consumer.  As in Lowering.tcm,
+        the out_conv of one block and the in_conv of the next (`next_pre`) of a chain run as ONE small-tile launch
+        (eab_conv_desc.f2_*); the next call gets the finished in_conv as `have_in`.  Returns (output, have_in or None)."""
         cfg, T, B = self.cfg, self.T, self.B
         D, cd, kd = cfg.d_feat, cfg.cd1, cfg.kd1
         bn = self.bn
@@ -1128,11 +1130,14 @@ class GagLowering(Lowering):
         assert bn or max(tiles, tiles_d) <= 64
         nD, nO = f"{pre}.d_conv.1", f"{pre}.out_conv.1"
         slD, slO = self.vec(f"{pre}.d_conv.0.weight"), self.vec(f"{pre}.out_conv.0.weight")
-        wref = self.W.add(f"{pre}.in_conv.weight#packed", pack_taps(self.P[f"{pre}.in_conv.weight"], [0]))
-        y = self.alloc_act(1, cd)
-        st = None if bn else self.alloc(B * tiles * cd * 4)
-        self.emit_conv(f"{pre}.in_conv", [x], wref, None, cd, D, 1, 1, 1, 0, 1, [0], [0], EPI_LINEAR, y,
-                       st, 0 if bn else 1, (None, None) if bn else (slD, None), 0 if bn else tiles, 0, bm, st=use_st)
+        if have_in is not None:                         # produced by the previous block's fused out_conv launch
+            y, st, tiles = have_in["y"], have_in["st"], have_in["tiles"]
+        else:
+            wref = self.W.add(f"{pre}.in_conv.weight#packed", pack_taps(self.P[f"{pre}.in_conv.weight"], [0]))
+            y = self.alloc_act(1, cd)
+            st = None if bn else self.alloc(B * tiles * cd * 4)
+            self.emit_conv(f"{pre}.in_conv", [x], wref, None, cd, D, 1, 1, 1, 0, 1, [0], [0], EPI_LINEAR, y,
+                           st, 0 if bn else 1, (None, None) if bn else (slD, None), 0 if bn else tiles, 0, bm, st=use_st)
         span = (kd - 1) * dilation
         lead = span if cfg.is_causal else span // 2
         dts = [j * dilation - lead for j in range(kd)]
@@ -1145,15 +1150,27 @@ class GagLowering(Lowering):
                        fin=None if bn else dict(stats=st, tiles=tiles, nsets=1, count=T, norms=[nD]), st=use_st)
         wo = self.W.add(f"{pre}.out_conv.2.weight#packed", pack_taps(self.P[f"{pre}.out_conv.2.weight"], [0]))
         xn = self.alloc_act(1, D)
-        self.emit_conv(f"{pre}.out_conv", [Act(z, 1, cd, self.bn_xf(nO) if bn else None, slO, XF_PRELU_NORM)], wo, None,
-                       D, cd, 1, 1, 1, 0, 1, [0], [0], EPI_ADD, xn, bm=bm_out, aux=x.ref,
-                       fin=None if bn else dict(stats=st2, tiles=tiles_d, nsets=1, count=T, norms=[nO]), st=use_st)
-        return Act(xn, 1, D)
+        op = self.emit_conv(f"{pre}.out_conv", [Act(z, 1, cd, self.bn_xf(nO) if bn else None, slO, XF_PRELU_NORM)], wo, None,
+                            D, cd, 1, 1, 1, 0, 1, [0], [0], EPI_ADD, xn, bm=bm_out, aux=x.ref,
+                            fin=None if bn else dict(stats=st2, tiles=tiles_d, nsets=1, count=T, norms=[nO]), st=use_st)
+        nxt = None
+        tiles_n = conv_tiles(T, 1, bm_out)
+        if use_st and next_pre is not None and self.precision == "f32" and self.fuse_out_in and (bn or tiles_n <= 64):
+            op.f2_w = self.W.add(f"{next_pre}.in_conv.weight#frag2", pack_frag(pack_taps(self.P[f"{next_pre}.in_conv.weight"], [0])))
+            op.f2_dst, op.f2_N = self.alloc_act(1, cd), cd
+            if not bn:
+                op.f2_stats, op.f2_nsets, op.f2_stat_tiles = self.alloc(B * tiles_n * cd * 4), 1, tiles_n
+                op.f2_stat_slope0 = self.vec(f"{next_pre}.d_conv.0.weight")
+            op.name = f"{pre}.out_conv+{next_pre}.in_conv"
+            self.flops += 2 * B * T * cd * D
+            nxt = dict(y=op.f2_dst, st=op.f2_stats, tiles=tiles_n)
+        return Act(xn, 1, D), nxt
 
     def chain(self, pre: str, x: Act) -> Act:
-        for j in range(self.cfg.p):
-            for k, d in enumerate(self.cfg.dilas):
-                x = self.tcm1(f"{pre}.{j}.tcns.{k}", x, d)
+        names = [(f"{pre}.{j}.tcns.{k}", d) for j in range(self.cfg.p) for k, d in enumerate(self.cfg.dilas)]
+        have_in = None
+        for i, (nm, d) in enumerate(names):
+            x, have_in = self.tcm1(nm, x, d, names[i + 1][0] if i + 1 < len(names) else None, have_in)
         return x
 
     def gated_in(self, pfx: str, feat: Act, pre: Act, feat_perm: np.ndarray) -> Act:
