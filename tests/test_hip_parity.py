@@ -765,6 +765,33 @@ def test_streaming_equals_offline_bit_for_bit(dev, chunk, use_graph):
     assert torch.equal(y2, off2)
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_streaming_s_tcn_runs_as_one_chain_launch(dev, precision, monkeypatch):
+    """A frame-synchronous step (BatchNorm norms, chunk <= 16) runs the 1-D convolutions of the whole S-TCN as ONE launch
+    (conv_st_chain_kernel: one workgroup per utterance walks the descriptors; model._Bound._plan_chains): the chain must
+    engage, cover every S-TCN launch, and give the bits of the separate launches (EAB_ST_CHAIN=0) and of the offline call."""
+    from eabnet_amd import program as prg
+    B, T, chunk = 2, 32, 8
+    x = torch.from_numpy(paramgen.make_spec_input(B, T, 161, 4, 610)).to(dev)
+
+    def run(chain: bool):
+        monkeypatch.setenv("EAB_ST_CHAIN", "1" if chain else "0")
+        net = _model(4, 201, dev, norm_type="BN", p=3, q=2)
+        net.precision = precision
+        with torch.no_grad():
+            off = net(x)
+        st = net.stream_begin(B, T_max=T, chunk=chunk)
+        y = torch.cat([st.step(x[:, t:t + chunk]) for t in range(0, T, chunk)], dim=2)
+        return off, y, st.bound
+    off1, y1, b1 = run(True)
+    off0, y0, b0 = run(False)
+    assert b1.chains and not b0.chains, "the chain launch did not engage"
+    stcn = [k for k, o in enumerate(b1.prog.ops) if o.kind == prg.OP_CONV and o.name.startswith("stcns.")]
+    (first, cnt, *_), = b1.chains
+    assert first == stcn[0] and cnt == len(stcn) and b1.n_exec == len(b1.prog.ops) - cnt + 1
+    assert torch.equal(y1, y0) and torch.equal(y1, off1) and torch.equal(off1, off0)
+
+
 def test_streaming_variants_and_refusals(dev):
     """cnn head + plain U-Net encoder stream too; InstanceNorm / non-causal / f16x3 are refused."""
     kw = dict(is_u2=False, norm_type="BN", bf_type="cnn")
