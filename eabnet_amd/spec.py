@@ -280,10 +280,9 @@ class GagConfig:
             bad.append(f"acti_type={self.acti_type!r}")
         if self.intra_connect not in ("cat", "add"):
             bad.append(f"intra_connect={self.intra_connect!r}")
-        if self.norm_type not in ("IN", "BN", "cLN"):
+        # (the post-filter is offered with BN / IN only: train_distributed.py:318 `--gagnet_norm_type`, choices ["BN", "IN"])
+        if self.norm_type not in ("IN", "BN"):
             bad.append(f"norm_type={self.norm_type!r}")
-        if self.norm_type == "cLN" and not (self.is_u2 and self.intra_connect == "cat" and self.is_causal):
-            bad.append("norm_type='cLN' is built for the default topology (U2, 'cat' skips, causal)")
         if tuple(self.k1) != (2, 3) or tuple(self.k2) != (1, 3) or self.c != 64 or self.cd1 != 64:
             bad.append("k1/k2/c/cd1 away from (2,3)/(1,3)/64/64")
         if self.d_feat != self.c_end * 4 or self.fft_num != 320:
