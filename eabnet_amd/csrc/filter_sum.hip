@@ -62,10 +62,27 @@ __global__ __launch_bounds__(256) void bfw_filter_sum_kernel(
     // `bins` counts the TF bins computed.  Streaming window: index j runs over [B][t_count][F] and maps to
     // bin (b*T + *t_pos)*F + rem; rows past the utterance end are dropped.
     const long long per_b = (long long)(t_pos ? t_count : T) * F, p_lo = t_pos ? (long long)*t_pos * F : 0;
-    auto to_bin = [&](long long j) -> long long {
-        if (j >= bins) return -1;
-        const long long b = j / per_b, rem = j - b * per_b;
-        return p_lo + rem < (long long)T * F ? b * T * F + p_lo + rem : -1;
+    // Index j = b * per_b + rem.  (b, rem) of a tile's first row is carried along the grid-stride walk and a row's bin follows
+    // by addition: no integer division anywhere (the 64-bit divisions of the first version -- four per thread and tile in the
+    // fetch, four more in the store -- were several hundred VALU instructions per tile, which this kernel's matrix pipe pays for).
+    const long long TF = (long long)T * F;
+    auto advance = [&](long long& b_, long long& rem_, long long by) {
+        rem_ += by;
+        while (rem_ >= per_b) {
+            rem_ -= per_b;
+            ++b_;
+        }
+    };
+    // bin of row r of the tile that starts at (b_, rem_), index j0 + r; -1: past the end
+    auto row_bin = [&](long long b_, long long rem_, long long j0, int r, long long& bb, long long& pos) -> bool {
+        bb = b_;
+        long long rr = rem_ + r;
+        while (rr >= per_b) {                       // at most once unless a batch element has fewer than 64 bins
+            rr -= per_b;
+            ++bb;
+        }
+        pos = p_lo + rr;
+        return j0 + r < bins && pos < TF;
     };
     // stage weights and activations (float4, coalesced)
     for (int e = tid; e < 2 * M * (BFW_K / 4); e += 256) {
@@ -86,25 +103,32 @@ __global__ __launch_bounds__(256) void bfw_filter_sum_kernel(
     // (4 float4 per thread): the HBM round trip used to sit in front of every tile's MFMAs
     constexpr int TPT = BFW_ROWS * (BFW_K / 4) / 256;
     f32x4 pre[TPT];
-    auto fetch_tile = [&](long long tl) {
+    auto fetch_tile = [&](long long tl, long long b_, long long rem_) {
 #pragma unroll
         for (int k = 0; k < TPT; ++k) {
             const int e = tid + k * 256, r = e / (BFW_K / 4), c4 = e % (BFW_K / 4);
-            const long long bn = tl < ntiles ? to_bin(tl * BFW_ROWS + r) : -1;
+            long long bb, pos;
+            const bool ok = tl < ntiles && row_bin(b_, rem_, tl * BFW_ROWS, r, bb, pos);
             pre[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (bn >= 0) pre[k] = *reinterpret_cast<const f32x4*>(&y1[(size_t)bn * BFW_K + c4 * 4]);
+            if (ok) pre[k] = *reinterpret_cast<const f32x4*>(&y1[(size_t)(bb * TF + pos) * BFW_K + c4 * 4]);
         }
     };
-    fetch_tile(blockIdx.x);
+    long long tb = 0, trem = 0;                      // (b, rem) of this tile's first row
+    advance(tb, trem, (long long)blockIdx.x * BFW_ROWS);
+    long long nb = tb, nrem = trem;                  // ... and of the next tile of the walk
+    fetch_tile(blockIdx.x, tb, trem);
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long long row0 = tile * BFW_ROWS;
+    tb = nb;
+    trem = nrem;
+    advance(nb, nrem, (long long)gridDim.x * BFW_ROWS);
     __syncthreads();                                 // previous tile fully consumed (and weights staged)
 #pragma unroll
     for (int k = 0; k < TPT; ++k) {
         const int e = tid + k * 256, r = e / (BFW_K / 4), c4 = e % (BFW_K / 4);
         *reinterpret_cast<f32x4*>(&ytile[r * (BFW_K + 4) + c4 * 4]) = pre[k];
     }
-    fetch_tile(tile + gridDim.x);
+    fetch_tile(tile + gridDim.x, nb, nrem);
     if (MLP) {
         __syncthreads();
         // y1[row][n] = relu(b1[n] + sum_k h[row][k] W1[n][k]): wave (wm, wn) owns the 32x32 block
@@ -171,8 +195,9 @@ __global__ __launch_bounds__(256) void bfw_filter_sum_kernel(
     }
     // per bin: 4 lanes share a row, lane p takes microphones p, p+4, ..; (wr, wi) come from the wave's own rows of ytile
     const int r = tid >> 2, p = tid & 3;
-    const long long bin = to_bin(row0 + r);
-    const bool valid = bin >= 0;
+    long long ob, opos;
+    const bool valid = row_bin(tb, trem, row0, r, ob, opos);
+    const long long bin = ob * TF + opos;
     const float* yr_ = &ytile[r * (BFW_K + 4)];
     float accr = 0.0f, acci = 0.0f;
     for (int m = p; m < M; m += 4) {
@@ -187,10 +212,9 @@ __global__ __launch_bounds__(256) void bfw_filter_sum_kernel(
     }
     accr += __shfl_xor(accr, 1); acci += __shfl_xor(acci, 1);
     accr += __shfl_xor(accr, 2); acci += __shfl_xor(acci, 2);
-    if (valid && p == 0) {
-        long long f = bin % F, bt = bin / F, t = bt % T, b = bt / T;
-        out[((b * 2 + 0) * T + t) * F + f] = accr;
-        out[((b * 2 + 1) * T + t) * F + f] = acci;
+    if (valid && p == 0) {                           // out[b][ri][t][f], t * F + f = opos
+        out[(ob * 2 + 0) * TF + opos] = accr;
+        out[(ob * 2 + 1) * TF + opos] = acci;
     }
     }   // tile loop
 }
