@@ -61,28 +61,30 @@ __global__ __launch_bounds__(256) void bfw_filter_sum_kernel(
     const int tid = threadIdx.x;
     // `bins` counts the TF bins computed.  Streaming window: index j runs over [B][t_count][F] and maps to
     // bin (b*T + *t_pos)*F + rem; rows past the utterance end are dropped.
-    const long long per_b = (long long)(t_pos ? t_count : T) * F, p_lo = t_pos ? (long long)*t_pos * F : 0;
+    // (32-bit index arithmetic throughout: the host checks B * T * F < 2^31)
+    const int per_b = (t_pos ? t_count : T) * F, p_lo = t_pos ? *t_pos * F : 0;
+    const int nbins = (int)bins;
     // Index j = b * per_b + rem.  (b, rem) of a tile's first row is carried along the grid-stride walk and a row's bin follows
     // by addition: no integer division anywhere (the 64-bit divisions of the first version -- four per thread and tile in the
     // fetch, four more in the store -- were several hundred VALU instructions per tile, which this kernel's matrix pipe pays for).
-    const long long TF = (long long)T * F;
-    auto advance = [&](long long& b_, long long& rem_, long long by) {
+    const int TF = T * F;
+    auto advance = [&](int& b_, int& rem_, int by) {
         rem_ += by;
         while (rem_ >= per_b) {
             rem_ -= per_b;
             ++b_;
         }
     };
-    // bin of row r of the tile that starts at (b_, rem_), index j0 + r; -1: past the end
-    auto row_bin = [&](long long b_, long long rem_, long long j0, int r, long long& bb, long long& pos) -> bool {
+    // bin of row r of the tile that starts at (b_, rem_), index j0 + r; false: past the end
+    auto row_bin = [&](int b_, int rem_, int j0, int r, int& bb, int& pos) -> bool {
         bb = b_;
-        long long rr = rem_ + r;
+        int rr = rem_ + r;
         while (rr >= per_b) {                       // at most once unless a batch element has fewer than 64 bins
             rr -= per_b;
             ++bb;
         }
         pos = p_lo + rr;
-        return j0 + r < bins && pos < TF;
+        return j0 + r < nbins && pos < TF;
     };
     // stage weights and activations (float4, coalesced)
     for (int e = tid; e < 2 * M * (BFW_K / 4); e += 256) {
@@ -98,37 +100,50 @@ __global__ __launch_bounds__(256) void bfw_filter_sum_kernel(
         }
     }
     // the weights stay in LDS while the workgroup walks over its 64-bin tiles (grid-stride)
-    const long long ntiles = (bins + BFW_ROWS - 1) / BFW_ROWS;
+    const int ntiles = (nbins + BFW_ROWS - 1) / BFW_ROWS;
     // the activation tile of the NEXT step of the grid-stride walk is fetched into registers while this one is multiplied
     // (4 float4 per thread): the HBM round trip used to sit in front of every tile's MFMAs
     constexpr int TPT = BFW_ROWS * (BFW_K / 4) / 256;
     f32x4 pre[TPT];
-    auto fetch_tile = [&](long long tl, long long b_, long long rem_) {
+    auto fetch_tile = [&](int tl, int b_, int rem_) {
 #pragma unroll
         for (int k = 0; k < TPT; ++k) {
             const int e = tid + k * 256, r = e / (BFW_K / 4), c4 = e % (BFW_K / 4);
-            long long bb, pos;
+            int bb, pos;
             const bool ok = tl < ntiles && row_bin(b_, rem_, tl * BFW_ROWS, r, bb, pos);
             pre[k] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (ok) pre[k] = *reinterpret_cast<const f32x4*>(&y1[(size_t)(bb * TF + pos) * BFW_K + c4 * 4]);
         }
     };
-    long long tb = 0, trem = 0;                      // (b, rem) of this tile's first row
-    advance(tb, trem, (long long)blockIdx.x * BFW_ROWS);
-    long long nb = tb, nrem = trem;                  // ... and of the next tile of the walk
-    fetch_tile(blockIdx.x, tb, trem);
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long long row0 = tile * BFW_ROWS;
+    int tb = 0, trem = 0;                            // (b, rem) of this tile's first row
+    advance(tb, trem, (int)blockIdx.x * BFW_ROWS);
+    int nb = tb, nrem = trem;                        // ... and of the next tile of the walk
+    fetch_tile((int)blockIdx.x, tb, trem);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row0 = tile * BFW_ROWS;
     tb = nb;
     trem = nrem;
-    advance(nb, nrem, (long long)gridDim.x * BFW_ROWS);
+    advance(nb, nrem, (int)gridDim.x * BFW_ROWS);
     __syncthreads();                                 // previous tile fully consumed (and weights staged)
 #pragma unroll
     for (int k = 0; k < TPT; ++k) {
         const int e = tid + k * 256, r = e / (BFW_K / 4), c4 = e % (BFW_K / 4);
         *reinterpret_cast<f32x4*>(&ytile[r * (BFW_K + 4) + c4 * 4]) = pre[k];
     }
-    fetch_tile(tile + gridDim.x, nb, nrem);
+    fetch_tile(tile + (int)gridDim.x, nb, nrem);
+    // this lane's bin and its microphones' X values (mics p, p+4, p+8, p+12; more are fetched in the tail): requested here so that
+    // the HBM round trip runs under the two matrix products instead of behind them
+    const int r = tid >> 2, p = tid & 3;
+    int ob, opos;
+    const bool valid = row_bin(tb, trem, row0, r, ob, opos);
+    const size_t bin = (size_t)(ob * TF + opos);
+    float2 xpre[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int m = p + 4 * k;
+        xpre[k] = make_float2(0.0f, 0.0f);
+        if (valid && m < M) xpre[k] = reinterpret_cast<const float2*>(x)[bin * M + m];
+    }
     if (MLP) {
         __syncthreads();
         // y1[row][n] = relu(b1[n] + sum_k h[row][k] W1[n][k]): wave (wm, wn) owns the 32x32 block
@@ -194,17 +209,13 @@ __global__ __launch_bounds__(256) void bfw_filter_sum_kernel(
         }
     }
     // per bin: 4 lanes share a row, lane p takes microphones p, p+4, ..; (wr, wi) come from the wave's own rows of ytile
-    const int r = tid >> 2, p = tid & 3;
-    long long ob, opos;
-    const bool valid = row_bin(tb, trem, row0, r, ob, opos);
-    const long long bin = ob * TF + opos;
     const float* yr_ = &ytile[r * (BFW_K + 4)];
     float accr = 0.0f, acci = 0.0f;
-    for (int m = p; m < M; m += 4) {
+    for (int m = p, k = 0; m < M; m += 4, ++k) {
         const float2 wv = *reinterpret_cast<const float2*>(&yr_[2 * m]);
         const float wr = wv.x, wi = wv.y;
         if (valid) {
-            float2 xv = reinterpret_cast<const float2*>(x)[bin * M + m];
+            const float2 xv = k < 4 ? xpre[k < 4 ? k : 0] : reinterpret_cast<const float2*>(x)[bin * M + m];
             accr += wr * xv.x - wi * xv.y;
             acci += wr * xv.y + wi * xv.x;
             if (bfw) reinterpret_cast<float2*>(bfw)[bin * M + m] = make_float2(wr, wi);
@@ -213,8 +224,8 @@ __global__ __launch_bounds__(256) void bfw_filter_sum_kernel(
     accr += __shfl_xor(accr, 1); acci += __shfl_xor(acci, 1);
     accr += __shfl_xor(accr, 2); acci += __shfl_xor(acci, 2);
     if (valid && p == 0) {                           // out[b][ri][t][f], t * F + f = opos
-        out[(ob * 2 + 0) * TF + opos] = accr;
-        out[(ob * 2 + 1) * TF + opos] = acci;
+        out[(size_t)(ob * 2 + 0) * TF + opos] = accr;
+        out[(size_t)(ob * 2 + 1) * TF + opos] = acci;
     }
     }   // tile loop
 }
@@ -238,6 +249,7 @@ extern "C" int eab_mlp_bfw_filter_sum_f32(const float* y1, const float* w1, cons
     EAB_CHECK_ARG((w1 == nullptr) == (b1 == nullptr));
     EAB_CHECK_ARG(win.pos == nullptr || win.count > 0);
     long long bins = (long long)B * (win.pos ? win.count : T) * F;
+    EAB_CHECK_ARG((long long)B * T * F < (1ll << 30));   // 32-bit bin arithmetic in the kernel ((2 b + 1) T F must fit too)
     long long grid = (bins + BFW_ROWS - 1) / BFW_ROWS;
     if (grid > 256 * 4) grid = 256 * 4;              // four resident workgroups per CU walk the tiles
     size_t shmem = (size_t)(BFW_ROWS + 2 * M + (w1 ? BFW_K : 0)) * (BFW_K + 4) * sizeof(float);
