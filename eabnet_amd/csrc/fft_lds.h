@@ -1,5 +1,5 @@
 // Half-length complex FFT in LDS shared by the STFT front end (stft.hip) and the ISTFT back end
-// (istft.hip): Stockham autosort passes of radix 5/4/2 against an exact twiddle table.
+// (istft.hip): Stockham autosort passes of radix 5/4/8/2 against an exact twiddle table.
 #pragma once
 #include "common.h"
 
@@ -41,7 +41,48 @@ __device__ __forceinline__ void fft_pass(const float2* __restrict__ x, float2* _
             o[2] = make_float2(t0.x - t2.x, t0.y - t2.y);
             o[1] = make_float2(t1.x + t3.y, t1.y - t3.x);     // t1 - i t3   (W_4 = -i)
             o[3] = make_float2(t1.x - t3.y, t1.y + t3.x);     // t1 + i t3
-        } else {                                              // generic small radix (5): direct DFT with table twiddles
+        } else if (R == 8) {
+            // radix 8, decimation in frequency: even outputs = DFT4 of the sums, odd outputs = DFT4 of the differences rotated by
+            // W8^j (W8 = exp(-2 pi i / 8) = (1 - i) / sqrt 2, W8^2 = -i, W8^3 = (-1 - i) / sqrt 2)
+            const float h = 0.70710678118654752440f;
+            float2 b[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                b[j] = make_float2(a[j].x + a[j + 4].x, a[j].y + a[j + 4].y);
+                b[j + 4] = make_float2(a[j].x - a[j + 4].x, a[j].y - a[j + 4].y);
+            }
+            b[5] = make_float2(h * (b[5].x + b[5].y), h * (b[5].y - b[5].x));
+            b[6] = make_float2(b[6].y, -b[6].x);
+            b[7] = make_float2(h * (b[7].y - b[7].x), -h * (b[7].x + b[7].y));
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {                     // q = 0: X0, X2, X4, X6;  q = 1: X1, X3, X5, X7
+                const float2* x = b + 4 * q;
+                const float2 t0 = make_float2(x[0].x + x[2].x, x[0].y + x[2].y), t1 = make_float2(x[0].x - x[2].x, x[0].y - x[2].y);
+                const float2 t2 = make_float2(x[1].x + x[3].x, x[1].y + x[3].y), t3 = make_float2(x[1].x - x[3].x, x[1].y - x[3].y);
+                o[q] = make_float2(t0.x + t2.x, t0.y + t2.y);
+                o[q + 4] = make_float2(t0.x - t2.x, t0.y - t2.y);
+                o[q + 2] = make_float2(t1.x + t3.y, t1.y - t3.x);
+                o[q + 6] = make_float2(t1.x - t3.y, t1.y + t3.x);
+            }
+        } else if (R == 5) {
+            // radix 5 with the symmetric / antisymmetric pairs (W = exp(-2 pi i / 5) = tw[TW/5], W^2 = tw[2 TW/5]):
+            //   X0 = a0 + t1 + t2;  X1,4 = m1 -+ i n1;  X2,3 = m2 -+ i n2   with  t1 = a1 + a4, t2 = a2 + a3, t3 = a1 - a4,
+            //   t4 = a2 - a3,  m1 = a0 + c1 t1 + c2 t2,  m2 = a0 + c2 t1 + c1 t2,  n1 = s1 t3 + s2 t4,  n2 = s2 t3 - s1 t4
+            // (~40 flops; the direct 5 x 4 complex products it replaces were 120 and twenty table reads)
+            const float2 w1 = tw[TW / 5], w2 = tw[2 * (TW / 5)];
+            const float c1 = w1.x, s1 = -w1.y, c2 = w2.x, s2 = -w2.y;
+            const float2 t1 = make_float2(a[1].x + a[4].x, a[1].y + a[4].y), t2 = make_float2(a[2].x + a[3].x, a[2].y + a[3].y);
+            const float2 t3 = make_float2(a[1].x - a[4].x, a[1].y - a[4].y), t4 = make_float2(a[2].x - a[3].x, a[2].y - a[3].y);
+            o[0] = make_float2(a[0].x + t1.x + t2.x, a[0].y + t1.y + t2.y);
+            const float2 m1 = make_float2(a[0].x + c1 * t1.x + c2 * t2.x, a[0].y + c1 * t1.y + c2 * t2.y);
+            const float2 m2 = make_float2(a[0].x + c2 * t1.x + c1 * t2.x, a[0].y + c2 * t1.y + c1 * t2.y);
+            const float2 n1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+            const float2 n2 = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+            o[1] = make_float2(m1.x + n1.y, m1.y - n1.x);
+            o[4] = make_float2(m1.x - n1.y, m1.y + n1.x);
+            o[2] = make_float2(m2.x + n2.y, m2.y - n2.x);
+            o[3] = make_float2(m2.x - n2.y, m2.y + n2.x);
+        } else {                                              // generic small radix: direct DFT with table twiddles
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 float2 acc = a[0];
@@ -68,6 +109,7 @@ __device__ __forceinline__ float2* fft_run(float2* src, float2* dst, const float
     for (int ps = 0; ps < plan.npass; ++ps) {
         const int R = plan.radix[ps];
         if (R == 5) fft_pass<5>(src, dst, tw, NT, TW, n, s, tid, nthreads);
+        else if (R == 8) fft_pass<8>(src, dst, tw, NT, TW, n, s, tid, nthreads);
         else if (R == 4) fft_pass<4>(src, dst, tw, NT, TW, n, s, tid, nthreads);
         else fft_pass<2>(src, dst, tw, NT, TW, n, s, tid, nthreads);
         __syncthreads();
@@ -82,7 +124,9 @@ static inline bool fft_plan(int n, FftPlan* p) {
     p->npass = 0;
     // radix 5 first (its generic butterfly is the most expensive one and runs once), then 4s, then a 2
     while (n % 5 == 0 && p->npass < FFT_MAX_PASSES) { p->radix[p->npass++] = 5; n /= 5; }
-    while (n % 4 == 0 && p->npass < FFT_MAX_PASSES) { p->radix[p->npass++] = 4; n /= 4; }
+    // (a trailing 4 . 2 becomes one radix-8 pass: one pass and one barrier fewer, and the last pass has no twiddles)
+    while (n % 4 == 0 && n != 8 && p->npass < FFT_MAX_PASSES) { p->radix[p->npass++] = 4; n /= 4; }
+    if (n == 8) { p->radix[p->npass++] = 8; n = 1; }
     while (n % 2 == 0 && p->npass < FFT_MAX_PASSES) { p->radix[p->npass++] = 2; n /= 2; }
     return n == 1;
 }

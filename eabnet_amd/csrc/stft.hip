@@ -123,15 +123,33 @@ __global__ __launch_bounds__(STFT_THREADS) void stft_fft_kernel(
     for (int m0 = 0; m0 < M; m0 += FFT_SIGS) {
         __syncthreads();
         // gather + window: z_mm[n/2].(re|im) = w[n] x_mm[reflect(t hop + n)]; consecutive threads -> consecutive samples
-        for (int e = tid; e < FFT_SIGS * n_fft; e += STFT_THREADS) {
-            const int mm = e / n_fft, n = e - mm * n_fft;
-            float v = 0.0f;
-            if (m0 + mm < M) v = window[n] * wav[((size_t)b * M + m0 + mm) * L + reflect_index(t * hop + n, NH, L)];
-            reinterpret_cast<float*>(buf0)[mm * n_fft + n] = v;           // float index 2*(n/2) + (n&1) = n
+        const int first = t * hop - NH;                                   // first sample of the frame (reflect padding: may be < 0)
+        if (first >= 0 && first + n_fft <= L && ((first | L | n_fft) & 3) == 0) {
+            // interior frame (all but the first and last of an utterance): no reflection, four samples per load
+            const int n4 = n_fft >> 2;
+            for (int e = tid; e < FFT_SIGS * n4; e += STFT_THREADS) {
+                const int mm = e / n4, q = e - mm * n4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (m0 + mm < M) {
+                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(&wav[((size_t)b * M + m0 + mm) * L + first + 4 * q]);
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(&window[4 * q]);
+                    v = f32x4{w4[0] * x4[0], w4[1] * x4[1], w4[2] * x4[2], w4[3] * x4[3]};
+                }
+                *reinterpret_cast<f32x4*>(&reinterpret_cast<float*>(buf0)[mm * n_fft + 4 * q]) = v;
+            }
+        } else {
+            for (int e = tid; e < FFT_SIGS * n_fft; e += STFT_THREADS) {
+                const int mm = e / n_fft, n = e - mm * n_fft;
+                float v = 0.0f;
+                if (m0 + mm < M) v = window[n] * wav[((size_t)b * M + m0 + mm) * L + reflect_index(t * hop + n, NH, L)];
+                reinterpret_cast<float*>(buf0)[mm * n_fft + n] = v;       // float index 2*(n/2) + (n&1) = n
+            }
         }
         __syncthreads();
         const float2* src;
-        if (NFFT_CT == 320) {                                 // 160 = 5 * 4 * 4 * 2 (what fft_plan gives), unrolled with constant sizes
+        if (NFFT_CT == 320) {                                 // 160 = 5 * 4 * 4 * 2, unrolled with constant sizes
+            // (fft_plan would end in one radix-8 pass; here -- 8 signals per workgroup at six workgroups per CU -- it measured
+            // slower, 48 vs 37 us: 160 of 256 threads busy and the registers of an 8-point butterfly cost a wave of occupancy)
             fft_pass<5>(buf0, buf1, tw, 160, 320, 160, 1, tid, STFT_THREADS);
             __syncthreads();
             fft_pass<4>(buf1, buf0, tw, 160, 320, 32, 5, tid, STFT_THREADS);
@@ -157,8 +175,10 @@ __global__ __launch_bounds__(STFT_THREADS) void stft_fft_kernel(
             const float2 wo = cmul(w, O);
             const float re = E.x + wo.x, im = E.y + wo.y;
             // sqrt-magnitude compression with the phase kept: X * |X|^-1/2, 0 -> 0
-            const float mag = sqrtf(re * re + im * im);
-            const float sc = mag > 0.0f ? 1.0f / sqrtf(mag) : 0.0f;
+            // |X|^-1/2 = (re^2 + im^2)^-1/4 on the hardware rsq / sqrt (1 ulp each; the IEEE sqrtf and division sequences this
+            // replaces were ~40 VALU instructions per bin); p = 0 or denormal -> 0
+            const float p2 = re * re + im * im;
+            const float sc = p2 > 1e-37f ? __builtin_amdgcn_sqrtf(__builtin_amdgcn_rsqf(p2)) : 0.0f;
             if (layout == EAB_STFT_LAYOUT_BTFM2) {
                 *reinterpret_cast<float2*>(&out[((((size_t)b * T + t) * F + f) * M + m) * 2]) = make_float2(re * sc, im * sc);
             } else {                                        // (B,2,T,F), M == 1
