@@ -11,7 +11,7 @@
 // silent microphone gives exactly 0 as in the reference and no rounding noise
 // leaks across channels (sqrt-compression would amplify 1e-8 to 1e-4).  The
 // n_fft/2-point complex FFT is a Stockham autosort chain of radix-5/4/2 passes
-// in LDS (160 = 5*4*4*2) against an exact (host, fp64-rounded) twiddle table, so the
+// in LDS (160 = 5*4*8) against an exact (host, fp64-rounded) twiddle table, so the
 // kernel does ~6.6 kFLOP per frame and mic and is bound by its HBM traffic
 // (5,120 B read + 20,608 B written per frame at M = 8).  Sizes that do not
 // factor into {5,4,2} fall back to a direct DFT kernel.
@@ -154,11 +154,9 @@ __global__ __launch_bounds__(STFT_THREADS) void stft_fft_kernel(
             __syncthreads();
             fft_pass<4>(buf1, buf0, tw, 160, 320, 32, 5, tid, STFT_THREADS);
             __syncthreads();
-            fft_pass<4>(buf0, buf1, tw, 160, 320, 8, 20, tid, STFT_THREADS);
+            fft_pass<8>(buf0, buf1, tw, 160, 320, 8, 20, tid, STFT_THREADS);
             __syncthreads();
-            fft_pass<2>(buf1, buf0, tw, 160, 320, 2, 80, tid, STFT_THREADS);
-            __syncthreads();
-            src = buf0;
+            src = buf1;
         } else {
             src = fft_run(buf0, buf1, tw, NH, n_fft, plan, tid, STFT_THREADS);
         }
@@ -208,9 +206,9 @@ extern "C" int eab_stft_compress_f32(const float* wav, const float* window, cons
     FftPlan plan;
     if (fft_plan(n_fft / 2, &plan)) {
         const size_t sh = (size_t)(2 * n_fft + 2 * FFT_SIGS * n_fft) * sizeof(float);
-        const bool ref_plan = n_fft == 320 && hop == 160 && plan.npass == 4 && plan.radix[0] == 5 && plan.radix[1] == 4 &&
-                              plan.radix[2] == 4 && plan.radix[3] == 2;
-        if (ref_plan)
+        // the reference front end (fft 320, hop 160) has its own instance: every size a constant, its passes written out
+        // (independent of what fft_plan picks for the generic kernel)
+        if (n_fft == 320 && hop == 160)
             hipLaunchKernelGGL((stft_fft_kernel<320, 160>), dim3(B * T), dim3(STFT_THREADS), sh, eab_stream(stream), wav, window,
                                twiddle, out, M, L, n_fft, hop, T, layout, plan);
         else
