@@ -4,31 +4,45 @@
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// one thread per TF bin; W and X rows are M*2 contiguous floats (64 B at M=8).
+// Four lanes per TF bin: lane p multiplies microphones p, p+4, ... and the quad is reduced with two xor-shuffles, so a wave
+// reads 16 bins x M x 8 B = one contiguous block of W and of X per load (one thread per bin -- the first version -- had every
+// lane walk its own 64-byte row, and paid four emulated 64-bit divisions per bin for the (b, t, f) of the store).
+// 32-bit bin arithmetic (host check), one division per stored bin.
 __global__ __launch_bounds__(256) void filter_sum_kernel(const float* __restrict__ w, const float* __restrict__ x,
-                                                         float* __restrict__ y, int T, int F, int M, long long bins) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < bins;
-         i += (long long)gridDim.x * blockDim.x) {
-        const float2* wp = reinterpret_cast<const float2*>(w) + i * M;
-        const float2* xp = reinterpret_cast<const float2*>(x) + i * M;
+                                                         float* __restrict__ y, unsigned TF, int M, unsigned bins) {
+    const unsigned p = threadIdx.x & 3, stride = gridDim.x * 64u;
+    for (unsigned base = blockIdx.x * 64u; base < bins; base += stride) {       // workgroup-uniform trip count
+        const unsigned bin = base + (threadIdx.x >> 2);
+        const bool valid = bin < bins;
+        const float2* wp = reinterpret_cast<const float2*>(w) + (size_t)bin * M;
+        const float2* xp = reinterpret_cast<const float2*>(x) + (size_t)bin * M;
         float yr = 0.0f, yi = 0.0f;
-        for (int m = 0; m < M; ++m) {
-            float2 a = wp[m], c = xp[m];
-            yr += a.x * c.x - a.y * c.y;
-            yi += a.x * c.y + a.y * c.x;
+        if (valid) {
+            for (int m = p; m < M; m += 4) {
+                const float2 a = wp[m], c = xp[m];
+                yr += a.x * c.x - a.y * c.y;
+                yi += a.x * c.y + a.y * c.x;
+            }
         }
-        long long f = i % F, bt = i / F, t = bt % T, b = bt / T;
-        y[((b * 2 + 0) * T + t) * F + f] = yr;
-        y[((b * 2 + 1) * T + t) * F + f] = yi;
+        yr += __shfl_xor(yr, 1); yi += __shfl_xor(yi, 1);
+        yr += __shfl_xor(yr, 2); yi += __shfl_xor(yi, 2);
+        if (valid && p == 0) {                             // y[b][ri][t][f]: t * F + f = bin - b * TF
+            const unsigned b = bin / TF, pos = bin - b * TF;
+            y[(size_t)(2 * b) * TF + pos] = yr;
+            y[(size_t)(2 * b + 1) * TF + pos] = yi;
+        }
     }
 }
 
 extern "C" int eab_filter_sum_f32(const float* w, const float* x, float* y, int B, int T, int F, int M,
                                   eab_stream_t stream) {
     EAB_CHECK_ARG(w && x && y && B > 0 && T > 0 && F > 0 && M > 0);
-    long long bins = (long long)B * T * F;
-    int grid = (int)((bins + 255) / 256 < 8192 ? (bins + 255) / 256 : 8192);
-    hipLaunchKernelGGL(filter_sum_kernel, dim3(grid), dim3(256), 0, eab_stream(stream), w, x, y, T, F, M, bins);
+    const long long bins = (long long)B * T * F;
+    EAB_CHECK_ARG(bins < (1ll << 30));                     // 32-bit bin arithmetic in the kernel
+    const long long tiles = (bins + 63) / 64;
+    const int grid = (int)(tiles < 256 * 8 ? tiles : 256 * 8);
+    hipLaunchKernelGGL(filter_sum_kernel, dim3(grid), dim3(256), 0, eab_stream(stream), w, x, y, (unsigned)((long long)T * F), M,
+                       (unsigned)bins);
     EAB_RETURN_LAUNCH_STATUS();
 }
 

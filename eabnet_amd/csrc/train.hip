@@ -712,43 +712,62 @@ extern "C" int eab_colsum_f32(const float* x, float* out, long long rows, int N,
 //   Yr = sum_m Wr Xr - Wi Xi,  Yi = sum_m Wr Xi + Wi Xr   =>   dWr = dYr Xr + dYi Xi,  dWi = dYi Xr - dYr Xi
 //   dout [B][2][T][F], x [B][T][F][M][2] -> dw [B][T][F][ld] (first 2M columns, the rest zero)
 // ---------------------------------------------------------------------------------------------------
+// Four lanes per TF bin (lane p: microphones p, p+4, ...), 32-bit bin arithmetic with one division per bin: see
+// filter_sum_kernel (csrc/filter_sum.hip) -- one thread per bin with four 64-bit divisions was the first version of these too.
 __global__ __launch_bounds__(TR_THREADS) void filter_sum_ld_kernel(const float* __restrict__ w, const float* __restrict__ x,
-                                                                   float* __restrict__ y, int T, int F, int M, int ld, long long bins) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < bins; i += (long long)gridDim.x * blockDim.x) {
-        const float2* wp = reinterpret_cast<const float2*>(w + i * ld);
-        const float2* xp = reinterpret_cast<const float2*>(x) + i * M;
+                                                                   float* __restrict__ y, unsigned TF, int M, int ld, unsigned bins) {
+    const unsigned p = threadIdx.x & 3, stride = gridDim.x * (TR_THREADS / 4);
+    for (unsigned base = blockIdx.x * (TR_THREADS / 4); base < bins; base += stride) {   // workgroup-uniform trip count
+        const unsigned bin = base + (threadIdx.x >> 2);
+        const bool valid = bin < bins;
+        const float2* wp = reinterpret_cast<const float2*>(w + (size_t)bin * ld);
+        const float2* xp = reinterpret_cast<const float2*>(x) + (size_t)bin * M;
         float yr = 0.0f, yi = 0.0f;
-        for (int m = 0; m < M; ++m) {
-            const float2 a = wp[m], c = xp[m];
-            yr += a.x * c.x - a.y * c.y;
-            yi += a.x * c.y + a.y * c.x;
+        if (valid) {
+            for (int m = p; m < M; m += 4) {
+                const float2 a = wp[m], c = xp[m];
+                yr += a.x * c.x - a.y * c.y;
+                yi += a.x * c.y + a.y * c.x;
+            }
         }
-        const long long f = i % F, bt = i / F, t = bt % T, b = bt / T;
-        y[((b * 2 + 0) * T + t) * F + f] = yr;
-        y[((b * 2 + 1) * T + t) * F + f] = yi;
+        yr += __shfl_xor(yr, 1); yi += __shfl_xor(yi, 1);
+        yr += __shfl_xor(yr, 2); yi += __shfl_xor(yi, 2);
+        if (valid && p == 0) {
+            const unsigned b = bin / TF, pos = bin - b * TF;
+            y[(size_t)(2 * b) * TF + pos] = yr;
+            y[(size_t)(2 * b + 1) * TF + pos] = yi;
+        }
     }
 }
 
 __global__ __launch_bounds__(TR_THREADS) void filter_sum_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x,
-                                                                    float* __restrict__ dw, int T, int F, int M, int ld, long long bins) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < bins; i += (long long)gridDim.x * blockDim.x) {
-        const long long f = i % F, bt = i / F, t = bt % T, b = bt / T;
-        const float dr = dout[((b * 2 + 0) * T + t) * F + f], di = dout[((b * 2 + 1) * T + t) * F + f];
-        const float2* xp = reinterpret_cast<const float2*>(x) + i * M;
-        float2* wp = reinterpret_cast<float2*>(dw + i * ld);
-        for (int m = 0; m < M; ++m) {
+                                                                    float* __restrict__ dw, unsigned TF, int M, int ld, unsigned bins) {
+    const unsigned p = threadIdx.x & 3;
+    for (unsigned bin = blockIdx.x * (TR_THREADS / 4) + (threadIdx.x >> 2); bin < bins; bin += gridDim.x * (TR_THREADS / 4)) {
+        const unsigned b = bin / TF, pos = bin - b * TF;
+        const float dr = dout[(size_t)(2 * b) * TF + pos], di = dout[(size_t)(2 * b + 1) * TF + pos];
+        const float2* xp = reinterpret_cast<const float2*>(x) + (size_t)bin * M;
+        float2* wp = reinterpret_cast<float2*>(dw + (size_t)bin * ld);
+        for (int m = p; m < M; m += 4) {
             const float2 c = xp[m];
             wp[m] = make_float2(dr * c.x + di * c.y, di * c.x - dr * c.y);
         }
-        for (int m = M; m < ld / 2; ++m) wp[m] = make_float2(0.0f, 0.0f);       // padding columns of the row
+        for (int m = M + p; m < ld / 2; m += 4) wp[m] = make_float2(0.0f, 0.0f);   // padding columns of the row
     }
+}
+
+static inline unsigned fs_grid(long long bins) {
+    const long long tiles = (bins + TR_THREADS / 4 - 1) / (TR_THREADS / 4);
+    return (unsigned)(tiles < 256 * 8 ? tiles : 256 * 8);
 }
 
 // w rows of `ld` floats (the first 2M used): the training program keeps the beam-forming weights in a 64-column tile
 extern "C" int eab_filter_sum_ld_f32(const float* w, const float* x, float* y, int B, int T, int F, int M, int ld, eab_stream_t stream) {
     EAB_CHECK_ARG(w && x && y && B > 0 && T > 0 && F > 0 && M > 0 && ld >= 2 * M && (ld % 2) == 0);
     const long long bins = (long long)B * T * F;
-    hipLaunchKernelGGL(filter_sum_ld_kernel, dim3(flat_grid(bins)), dim3(TR_THREADS), 0, eab_stream(stream), w, x, y, T, F, M, ld, bins);
+    EAB_CHECK_ARG(bins < (1ll << 30));
+    hipLaunchKernelGGL(filter_sum_ld_kernel, dim3(fs_grid(bins)), dim3(TR_THREADS), 0, eab_stream(stream), w, x, y,
+                       (unsigned)((long long)T * F), M, ld, (unsigned)bins);
     EAB_RETURN_LAUNCH_STATUS();
 }
 
@@ -756,7 +775,9 @@ extern "C" int eab_filter_sum_bwd_f32(const float* dout, const float* x, float* 
                                       eab_stream_t stream) {
     EAB_CHECK_ARG(dout && x && dw && B > 0 && T > 0 && F > 0 && M > 0 && ld >= 2 * M && (ld % 2) == 0);
     const long long bins = (long long)B * T * F;
-    hipLaunchKernelGGL(filter_sum_bwd_kernel, dim3(flat_grid(bins)), dim3(TR_THREADS), 0, eab_stream(stream), dout, x, dw, T, F, M, ld, bins);
+    EAB_CHECK_ARG(bins < (1ll << 30));
+    hipLaunchKernelGGL(filter_sum_bwd_kernel, dim3(fs_grid(bins)), dim3(TR_THREADS), 0, eab_stream(stream), dout, x, dw,
+                       (unsigned)((long long)T * F), M, ld, (unsigned)bins);
     EAB_RETURN_LAUNCH_STATUS();
 }
 
