@@ -209,7 +209,7 @@ __global__ __launch_bounds__(TR_THREADS) void tr_norm_act_kernel(const float* __
     const unsigned C4 = (unsigned)C >> 2, n4 = (unsigned)P * C4, b = blockIdx.y;
     const size_t base = (size_t)b * n4;
     for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < n4; r += gridDim.x * blockDim.x) {
-        const int c = (int)(r % C4) * 4;
+        const int c = (int)(((C4 & (C4 - 1)) == 0) ? (r & (C4 - 1)) : (r % C4)) * 4;   // (64 / 128 / 256 channels: a mask)
         const f32x4 v = reinterpret_cast<const f32x4*>(x)[base + r];
         // xf == NULL: no norm in front of the PReLU (the plain U-Net's middle encoder layers, EaBNet.py:219-226)
         const f32x4 one0 = {1.f, 0.f, 1.f, 0.f};
@@ -550,12 +550,15 @@ extern "C" int eab_train_norm_bwd_multi_f32(const float* dy0, const float* dy1, 
 // holds a and s in the PACKED column order of the convolution (column r: half = (r%64)/32 (0 = value, 1 = gate),
 // channel c = (r/64)*32 + r%32).  dz (same packed order, N = 2*Cout columns) = (dy*s | dy*a*s*(1-s)).
 // ---------------------------------------------------------------------------------------------------
+// (LG4 >= 0: N / 4 = 1 << LG4 -- every width the networks use -- so the row of a float4 is a shift; the emulated 64-bit
+// division of the generic form costs more VALU work than the rest of the loop body)
+template <int GENERIC>
 __global__ __launch_bounds__(TR_THREADS) void glu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dump,
-                                                             float* __restrict__ dz, long long rows, int N) {
+                                                             float* __restrict__ dz, long long rows, int N, int lg4) {
     const int Cout = N >> 1, N4 = N >> 2;
     const long long n4 = rows * N4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-        const long long row = i / N4;
+        const long long row = GENERIC ? i / N4 : i >> lg4;
         const int r = (int)(i - row * N4) * 4;                 // first packed column of this float4 (same half, same 32-group)
         const int half = (r & 63) >> 5, c = (r >> 6) * 32 + (r & 31);
         const int mate = half ? r - 32 : r + 32;               // packed column of the partner (gate <-> value)
@@ -573,7 +576,12 @@ extern "C" int eab_glu_bwd_f32(const float* dy, const float* dump, float* dz, lo
     EAB_CHECK_ARG(dy && dump && dz && rows > 0 && N > 0 && (N % 64) == 0);
     long long g = (rows * (N / 4) + TR_THREADS - 1) / TR_THREADS;
     if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(glu_bwd_kernel, dim3((unsigned)g), dim3(TR_THREADS), 0, eab_stream(stream), dy, dump, dz, rows, N);
+    const int N4 = N / 4;
+    if ((N4 & (N4 - 1)) == 0)
+        hipLaunchKernelGGL(glu_bwd_kernel<0>, dim3((unsigned)g), dim3(TR_THREADS), 0, eab_stream(stream), dy, dump, dz, rows, N,
+                           __builtin_ctz(N4));
+    else
+        hipLaunchKernelGGL(glu_bwd_kernel<1>, dim3((unsigned)g), dim3(TR_THREADS), 0, eab_stream(stream), dy, dump, dz, rows, N, 0);
     EAB_RETURN_LAUNCH_STATUS();
 }
 
