@@ -1,0 +1,44 @@
+"""The bench line's contract (driver + judge read it): checked on the committed line of the round's final run, and on bench.py's
+source for the flags the driver passes.  No GPU."""
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line():
+    with open(os.path.join(ROOT, "profiles", "r03_bench_final.json")) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    j = _line()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["unit"] == "frames/s" and j["higher_is_better"] is True and j["scaling"] == "weak" and j["data"] == "synthetic"
+    assert j["dtype"] == "f32" and j["vs_baseline"] is None and "workload" in j["config"] and "model" not in j["config"]
+    # value = frames of all steps / time, consistent with ms_per_step
+    frames_per_step = j["config"]["global_batch"] * j["config"]["frames_per_utt"]
+    assert abs(j["value"] - frames_per_step / (j["ms_per_step"] * 1e-3)) <= 1e-6 * j["value"]
+    r = j["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["traffic"] is None or r["traffic"] > 0
+    # achieved = algorithmic flops per launch / average launch duration
+    assert abs(r["achieved"] - r["algorithmic_gflop_per_launch"] / r["avg_launch_ms"]) <= 1e-6 * r["achieved"]
+    c = j["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    # configs[3] inside the driver-timed line, every configuration with its in-run check
+    tr = j["next_rows"]["training"]
+    for k in ("beam_former_f32", "beam_former_bf16", "two_stage_f32", "two_stage_bf16"):
+        assert tr[k]["check"]["ok"] and tr[k]["check"]["hip_programs_engaged"] and tr[k]["ms_per_step"] > 0
+
+
+def test_bench_accepts_the_drivers_flags_and_reads_the_rendezvous_from_the_environment():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert re.search(r'add_argument\("%s"' % flag, src), flag
+    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        assert var in src or var in open(os.path.join(ROOT, "eabnet_amd", "dist.py")).read(), var
