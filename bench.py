@@ -132,21 +132,31 @@ def cpu_baseline(state, M: int, L: int, budget_s: float = 15.0):
 _CALIBRATED: list = []
 
 
+def _operator_path():
+    """tests/operator_path.py: the PyTorch-ROCm operator evaluation of the networks, a comparator (in-run loss check of the
+    training rows, --train-operator-path); the package itself has no such backend"""
+    tdir = os.path.join(ROOT, "tests")
+    if tdir not in sys.path:
+        sys.path.insert(0, tdir)
+    import operator_path
+    return operator_path
+
+
 def train_measure(rank, world, dev, is_dist, *, precision="f32", two_stage=False, operator_path=False, ddp=False,
                   steps=5, warmup=2, per_op="", roofline=True, check=False):
     """BASELINE configs[3] / train_distributed.py:214-230: per step prepare_data (noisy + target STFT) -> net(noisy) ->
     com_mag_mse_loss (two_stage: eabnet_with_postnet_loss of the model train_distributed.py:181 builds) -> backward ->
     clip_grad_norm_(1.0) -> Adam(5e-4), forward and backward on the HIP training programs (eabnet_amd/train.py, train_gag.py),
     gradients averaged over the ranks.  Returns the result dict of one configuration (nothing is printed).
-    check=True: before the timed steps, the loss of the first step is compared with the PyTorch-ROCm operator path
-    (autograd_path.py) on the same parameters and batch, and every gradient must be finite."""
+    check=True: before the timed steps, the loss of the first step is compared with the PyTorch-ROCm operator comparator
+    (tests/operator_path.py -- test infrastructure, never timed in the default run) on the same parameters and batch, and
+    every gradient must be finite.  operator_path=True times that comparator instead (the --train-operator-path line)."""
     from eabnet_amd import train as tr
     B, M, seconds = 6, MICS, 6.0                            # train_distributed.py:273,279 (batch 6, wav_len 6 s)
     L = int(seconds * SR)
     T = 1 + L // HOP
     net, _ = make_model(M, dev)
     net.train()
-    net.use_hip_training = not operator_path
     net.precision = "bf16" if precision == "bf16" else "f32"
     two = None
     if two_stage:
@@ -162,7 +172,6 @@ def train_measure(rank, world, dev, is_dist, *, precision="f32", two_stage=False
         torch.manual_seed(1)
         two = eabnet_amd.make_eabnet_with_postnet(pa).to(dev).train()
         two.eabnet.load_state_dict(net.state_dict(), strict=True)
-        two.eabnet.use_hip_training = two.postnet.use_hip_training = net.use_hip_training
         two.eabnet.precision = two.postnet.precision = net.precision
         net = two.eabnet
     pd_args = argparse.Namespace(mics=M, sr=SR, wav_len=seconds, win_size=0.020, win_shift=0.010, fft_num=N_FFT)
@@ -177,18 +186,23 @@ def train_measure(rank, world, dev, is_dist, *, precision="f32", two_stage=False
     elif is_dist:
         tr.broadcast_parameters(net)
         if ddp:
-            model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[dev.index], bucket_cap_mb=64,
+            inner = _operator_path().OperatorPath(net) if operator_path else net
+            model = torch.nn.parallel.DistributedDataParallel(inner, device_ids=[dev.index], bucket_cap_mb=64,
                                                               gradient_as_bucket_view=True, static_graph=True)
         else:
             tr.enable_flat_allreduce(net)
     trained = two if two is not None else net
     opt = torch.optim.Adam(trained.parameters(), lr=5e-4)
     frames_list = [T] * B
+    # the PyTorch-ROCm operator evaluation of the same modules on the same parameter objects (comparator only)
+    op_fwd = _operator_path().OperatorPath(trained) if (operator_path or check) else None
 
-    def loss_of(noisy, target):
+    def loss_of(noisy, target, fwd=None):
+        if fwd is None:
+            fwd = (op_fwd if model is net else model) if operator_path else (two if two is not None else model)
         if two is not None:
-            return eabnet_amd.eabnet_with_postnet_loss(two(noisy), target, frames_list)["final"]
-        return eabnet_amd.com_mag_mse_loss(model(noisy), target, frames_list)
+            return eabnet_amd.eabnet_with_postnet_loss(fwd(noisy), target, frames_list)["final"]
+        return eabnet_amd.com_mag_mse_loss(fwd(noisy), target, frames_list)
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -211,11 +225,7 @@ def train_measure(rank, world, dev, is_dist, *, precision="f32", two_stage=False
         n_grads = sum(1 for p in trained.parameters() if p.grad is not None)
         mods = [two.eabnet, two.postnet] if two is not None else [net]
         hip_engaged = all(m_.training_backend == "hip" for m_ in mods)
-        for m_ in mods:
-            m_.use_hip_training = False
-        l_op = loss_of(noisy, target)                      # operator path (needs grad mode to be taken; no backward)
-        for m_ in mods:
-            m_.use_hip_training = True
+        l_op = loss_of(noisy, target, op_fwd)              # operator comparator, same parameters and batch (no backward)
         rel = abs(float(l_hip.detach()) - float(l_op.detach())) / max(abs(float(l_op.detach())), 1e-12)
         tol = 1e-4 if precision == "f32" else 5e-2
         checked = {"loss_hip": float(l_hip.detach()), "loss_operator_path": float(l_op.detach()), "rel_diff": rel, "tolerance": tol,
@@ -263,7 +273,7 @@ def train_measure(rank, world, dev, is_dist, *, precision="f32", two_stage=False
             out["check"] = checked
         return out
     if operator_path:
-        return {"mode": "training step on PyTorch-ROCm operators (autograd_path.py): comparison line", "value": frames / elapsed,
+        return {"mode": "training step on PyTorch-ROCm operators (tests/operator_path.py): comparison line", "value": frames / elapsed,
                 "unit": "frames/s (trained)", "n_gpus": world, "steps": steps, "ms_per_step": 1e3 * elapsed / steps,
                 "final_loss": float(loss.detach())}
     bound = next(reversed(net._train_bound.values()))
@@ -413,7 +423,7 @@ def main():
                     help="with --train: the two-stage model of train_distributed.py (beam-former + GaGNet post-filter, both on "
                          "their HIP training programs; --gpus N: one flat RCCL all-reduce per stage and step)")
     ap.add_argument("--train-operator-path", action="store_true",
-                    help="with --train: forward/backward on PyTorch-ROCm operators (autograd_path.py, MIOpen) -- the comparison line")
+                    help="with --train: forward/backward on PyTorch-ROCm operators (tests/operator_path.py, MIOpen) -- the comparison line")
     ap.add_argument("--train-ddp", action="store_true", help="with --train: wrap in torch DistributedDataParallel (one 64 MB bucket, "
                                                              "gradient_as_bucket_view, static_graph) instead of the flat all-reduce")
     a = ap.parse_args()

@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libeabnet_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_TAPS = 16
 _fp = C.POINTER(C.c_float)
 
@@ -77,7 +77,7 @@ _SIGS = {
     "eab_abi_version": (C.c_int, []),
     "eab_error_string": (C.c_char_p, [C.c_int]),
     "eab_stft_compress_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]),
-    "eab_stft_frames_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
+    "eab_stft_frames_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 5 + [C.c_void_p]),
     "eab_filter_sum_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
     "eab_istft_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
     "eab_norm_act_win_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [TimeWindow, C.c_void_p]),

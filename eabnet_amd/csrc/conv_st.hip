@@ -25,6 +25,7 @@
 // Every output row is one fmaf chain in a fixed k order, independent of the tile it falls into: streamed frames stay
 // bit-identical to the offline pass (eab_time_window), as with conv_gemm_kernel.
 #include "common.h"
+#include <atomic>
 #include <type_traits>
 
 #define ST_THREADS 256
@@ -98,8 +99,15 @@ struct StTables {
     double fin[3][ST_THREADS];   // slice partials of the in-kernel InstanceNorm finalisation
 };
 
+// workgroups per CU the register budget is cut for: two, except where 160 registers of resident weights (N = 128, K up to
+// 320) plus a 32-row tile's gather and transform state do not fit 256 registers (no instantiation may spill)
 template <int RB, int NCB, int MODE, int XF, bool BF>
-__global__ __launch_bounds__(ST_THREADS, MODE == ST_DUAL ? 1 : 2) void conv_st_kernel(const eab_conv_desc d) {
+constexpr int st_wgs_per_cu() {
+    return (MODE == ST_DUAL || (RB == 2 && NCB == 2 && MODE == ST_PLAIN && (XF != EAB_XF_NONE || BF))) ? 1 : 2;
+}
+
+template <int RB, int NCB, int MODE, int XF, bool BF>
+__global__ __launch_bounds__(ST_THREADS, (st_wgs_per_cu<RB, NCB, MODE, XF, BF>())) void conv_st_kernel(const eab_conv_desc d) {
     const unsigned block = blockIdx.x, grid = gridDim.x;
 #include "conv_st_body.inc"
 }
@@ -152,6 +160,14 @@ struct StPlan {
 };
 static thread_local StPlan* st_plan = nullptr;
 
+// the current device, as an index into the per-device "attribute set" flags (-1: none / out of range)
+#define ST_MAX_DEVICES 64
+static int st_device() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ST_MAX_DEVICES) return -1;
+    return dev;
+}
+
 // LDS bytes of a launch
 static size_t st_lds_bytes(const eab_conv_desc* d, int bm, bool dual) {
     const bool bf = d->precision == EAB_PREC_BF16;
@@ -177,12 +193,16 @@ static int st_launch_p(const eab_conv_desc* d, hipStream_t s) {
         st_plan->tiles_per_b = tiles;
         return EAB_OK;
     }
-    static bool attr_set = false;                        // per instantiation: allow more than the default 64 KB
-    if (!attr_set) {
+    // per instantiation AND device: allow more than the default 64 KB of dynamic LDS (the attribute belongs to the
+    // function on one device; a second GPU in the process needs its own call)
+    static std::atomic<bool> attr_set[ST_MAX_DEVICES];
+    const int dev = st_device();
+    if (dev < 0) return EAB_EINVAL;
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_st_kernel<RB, NCB, MODE, XF, BF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return eab_hip_status(e);
-        attr_set = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((conv_st_kernel<RB, NCB, MODE, XF, BF>), dim3((unsigned)(d->B * tiles)), dim3(ST_THREADS), lds, s, *d);
     EAB_RETURN_LAUNCH_STATUS();
@@ -213,7 +233,12 @@ int eab_conv_st(const eab_conv_desc* d, hipStream_t s) {
     EAB_CHECK_ARG((d->C0 == 64 || d->C0 == 128 || d->C0 == 256) && (d->C1 == 0 || d->C1 == 64 || d->C1 == 128 || d->C1 == 256));
     EAB_CHECK_ARG(d->epi == EAB_EPI_LINEAR || d->epi == EAB_EPI_RELU || d->epi == EAB_EPI_ADD || d->epi == EAB_EPI_DUALGATE ||
                   d->epi == EAB_EPI_GLU);
-    EAB_CHECK_ARG(d->fz_counter == nullptr);          // (glu_dump: diagnostic stamp buffer or NULL)
+    EAB_CHECK_ARG(d->fz_counter == nullptr);
+#ifndef EAB_ST_STAMPS
+    // this kernel writes no GLU factor dump (the training forward's gated convolutions run on conv_gemm_kernel): refuse
+    // rather than leave the buffer eab_glu_bwd_f32 reads unwritten
+    if (d->glu_dump != nullptr) return EAB_EUNSUPPORTED;
+#endif
     const bool dual = d->epi == EAB_EPI_DUALGATE;
     if (d->ph1_No > 0) {                                 // second output-column phase of a transposed convolution
         EAB_CHECK_ARG(d->ph1_w && d->ph1_ntaps > 0 && d->ph1_ntaps <= EAB_MAX_TAPS && d->ph1_Kpad > 0 && d->ph1_Kpad <= d->Kpad);
@@ -289,13 +314,15 @@ extern "C" int eab_conv_st_chain_plan(const eab_conv_desc* descs, int n, int* co
 extern "C" int eab_conv_st_chain_run(const eab_conv_desc* dev_descs, const int* dev_codes, int n, int B, int lds_bytes, int bf16,
                                      eab_stream_t stream) {
     EAB_CHECK_ARG(dev_descs && dev_codes && n > 0 && B > 0 && lds_bytes > 0 && lds_bytes <= 160 * 1024);
-    static bool attr_set[2] = {false, false};
+    static std::atomic<bool> attr_set[2][ST_MAX_DEVICES];
     const void* fn = bf16 ? reinterpret_cast<const void*>(&conv_st_chain_kernel<true>)
                           : reinterpret_cast<const void*>(&conv_st_chain_kernel<false>);
-    if (!attr_set[bf16 ? 1 : 0]) {
+    const int dev = st_device();
+    if (dev < 0) return EAB_EINVAL;
+    if (!attr_set[bf16 ? 1 : 0][dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return eab_hip_status(e);
-        attr_set[bf16 ? 1 : 0] = true;
+        attr_set[bf16 ? 1 : 0][dev].store(true, std::memory_order_release);
     }
     if (bf16)
         hipLaunchKernelGGL(conv_st_chain_kernel<true>, dim3((unsigned)B), dim3(ST_THREADS), (size_t)lds_bytes, eab_stream(stream),

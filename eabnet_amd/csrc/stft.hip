@@ -94,8 +94,12 @@ __global__ __launch_bounds__(STFT_THREADS) void stft_dft_kernel(
 
 // NFFT_CT / HOP_CT != 0: the reference's front end (fft_num 320, hop 160) with every size a compile-time constant -- the
 // same passes and the same arithmetic as the run-time plan (bit-identical results), but the index divisions fold into
-// multiplies and shifts
-template <int NFFT_CT, int HOP_CT>
+// multiplies and shifts.
+// DUMP: the verification twin behind eab_stft_frames_f32 -- the SAME gather code (both paths: four samples per load for
+// interior frames, reflected scalar loads otherwise) with the window factor left out, and the gathered LDS rows stored
+// instead of transformed: frames[b][m][t][n] must equal reflect_pad(wav[b][m], n_fft/2)[t*hop + n] bit for bit
+// (train_distributed.py:83, torch.stft(center=True, pad_mode="reflect")).
+template <int NFFT_CT, int HOP_CT, bool DUMP>
 __global__ __launch_bounds__(STFT_THREADS) void stft_fft_kernel(
     const float* __restrict__ wav, const float* __restrict__ window, const float* __restrict__ twiddle,
     float* __restrict__ out, int M, int L, int n_fft_rt, int hop_rt, int T, int layout, FftPlan plan) {
@@ -115,10 +119,11 @@ __global__ __launch_bounds__(STFT_THREADS) void stft_fft_kernel(
     }
     const int b = (int)(vblk / (unsigned)T), t = (int)(vblk - (unsigned)b * T);
     const int tid = threadIdx.x;
-    for (int k = tid; k < n_fft; k += STFT_THREADS) {       // table is (cos, sin)(+theta); the passes use exp(-i theta)
-        const float2 cs = reinterpret_cast<const float2*>(twiddle)[k];
-        tw[k] = make_float2(cs.x, -cs.y);
-    }
+    if (!DUMP)
+        for (int k = tid; k < n_fft; k += STFT_THREADS) {   // table is (cos, sin)(+theta); the passes use exp(-i theta)
+            const float2 cs = reinterpret_cast<const float2*>(twiddle)[k];
+            tw[k] = make_float2(cs.x, -cs.y);
+        }
 
     for (int m0 = 0; m0 < M; m0 += FFT_SIGS) {
         __syncthreads();
@@ -132,8 +137,12 @@ __global__ __launch_bounds__(STFT_THREADS) void stft_fft_kernel(
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (m0 + mm < M) {
                     const f32x4 x4 = *reinterpret_cast<const f32x4*>(&wav[((size_t)b * M + m0 + mm) * L + first + 4 * q]);
-                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(&window[4 * q]);
-                    v = f32x4{w4[0] * x4[0], w4[1] * x4[1], w4[2] * x4[2], w4[3] * x4[3]};
+                    if (DUMP) {
+                        v = x4;
+                    } else {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(&window[4 * q]);
+                        v = f32x4{w4[0] * x4[0], w4[1] * x4[1], w4[2] * x4[2], w4[3] * x4[3]};
+                    }
                 }
                 *reinterpret_cast<f32x4*>(&reinterpret_cast<float*>(buf0)[mm * n_fft + 4 * q]) = v;
             }
@@ -141,11 +150,22 @@ __global__ __launch_bounds__(STFT_THREADS) void stft_fft_kernel(
             for (int e = tid; e < FFT_SIGS * n_fft; e += STFT_THREADS) {
                 const int mm = e / n_fft, n = e - mm * n_fft;
                 float v = 0.0f;
-                if (m0 + mm < M) v = window[n] * wav[((size_t)b * M + m0 + mm) * L + reflect_index(t * hop + n, NH, L)];
+                if (m0 + mm < M) {
+                    const float x = wav[((size_t)b * M + m0 + mm) * L + reflect_index(t * hop + n, NH, L)];
+                    v = DUMP ? x : window[n] * x;
+                }
                 reinterpret_cast<float*>(buf0)[mm * n_fft + n] = v;       // float index 2*(n/2) + (n&1) = n
             }
         }
         __syncthreads();
+        if (DUMP) {                                           // out = frames [B][M][T][n_fft]
+            for (int e = tid; e < FFT_SIGS * n_fft; e += STFT_THREADS) {
+                const int mm = e / n_fft, n = e - mm * n_fft;
+                if (m0 + mm < M)
+                    out[(((size_t)b * M + m0 + mm) * T + t) * n_fft + n] = reinterpret_cast<const float*>(buf0)[mm * n_fft + n];
+            }
+            continue;
+        }
         const float2* src;
         if (NFFT_CT == 320) {                                 // 160 = 5 * 4 * 8, unrolled with constant sizes
             // (the trailing radix-8 pass instead of 4 . 2: one pass and one barrier fewer, no twiddles in it: 37 -> 34.5 us)
@@ -186,13 +206,6 @@ __global__ __launch_bounds__(STFT_THREADS) void stft_fft_kernel(
     }
 }
 
-__global__ void stft_frames_kernel(const float* __restrict__ wav, float* __restrict__ frames, int L, int n_fft,
-                                   int hop, int T) {
-    const int n = blockIdx.x / T, t = blockIdx.x % T;
-    for (int k = threadIdx.x; k < n_fft; k += blockDim.x)
-        frames[((size_t)n * T + t) * n_fft + k] = wav[(size_t)n * L + reflect_index(t * hop + k, n_fft / 2, L)];
-}
-
 extern "C" int eab_stft_compress_f32(const float* wav, const float* window, const float* twiddle, float* out,
                                      int B, int M, int L, int n_fft, int hop, int layout, eab_stream_t stream) {
     EAB_CHECK_ARG(wav && window && twiddle && out);
@@ -208,10 +221,10 @@ extern "C" int eab_stft_compress_f32(const float* wav, const float* window, cons
         // the reference front end (fft 320, hop 160) has its own instance: every size a constant, its passes written out
         // (independent of what fft_plan picks for the generic kernel)
         if (n_fft == 320 && hop == 160)
-            hipLaunchKernelGGL((stft_fft_kernel<320, 160>), dim3(B * T), dim3(STFT_THREADS), sh, eab_stream(stream), wav, window,
+            hipLaunchKernelGGL((stft_fft_kernel<320, 160, false>), dim3(B * T), dim3(STFT_THREADS), sh, eab_stream(stream), wav, window,
                                twiddle, out, M, L, n_fft, hop, T, layout, plan);
         else
-            hipLaunchKernelGGL((stft_fft_kernel<0, 0>), dim3(B * T), dim3(STFT_THREADS), sh, eab_stream(stream), wav, window,
+            hipLaunchKernelGGL((stft_fft_kernel<0, 0, false>), dim3(B * T), dim3(STFT_THREADS), sh, eab_stream(stream), wav, window,
                                twiddle, out, M, L, n_fft, hop, T, layout, plan);
         EAB_RETURN_LAUNCH_STATUS();
     }
@@ -221,12 +234,21 @@ extern "C" int eab_stft_compress_f32(const float* wav, const float* window, cons
     EAB_RETURN_LAUNCH_STATUS();
 }
 
-extern "C" int eab_stft_frames_f32(const float* wav, float* frames, int N, int L, int n_fft, int hop,
+extern "C" int eab_stft_frames_f32(const float* wav, float* frames, int B, int M, int L, int n_fft, int hop,
                                    eab_stream_t stream) {
-    EAB_CHECK_ARG(wav && frames && N > 0 && hop > 0 && n_fft >= 2 && (n_fft % 2) == 0 && L > n_fft / 2);
+    EAB_CHECK_ARG(wav && frames && B > 0 && M > 0 && hop > 0);
+    EAB_CHECK_ARG(n_fft >= 2 && n_fft <= STFT_MAX_NFFT && (n_fft % 2) == 0 && L > n_fft / 2);
     const int T = 1 + L / hop;
-    EAB_CHECK_ARG((long long)N * T < (1ll << 31));
-    hipLaunchKernelGGL(stft_frames_kernel, dim3(N * T), dim3(256), 0, eab_stream(stream), wav, frames, L, n_fft, hop,
-                       T);
+    EAB_CHECK_ARG((long long)B * T < (1ll << 31));
+    // the product kernel's own gather (the instance eab_stft_compress_f32 picks for these sizes), stores instead of passes
+    FftPlan plan;
+    EAB_CHECK_ARG(fft_plan(n_fft / 2, &plan));
+    const size_t sh = (size_t)(2 * n_fft + 2 * FFT_SIGS * n_fft) * sizeof(float);
+    if (n_fft == 320 && hop == 160)
+        hipLaunchKernelGGL((stft_fft_kernel<320, 160, true>), dim3(B * T), dim3(STFT_THREADS), sh, eab_stream(stream), wav,
+                           (const float*)nullptr, (const float*)nullptr, frames, M, L, n_fft, hop, T, 0, plan);
+    else
+        hipLaunchKernelGGL((stft_fft_kernel<0, 0, true>), dim3(B * T), dim3(STFT_THREADS), sh, eab_stream(stream), wav,
+                           (const float*)nullptr, (const float*)nullptr, frames, M, L, n_fft, hop, T, 0, plan);
     EAB_RETURN_LAUNCH_STATUS();
 }

@@ -103,7 +103,8 @@ __global__ __launch_bounds__(16 * NPL) void in_stats_kernel(const float* __restr
         const int cc = blockIdx.y * 64 + threadIdx.x;
         if (cc < C) {
             double ss = 0.0, qq = 0.0;
-#pragma unroll
+            // (eight at a time: the fully unrolled 64-lane form of the 1024-thread instance kept 128 doubles live and spilled)
+#pragma unroll 8
             for (int r = 0; r < NPL; ++r) {
                 ss += red[0][r][threadIdx.x];
                 qq += red[1][r][threadIdx.x];

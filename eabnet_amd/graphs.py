@@ -1,0 +1,130 @@
+"""Replay of op programs with parallel branches as a set of SINGLE-STREAM hipGraphs.
+
+Programs mark independent chains (the post-filter's glance / gaze S-TCM chains, forward and backward) with fork / join
+points and a stream lane per op (program.Program.lanes / .sync, train.TrainProgram.lanes / .sync).  Rounds 1-3 captured such
+a program into ONE hipGraph with internal branches and let the HIP runtime pick the streams of a replay.  That ends in a
+segmentation fault inside the runtime under a condition the caller cannot see (ROCm 7.2,
+profiles/r03_graph_branch_segfault_backtrace.txt; DESIGN.md section 7 has the disassembly):
+
+    hip::Graph::UpdateStreams(launch_stream, parallel_streams)          libamdhip64.so + 0xaed90
+        streams_.resize(max_streams_); streams_[0] = launch_stream;
+        for (i = 1, j = 0; i < streams_.size(); ++j) {
+            if (parallel_streams[j]->vdev()->f() == launch_stream->vdev()->f()) continue;   // <- crash: + 0xb1, j unchecked
+            streams_[i++] = parallel_streams[j];
+        }
+
+A parallel stream of the graph that maps to the same device queue as the launch stream is skipped, and nothing bounds j by
+parallel_streams.size(): when more of the graph's own streams collide with the launch stream than the runtime created spares
+for, the loop reads past the vector and dereferences what it finds.  Which queue a stream maps to depends on every stream the
+process created and destroyed before (RCCL communicators create and destroy their own) -- not on anything in this package.
+A graph captured on ONE stream has max_streams_ == 1 and never enters that loop.
+
+So the branches are kept out of the runtime's hands: every maximal run of ops on one lane between two fork / join marks is
+captured as its own single-stream hipGraph, and a replay launches those graphs on streams this object owns, with ordinary
+events for the forks and joins.  Same kernels, same order per lane, same concurrency between lanes; 13 graph launches
+instead of 1 for the default post-filter."""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Sequence, Tuple
+
+import torch
+
+# plan entries
+FORK, JOIN, RUN = "fork", "join", "run"
+
+
+def plan_segments(n_ops: int, lanes: Sequence[int], sync: Dict[int, list]) -> List[tuple]:
+    """The replay plan of a program: a list of ("fork", [lanes]) / ("join", [lanes]) / ("run", lane, first, count).
+    `sync[k]` applies BEFORE op k (k == n_ops: after the last op); a run never crosses a mark or a lane change.
+    Pure Python: tested on a machine without a GPU."""
+    if len(lanes) != n_ops:
+        raise ValueError("one lane per op")
+    open_lanes = set()
+    plan: List[tuple] = []
+    k = 0
+    while k <= n_ops:
+        for what, ls in sync.get(k, ()):
+            ls = [int(l) for l in ls]
+            if what == FORK:
+                if 0 in ls or open_lanes & set(ls):
+                    raise ValueError(f"fork of lane 0 or of an open lane at op {k}")
+                open_lanes |= set(ls)
+            elif what == JOIN:
+                if not set(ls) <= open_lanes:
+                    raise ValueError(f"join of a lane that was not forked at op {k}")
+                open_lanes -= set(ls)
+            else:
+                raise ValueError(what)
+            plan.append((what, ls))
+        if k == n_ops:
+            break
+        j = k + 1
+        while j < n_ops and lanes[j] == lanes[k] and j not in sync:
+            j += 1
+        if lanes[k] != 0 and lanes[k] not in open_lanes:
+            raise ValueError(f"op {k} runs on lane {lanes[k]} outside a fork / join pair")
+        plan.append((RUN, int(lanes[k]), k, j - k))
+        k = j
+    if open_lanes:
+        raise ValueError(f"lanes {sorted(open_lanes)} are never joined")
+    return plan
+
+
+def single_lane(n_ops: int) -> List[tuple]:
+    return [(RUN, 0, 0, n_ops)] if n_ops else []
+
+
+class LaneGraphs:
+    """The captured form of one program: one single-stream hipGraph per ("run", ...) entry of the plan.
+
+    launch(stream_ptr, first, count) must enqueue ops [first, first + count) on the raw stream it is given and nothing
+    else (no allocation, no other stream)."""
+
+    def __init__(self, device: torch.device, plan: List[tuple], launch: Callable[[int, int, int], None]):
+        self.device, self.plan, self.launch = device, plan, launch
+        self.side: Dict[int, torch.cuda.Stream] = {}
+        self.graphs: Dict[Tuple[int, int], torch.cuda.CUDAGraph] = {}
+        for e in plan:
+            if e[0] == RUN and e[1] != 0 and e[1] not in self.side:
+                self.side[e[1]] = torch.cuda.Stream(device=device)
+
+    @property
+    def n_graphs(self) -> int:
+        return len(self.graphs)
+
+    def run_direct(self) -> None:
+        """The plan with direct kernel launches (warm-up; programs that must not be captured)."""
+        self._walk(lambda lane, first, count, st: self.launch(st.cuda_stream, first, count))
+
+    def capture(self) -> None:
+        """Capture every run on the capture stream torch provides: nothing crosses streams inside a capture, so every
+        graph is a single-stream graph.  thread_local: other threads of the process (RCCL's watchdog, a data loader) may
+        issue HIP calls while this thread captures; in the default global mode such a call invalidates the capture."""
+        for e in self.plan:
+            if e[0] != RUN:
+                continue
+            _, lane, first, count = e
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self.launch(torch.cuda.current_stream().cuda_stream, first, count)
+            self.graphs[(first, count)] = g
+
+    def replay(self) -> None:
+        self._walk(lambda lane, first, count, st: self.graphs[(first, count)].replay())
+
+    def _walk(self, do) -> None:
+        main = torch.cuda.current_stream(self.device)
+        for e in self.plan:
+            if e[0] == FORK:
+                for l in e[1]:
+                    self.side[l].wait_stream(main)
+            elif e[0] == JOIN:
+                for l in e[1]:
+                    main.wait_stream(self.side[l])
+            else:
+                _, lane, first, count = e
+                if lane == 0:
+                    do(lane, first, count, main)
+                else:
+                    with torch.cuda.stream(self.side[lane]):
+                        do(lane, first, count, self.side[lane])

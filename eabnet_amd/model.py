@@ -21,6 +21,7 @@ import torch.nn as nn
 
 from . import _lib
 from . import program as prg
+from .graphs import LaneGraphs, plan_segments, single_lane
 from .spec import GagConfig, NetConfig, ParamSpec, gag_param_specs, param_specs
 
 
@@ -132,13 +133,12 @@ class _Bound:
                     self.static_in2.zero_()
                 self.run(side.cuda_stream)
             torch.cuda.current_stream().wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            # thread_local: other threads of the process (RCCL's watchdog under DistributedDataParallel, a data loader) may
-            # issue HIP calls while this thread captures; in the default global mode such a call invalidates the capture and the
-            # other thread aborts the process
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                self.run(torch.cuda.current_stream().cuda_stream)
-            self.graph = g
+            # one single-stream hipGraph per lane segment (graphs.py: a hipGraph with internal branches can crash the HIP
+            # runtime at replay, depending on streams created elsewhere in the process); programs without parallel
+            # branches are one segment, i.e. one graph
+            lg = LaneGraphs(self.device, self._plan(), self._launch)
+            lg.capture()
+            self.graph = lg
         except Exception as e:                            # noqa: BLE001 - any capture failure -> direct launches
             import warnings
             warnings.warn(f"eabnet_amd: hipGraph capture failed ({e!r}); using direct launches")
@@ -309,39 +309,23 @@ class _Bound:
         ops = C.cast(C.byref(self.ops, first * C.sizeof(_lib.Op)), C.POINTER(_lib.Op))
         _lib.check(_lib.load().eab_run_program(ops, n, C.c_void_p(stream)), "eab_run_program")
 
+    def _plan(self) -> list:
+        n = len(self.prog.ops)
+        if self.prog.sync and graph_branches_allowed():
+            return plan_segments(n, self.prog.lanes, self.prog.sync)
+        return single_lane(n)
+
     def run(self, stream: int, first: int = 0, count: Optional[int] = None) -> None:
-        """Enqueue ops [first, first+count) on ``stream`` (a raw hipStream_t).  Programs with parallel
-        branches (prog.sync) fork onto side streams with events -- inside a hipGraph capture these become
-        graph edges, so the branches replay concurrently."""
+        """Enqueue ops [first, first+count) on ``stream`` (a raw hipStream_t) with direct kernel launches.  Whole programs
+        with parallel branches (prog.sync) fork onto side streams with events, exactly as their captured form replays
+        (graphs.LaneGraphs)."""
         n = len(self.prog.ops) - first if count is None else count
         if not self.prog.sync or count is not None or not graph_branches_allowed():
             return self._launch(stream, first, n)         # single lane (or a single-op debug launch)
-        main = torch.cuda.current_stream()
-        assert main.cuda_stream == stream, "multi-lane programs run on torch's current stream"
-        if not hasattr(self, "_side"):
-            self._side = {}
-        lanes, sync = self.prog.lanes, self.prog.sync
-        streams = {0: main}
-        k = first
-        end = first + n
-        while k <= end:
-            for what, ls in sync.get(k, ()):
-                for l in ls:
-                    if l not in self._side:
-                        self._side[l] = torch.cuda.Stream(device=self.device)
-                    streams[l] = self._side[l]
-                    if what == "fork":
-                        streams[l].wait_stream(main)
-                    else:
-                        main.wait_stream(streams[l])
-            if k == end:
-                break
-            j = k + 1
-            while j < end and lanes[j] == lanes[k] and j not in sync:
-                j += 1
-            with torch.cuda.stream(streams[lanes[k]]):
-                self._launch(streams[lanes[k]].cuda_stream, k, j - k)
-            k = j
+        assert torch.cuda.current_stream().cuda_stream == stream, "multi-lane programs run on torch's current stream"
+        if getattr(self, "_direct", None) is None:
+            self._direct = LaneGraphs(self.device, self._plan(), self._launch)
+        self._direct.run_direct()
 
     def view(self, act: prg.Act) -> torch.Tensor:
         """Debug view of a named activation as (B, T, F, C)."""
@@ -355,28 +339,20 @@ class _Bound:
 # the module
 # ----------------------------------------------------------------------------
 def graph_branches_allowed() -> bool:
-    """Parallel branches (side streams -> branches of the captured hipGraph) for programs that mark independent chains?
-    EAB_GRAPH_BRANCHES=0 runs every program on one stream."""
+    """Parallel branches (side streams) for programs that mark independent chains?  EAB_GRAPH_BRANCHES=0 runs every program
+    on one stream.  (Rounds 1-3 also switched them off while a torch.distributed process group was alive: a hipGraph with
+    internal branches could crash the HIP runtime at replay.  The cause is an unchecked index in the runtime's stream
+    assignment, graphs.py; since branches replay as separate single-stream graphs the condition no longer exists.)"""
     import os
-    if os.environ.get("EAB_GRAPH_BRANCHES", "1") == "0":
-        return False
-    # With a torch.distributed process group alive in the process, replaying a multi-branch hipGraph has ended in a
-    # segmentation fault inside the HIP runtime (hip::Graph::UpdateStreams <- hip::GraphExec::Run <- hipGraphLaunch; ROCm 7.2,
-    # gpurun_out/r03_gdb.log: reproducible with the round-2 sources as well, never without graph branches): data-parallel
-    # jobs run their programs on one stream.
-    import torch.distributed as td
-    return not (td.is_available() and td.is_initialized())
+    return os.environ.get("EAB_GRAPH_BRANCHES", "1") != "0"
 
 
-def _warn_operator_path(module: nn.Module, reason: str) -> None:
-    """One warning per module when `use_hip_training` is on but a differentiable forward runs on PyTorch-ROCm operators
-    (autograd_path.py, ~5x slower at the training benchmark's size): the switch must not be silent."""
-    if module.__dict__.get("_warned_operator_path"):
-        return
-    module.__dict__["_warned_operator_path"] = True
-    import warnings
-    warnings.warn(f"{type(module).__name__}: training forward on PyTorch-ROCm operators instead of the HIP training programs "
-                  f"({reason}); module.training_backend == 'operators'", RuntimeWarning, stacklevel=3)
+def _refuse_differentiable(module: nn.Module, what: str, reason: str):
+    """A differentiable call the HIP training programs do not cover is refused, never served by another backend: the package
+    has one (the PyTorch-ROCm operator evaluation that used to sit here is now test infrastructure, tests/operator_path.py)."""
+    return NotImplementedError(
+        f"{type(module).__name__}: {what} ({reason}).  eabnet_amd runs differentiable calls on its HIP training programs "
+        "(eabnet_amd/train.py, train_gag.py) and has no operator fallback; call under torch.no_grad() for inference.")
 
 
 class _HipModule(nn.Module):
@@ -399,11 +375,7 @@ class _HipModule(nn.Module):
         # "bf16" = operands rounded to bf16, fp32 accumulate / norms / activations (BASELINE configs[3]/[4];
         # outside the 1e-4 bar: ~1e-2)
         self.precision = "f32"
-        # training forward/backward on the HIP programs (train.py) where the topology allows; False = the
-        # PyTorch-ROCm operator path (autograd_path.py) everywhere
-        self.use_hip_training = True
-        # which path the most recent differentiable forward took: "hip" (train.py / train_gag.py programs) or
-        # "operators" (autograd_path.py, PyTorch-ROCm); None before the first one
+        # "hip" once a differentiable forward has run (train.py / train_gag.py programs -- the only backend); None before
         self.training_backend = None
 
     def _param_fingerprint(self) -> tuple:
@@ -478,10 +450,12 @@ class EaBNet(_HipModule):
     Same constructor keywords and defaults, same ``forward`` signature:
     ``inpt`` (B, T, F, M, 2) [or (B, T, F, 2) for one microphone] ->
     (B, 2, T, F), same state-dict keys.  ``torch.no_grad()`` / ``requires_grad=False`` calls run
-    the hand-written HIP program (CUDA tensors only, no fallback).  A call that must be
-    differentiable (training: train.py / train_distributed.py) is evaluated by
-    eabnet_amd/autograd_path.py with PyTorch-ROCm operators so that backward, the optimiser and
-    DistributedDataParallel work; hand-written backward kernels are a later row.
+    the hand-written HIP inference program; a call that must be differentiable (training: train.py /
+    train_distributed.py:218-230) runs the HIP training programs (eabnet_amd/train.py: forward and
+    backward as two static op programs behind one autograd node), so ``loss.backward()``, the optimiser,
+    ``clip_grad_norm_`` and DistributedDataParallel work on the ordinary ``nn.Parameter``s.  CUDA
+    tensors only; there is no second backend.  Refused (NotImplementedError): a gradient w.r.t. the input
+    spectrogram, BatchNorm in eval mode under autograd, more than 32 microphones.
     """
 
     def __init__(self, k1: tuple = (2, 3), k2: tuple = (1, 3), c: int = 64, M: int = 9, embed_dim: int = 64,
@@ -507,26 +481,23 @@ class EaBNet(_HipModule):
         if inpt.ndim != 5 or inpt.shape[-1] != 2 or inpt.shape[-2] != self.M:
             raise ValueError(f"expected (B,T,F,{self.M},2), got {tuple(inpt.shape)}")
         if self._needs_graph(inpt):
-            # training: autograd needs a graph.  The default topology with InstanceNorm runs forward AND backward on
-            # the hand-written kernels (train.py: two static op programs behind one autograd node); the other
-            # constructor branches, BatchNorm in train mode, CPU tensors and a differentiable INPUT still take the
-            # PyTorch-ROCm operator path (autograd_path.py)
+            # training: forward AND backward on the hand-written kernels (train.py: two static op programs behind one
+            # autograd node) for every constructor branch; BatchNorm = train mode (batch statistics + buffer update)
             from . import train
-            # (BatchNorm: the HIP programs implement train mode -- batch statistics; a differentiable eval-mode pass with the
-            # running statistics stays on the operator path)
-            bn_eval = self.norm_type == "BN" and not self.training
-            if self.use_hip_training and inpt.is_cuda and not inpt.requires_grad and torch.is_grad_enabled() \
-                    and train.supported(self.cfg) and not bn_eval and next(self.parameters()).is_cuda:
-                self.training_backend = "hip"
-                out = train.forward_train(self, inpt)
-                return out.sum(dim=-1) if self.topo_type == "miso" else out      # (EaBNet.py:122-123, as in inference below)
-            from .autograd_path import forward_autograd
-            self.training_backend = "operators"
-            if self.use_hip_training and inpt.is_cuda:
-                _warn_operator_path(self, "input requires grad" if inpt.requires_grad else
-                                    "BatchNorm in eval mode under autograd" if bn_eval and train.supported(self.cfg) else
-                                    f"topology outside train.supported(): {train.unsupported_reason(self.cfg)}")
-            return forward_autograd(self, inpt)
+            if not (inpt.is_cuda and next(self.parameters()).is_cuda):
+                raise _lib.EabError("eabnet_amd.EaBNet trains on MI355X only: move the input and the module to 'cuda'. "
+                                    "There is no CPU fallback by design.")
+            if inpt.requires_grad:
+                raise _refuse_differentiable(self, "the input requires grad", "the training programs produce parameter "
+                                             "gradients only, as the reference's training loop needs")
+            if self.norm_type == "BN" and not self.training:
+                raise _refuse_differentiable(self, "BatchNorm in eval mode under autograd", "the training programs implement "
+                                             "BatchNorm's train mode; call .train(), or torch.no_grad() for inference")
+            if not train.supported(self.cfg):
+                raise _refuse_differentiable(self, "topology outside the training programs", train.unsupported_reason(self.cfg))
+            self.training_backend = "hip"
+            out = train.forward_train(self, inpt)
+            return out.sum(dim=-1) if self.topo_type == "miso" else out      # (EaBNet.py:122-123, as in inference below)
         if not inpt.is_cuda:
             raise _lib.EabError("eabnet_amd.EaBNet inference runs on MI355X only: move the input (and module) to "
                                 "'cuda'. There is no CPU fallback by design.")
@@ -796,7 +767,7 @@ class GaGNet(_HipModule):
     constructor keywords, same state-dict keys, ``forward(inpt, pre_x)`` with both (B, 2, T, F)
     returning the list of the q stage estimates, each (B, 2, F, T).  Inference runs the HIP program
     (U2-encoder on the conv kernels, 24 single-branch S-TCMs per stage, fused gain/residual tail);
-    a call that needs autograd goes through autograd_path.forward_gagnet."""
+    a call that needs autograd runs the HIP training programs (eabnet_amd/train_gag.py)."""
 
     def __init__(self, cin: int = 2, k1: tuple = (2, 3), k2: tuple = (1, 3), c: int = 64, kd1: int = 3, cd1: int = 64,
                  d_feat: int = 256, p: int = 2, q: int = 3, dilas=(1, 2, 5, 9), fft_num: int = 320, is_u2: bool = True,
@@ -819,22 +790,22 @@ class GaGNet(_HipModule):
         if inpt.ndim != 4 or inpt.shape[1] != 2 or inpt.shape[3] != self.cfg.freq or pre_x.shape != inpt.shape:
             raise ValueError(f"expected two (B,2,T,{self.cfg.freq}) tensors, got {tuple(inpt.shape)} and {tuple(pre_x.shape)}")
         if self._needs_graph(inpt, pre_x):
-            # training: the default topology with InstanceNorm runs forward AND backward on the hand-written kernels
-            # (train_gag.py); other constructor branches, a differentiable input (the reference detaches the beam-former's
-            # estimate, EaBNet.py:142) and CPU tensors take the PyTorch-ROCm operator path
+            # training: forward AND backward on the hand-written kernels (train_gag.py).  No gradient flows to the inputs:
+            # the reference feeds the detached beam-former estimate (EaBNet.py:142)
             from . import train_gag
-            if self.use_hip_training and inpt.is_cuda and pre_x.is_cuda and not inpt.requires_grad and not pre_x.requires_grad \
-                    and torch.is_grad_enabled() and train_gag.supported(self.cfg) and next(self.parameters()).is_cuda \
-                    and not (self.norm_type == "BN" and not self.training):       # (BatchNorm: train mode only, as EaBNet)
-                self.training_backend = "hip"
-                return train_gag.forward_train(self, inpt, pre_x)
-            from .autograd_path import forward_gagnet
-            self.training_backend = "operators"
-            if self.use_hip_training and inpt.is_cuda:
-                _warn_operator_path(self, "an input requires grad" if (inpt.requires_grad or pre_x.requires_grad) else
-                                    "BatchNorm in eval mode under autograd" if self.norm_type == "BN" and not self.training else
-                                    "post-filter topology outside train_gag.supported() (U2 / IN or BN / cat / causal only)")
-            return forward_gagnet(self, inpt, pre_x)
+            if not (inpt.is_cuda and pre_x.is_cuda and next(self.parameters()).is_cuda):
+                raise _lib.EabError("eabnet_amd.GaGNet trains on MI355X only: move the inputs and the module to 'cuda'. "
+                                    "There is no CPU fallback by design.")
+            if inpt.requires_grad or pre_x.requires_grad:
+                raise _refuse_differentiable(self, "an input requires grad", "the reference detaches the beam-former's estimate, "
+                                             "EaBNet.py:142; the training programs produce parameter gradients only")
+            if self.norm_type == "BN" and not self.training:
+                raise _refuse_differentiable(self, "BatchNorm in eval mode under autograd", "the training programs implement "
+                                             "BatchNorm's train mode; call .train(), or torch.no_grad() for inference")
+            if not train_gag.supported(self.cfg):
+                raise _refuse_differentiable(self, "post-filter topology outside the training programs", "see train_gag.supported")
+            self.training_backend = "hip"
+            return train_gag.forward_train(self, inpt, pre_x)
         if not (inpt.is_cuda and pre_x.is_cuda):
             raise _lib.EabError("eabnet_amd.GaGNet inference runs on MI355X only: move the inputs (and module) to "
                                 "'cuda'. There is no CPU fallback by design.")

@@ -20,8 +20,9 @@ Parameters reach the kernels through ONE gather launch (flat parameter vector ->
 and dgrad layouts; index tables built here from the same packing rules as program.py) and the packed gradient
 arena goes back to the flat gradient through the inverse table.
 
-Scope: the reference's default topology (U2 encoder/decoder, LSTM beam-former, mimo, 'cat' skips) with
-InstanceNorm; anything else keeps using autograd_path.py.
+Scope: every constructor branch of the reference (`supported`): U2 / plain U-Net, LSTM / cnn head, mimo / miso, cat / add,
+causal or not, InstanceNorm, BatchNorm (train mode) and cLN, up to 32 microphones.  This is the package's only differentiable
+path; what it does not cover (a gradient w.r.t. the input, eval-mode BatchNorm under autograd) is refused by model.py.
 """
 from __future__ import annotations
 
@@ -36,6 +37,7 @@ import torch
 
 from . import _lib
 from . import program as prg
+from .graphs import LaneGraphs, plan_segments, single_lane
 from .program import ALIGN, EPS_IN, EPS_LN, Ref, conv_tiles, glu_row_order
 from .spec import NetConfig, param_specs
 
@@ -953,32 +955,7 @@ class TrainBound:
         self.graphs = None                  # (forward hipGraph, backward hipGraph) on the static boundary buffers
         self.graph_failed = False
         self.static_x = self.static_x2 = self.static_out = self.static_dout = None
-        # Backward lanes: a weight gradient is a leaf of the backward graph -- nothing reads dW before the step ends, its
-        # operands (the finished gradient of a convolution output, a forward activation) are never written again
-        # (TrainLowering never recycles a buffer) -- so every block of wgrad launches forks onto a side stream right after
-        # its producer and joins at the end.  The dgrad / norm-backward chain of the small layers and the 161-workgroup LSTM
-        # backward leave most of the chip idle; the wgrads fill it.  Captured into the hipGraph these are parallel branches.
-        # EAB_WGRAD_LANES: 0 = off, 1 / 2 = side streams for every wgrad block, "small" = only the launches of the small
-        # layers (at most `small_rows` output rows: the S-TCN's) -- the big ones only contend with their neighbours
-        # (measured: 30.5 (2 lanes) / 30.7 (1) / 30.2 ms (off) per step; a dgrad next to a big wgrad: 239 -> 623 us)
-        mode = os.environ.get("EAB_WGRAD_LANES", "0")
-        small_rows = 1 << 15
-        self.wgrad_lanes = 1 if mode == "small" else int(mode)
-        self.segments = []                  # (lane, first op, count) of the backward program; lane 0 = the caller's stream
-
-        def side(op) -> bool:
-            return op.kind == OP_WGRAD and (mode != "small" or op.B * op.T * op.No <= small_rows)
-        k, nb, blk = 0, len(prog.bwd), 0
-        while k < nb:
-            j, is_w = k + 1, side(prog.bwd[k])
-            while j < nb and side(prog.bwd[j]) == is_w:
-                j += 1
-            if is_w:
-                blk += 1
-            self.segments.append((1 + blk % 2 if is_w else 0, k, j - k))
-            k = j
-        self._side = None
-        self._lane_streams = {}
+        self._direct = {}                   # which -> graphs.LaneGraphs for direct (uncaptured) multi-lane runs
         self.parallel_branches = os.environ.get("EAB_TRAIN_BRANCHES", "1") != "0"      # A/B knob
 
     def capture(self, x_shape) -> bool:
@@ -1001,15 +978,13 @@ class TrainBound:
                 self.run("fwd", side.cuda_stream)
                 self.run("bwd", side.cuda_stream)
             torch.cuda.current_stream().wait_stream(side)
+            # one single-stream hipGraph per lane segment (graphs.py: a hipGraph with internal branches can crash the HIP
+            # runtime at replay); programs without parallel branches are one graph each
             graphs = []
             for which in ("fwd", "bwd"):
-                g = torch.cuda.CUDAGraph()
-                # thread_local: other threads of the process (RCCL's watchdog under DistributedDataParallel, a data loader) may
-                # issue HIP calls while this thread captures; in the default global mode such a call invalidates the capture and the
-                # other thread aborts the process
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    self.run(which, torch.cuda.current_stream().cuda_stream)
-                graphs.append(g)
+                lg = LaneGraphs(self.device, self._plan(which), lambda st, first, count, w=which: self._launch(w, st, first, count))
+                lg.capture()
+                graphs.append(lg)
             self.graphs = tuple(graphs)
         except Exception as e:                            # noqa: BLE001 - any capture failure -> direct launches
             import warnings
@@ -1074,58 +1049,30 @@ class TrainBound:
                         o.f[j] = float(v)
         self._bound = (in_ptr, out_ptr, dout_ptr, in2_ptr)
 
-    def run(self, which: str, stream: int, first: int = 0, count: Optional[int] = None) -> None:
-        arr = self.fwd if which == "fwd" else self.bwd
-        if which == "bwd" and self.wgrad_lanes and first == 0 and count is None:
-            main = torch.cuda.current_stream()
-            assert main.cuda_stream == stream, "the backward program forks from torch's current stream"
-            if self._side is None:
-                self._side = [torch.cuda.Stream(device=self.device) for _ in range(2)]
-            used = set()
-            for lane, k, n in self.segments:
-                if lane == 0:
-                    self.run(which, stream, k, n)
-                    continue
-                sd = self._side[(lane - 1) % self.wgrad_lanes]
-                sd.wait_stream(main)
-                used.add(sd)
-                with torch.cuda.stream(sd):
-                    self.run(which, sd.cuda_stream, k, n)
-            for sd in used:
-                main.wait_stream(sd)
-            return
+    def _plan(self, which: str) -> list:
         from .model import graph_branches_allowed
+        n = len(self.prog.fwd if which == "fwd" else self.prog.bwd)
         sync = self.prog.sync.get(which) if (self.parallel_branches and graph_branches_allowed()) else None
-        if sync and first == 0 and count is None:
-            # programs with parallel branches (the post-filter's three S-TCM chains): fork onto side streams with events --
-            # inside a hipGraph capture these become graph edges, so the branches replay concurrently
-            main = torch.cuda.current_stream()
-            assert main.cuda_stream == stream, "multi-lane programs run on torch's current stream"
-            lanes = self.prog.lanes[which]
-            streams = {0: main}
-            k, end = 0, len(arr)
-            while k <= end:
-                for what, ls in sync.get(k, ()):
-                    for l in ls:
-                        if l not in self._lane_streams:
-                            self._lane_streams[l] = torch.cuda.Stream(device=self.device)
-                        streams[l] = self._lane_streams[l]
-                        if what == "fork":
-                            streams[l].wait_stream(main)
-                        else:
-                            main.wait_stream(streams[l])
-                if k == end:
-                    break
-                j = k + 1
-                while j < end and lanes[j] == lanes[k] and j not in sync:
-                    j += 1
-                with torch.cuda.stream(streams[lanes[k]]):
-                    self.run(which, streams[lanes[k]].cuda_stream, k, j - k)
-                k = j
-            return
-        n = len(arr) - first if count is None else count
+        return plan_segments(n, self.prog.lanes[which], sync) if sync else single_lane(n)
+
+    def _launch(self, which: str, stream: int, first: int, n: int) -> None:
+        arr = self.fwd if which == "fwd" else self.bwd
         ops = C.cast(C.byref(arr, first * C.sizeof(_lib.Op)), C.POINTER(_lib.Op))
         _lib.check(_lib.load().eab_run_program(ops, n, C.c_void_p(stream)), f"eab_run_program({which})")
+
+    def run(self, which: str, stream: int, first: int = 0, count: Optional[int] = None) -> None:
+        """Direct launches of ops [first, first + count) of one program.  Whole programs with parallel branches (the
+        post-filter's three S-TCM chains) fork onto side streams with events, exactly as their captured form replays."""
+        arr = self.fwd if which == "fwd" else self.bwd
+        if first == 0 and count is None:
+            plan = self._plan(which)
+            if len(plan) > 1:
+                assert torch.cuda.current_stream().cuda_stream == stream, "multi-lane programs run on torch's current stream"
+                if which not in self._direct:
+                    self._direct[which] = LaneGraphs(self.device, plan, lambda st, f, c, w=which: self._launch(w, st, f, c))
+                self._direct[which].run_direct()
+                return
+        self._launch(which, stream, first, len(arr) - first if count is None else count)
 
     def update_bn_buffers(self, module, momentum: float = 0.1) -> None:
         """nn.BatchNorm's train-mode side effect (NormSwitch BN branch, EaBNet.py:677-681): running_mean / running_var move

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EAB_ABI_VERSION 6
+#define EAB_ABI_VERSION 7
 
 #define EAB_OK          0
 #define EAB_EINVAL      1   /* bad argument (shape, alignment, limit) */
@@ -74,10 +74,13 @@ int eab_stft_compress_f32(const float* wav, const float* window, const float* tw
                           float* out, int B, int M, int L, int n_fft, int hop,
                           int layout, eab_stream_t stream);
 
-/* Debug/verification twin of the framing step only (bit-exact contract for
- * "STFT frame indexing"): frames[n][t][k] = reflect_pad(wav[n], n_fft/2)[t*hop + k].
- *   wav [N][L] -> frames [N][T][n_fft] */
-int eab_stft_frames_f32(const float* wav, float* frames, int N, int L, int n_fft, int hop,
+/* Verification twin of the framing step (the bit-exact contract for "STFT frame indexing",
+ * train_distributed.py:83 torch.stft(center=True, pad_mode="reflect")): the product kernel of
+ * eab_stft_compress_f32 itself, compiled to store the rows it gathered (un-windowed) instead of
+ * transforming them -- both of its gather paths are the ones under test:
+ *     frames[b][m][t][k] = reflect_pad(wav[b][m], n_fft/2)[t*hop + k].
+ *   wav [B][M][L] -> frames [B][M][T][n_fft];  n_fft/2 must factor into {2,4,5,8} as for the FFT path */
+int eab_stft_frames_f32(const float* wav, float* frames, int B, int M, int L, int n_fft, int hop,
                         eab_stream_t stream);
 
 /* --------------------------------------------------------------------------

@@ -1,16 +1,16 @@
-"""Differentiable evaluation of EaBNet for TRAINING (BASELINE config 4).
+"""COMPARATOR, not product code: EaBNet / GaGNet evaluated with PyTorch-ROCm operators (MIOpen convolutions, ATen
+LSTM) on a module's own ``nn.Parameter``s, differentiable through ordinary autograd.
 
-Inference runs the hand-written HIP program (model.py -> libeabnet_hip.so).  The backward kernels
-are a later row; until they exist, a forward that must be differentiable is evaluated with
-PyTorch-ROCm operators (MIOpen convolutions, ATen LSTM) on the module's own ``nn.Parameter``s, so
-``loss.backward()``, ``clip_grad_norm_``, Adam and ``DistributedDataParallel`` (RCCL bucketed
-gradient all-reduce over xGMI; reference train_distributed.py:198,228-230) work unchanged.  It is
-selected only when autograd needs a graph (``torch.is_grad_enabled()`` and something requires
-grad); ``torch.no_grad()`` inference never takes this path and never falls back to it.
+Until round 3 this file lived in the package (eabnet_amd/autograd_path.py) and served differentiable calls the HIP training
+programs did not cover; the package now has ONE backend (a differentiable call runs eabnet_amd/train.py / train_gag.py or
+raises) and this file is what the GPU tests and ``bench.py``'s untimed in-run check compare the HIP training programs
+against (``test_config3_full_size_*``, ``test_hip_training_step_matches_operator_path``, the torch.autocast(bf16) side of
+the bf16 gradient test, ``bench.py --train --train-operator-path``).  Nothing under eabnet_amd/ imports it.
 
-The network definition follows the reference's forward (EaBNet.py:88-117 and the block
-forwards :372-388, :455-460, :485-490, :572-578, :600-614); parameters are looked up by their
-state-dict keys (eabnet_amd/spec.py).
+The network definition follows the reference's forward (EaBNet.py:88-117 and the block forwards :372-388, :455-460,
+:485-490, :572-578, :600-614; GaGNet.py:76-133); parameters are looked up by their state-dict keys (eabnet_amd/spec.py).
+``OperatorPath(module)`` wraps an eabnet_amd module (EaBNet, GaGNet or EaBNetWithPostNet) so that a differentiable call
+runs here, on the SAME parameter objects, and a ``torch.no_grad()`` call runs the module's own HIP inference program.
 """
 from __future__ import annotations
 
@@ -217,3 +217,39 @@ def forward_gagnet(m, inpt: torch.Tensor, pre_x: torch.Tensor) -> list:
         pre = torch.stack((filt * torch.cos(ph), filt * torch.sin(ph)), dim=1) + resi
         outs.append(pre)
     return outs
+
+
+# ----------------------------------------------------------------------------
+# wrapper: the same call surface as the wrapped module, differentiable calls on operators
+# ----------------------------------------------------------------------------
+class OperatorPath(torch.nn.Module):
+    """``OperatorPath(net)(x)`` == ``net(x)`` with the differentiable work done by PyTorch-ROCm operators.  Parameters and
+    buffers are the wrapped module's own objects (``parameters()`` / optimisers / DDP see them under the prefix ``net.``)."""
+
+    def __init__(self, net: torch.nn.Module):
+        super().__init__()
+        self.net = net
+
+    @staticmethod
+    def _needs_graph(net, inputs) -> bool:
+        return torch.is_grad_enabled() and (any(t.requires_grad for t in inputs) or any(p.requires_grad for p in net.parameters())) \
+            or (getattr(net, "norm_type", None) == "BN" and net.training)
+
+    def _one(self, net, *inputs):
+        import eabnet_amd
+        if not self._needs_graph(net, inputs):
+            return net(*inputs)                                   # the module's own HIP inference program
+        if isinstance(net, eabnet_amd.GaGNet):
+            return forward_gagnet(net, *inputs)
+        return forward_autograd(net, *inputs)
+
+    def forward(self, *inputs):
+        import eabnet_amd
+        net = self.net
+        if isinstance(net, eabnet_amd.EaBNetWithPostNet):         # EaBNet.py:138-148
+            noisy = inputs[0]
+            esti0 = self._one(net.eabnet, noisy)
+            inpt = noisy[..., net.ref_mic, :].permute(0, 3, 1, 2)
+            lst = self._one(net.postnet, inpt, esti0.detach())
+            return {"esti0_stft": esti0, "esti1_stft_list": lst, "esti_stft": lst[-1].permute(0, 1, 3, 2)}
+        return self._one(net, *inputs)

@@ -59,11 +59,35 @@ def test_product_path_refuses_cpu_tensors():
         eabnet_amd.filter_and_sum(torch.zeros(1, 1, 1, 1, 2), torch.zeros(1, 1, 1, 1, 2))
 
 
-def test_training_forward_matches_oracle_on_cpu():
-    """The differentiable path (training) against the oracle; runs on CPU because it is plain PyTorch."""
+def test_differentiable_calls_have_no_cpu_or_operator_fallback():
+    """One backend: a differentiable call on CPU tensors is refused like an inference call (the PyTorch-operator evaluation
+    that used to serve it is test infrastructure now, tests/operator_path.py), and the package does not import it."""
+    import torch
+    import eabnet_amd
+    net = eabnet_amd.EaBNet(M=2, p=1, q=1)
+    with pytest.raises(eabnet_amd._lib.EabError, match="no CPU fallback"):
+        net(torch.zeros(1, 4, 161, 2, 2))                # grad enabled, parameters require grad
+    gag = eabnet_amd.GaGNet(p=1, q=1, dilas=(1,))
+    with pytest.raises(eabnet_amd._lib.EabError, match="no CPU fallback"):
+        gag(torch.zeros(1, 2, 4, 161), torch.zeros(1, 2, 4, 161))
+    assert not hasattr(net, "use_hip_training")
+    import re
+    pkg = os.path.join(ROOT, "eabnet_amd")
+    assert not os.path.exists(os.path.join(pkg, "autograd_path.py"))
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            bad = re.findall(r"^\s*(?:from|import)\s+\S*(?:autograd_path|operator_path|oracle)\b.*$", src, re.M)
+            assert not bad, (fn, bad)
+
+
+def test_operator_comparator_matches_oracle_on_cpu():
+    """tests/operator_path.py (the PyTorch-operator comparator of the GPU training tests and of bench.py's in-run check)
+    against the oracle; runs on CPU because it is plain PyTorch."""
     import torch
     import paramgen
     import eabnet_amd
+    from operator_path import OperatorPath
     from eabnet_amd.spec import NetConfig, param_specs
     from oracle import eabnet_oracle as orc
     cfg = NetConfig(M=3, p=2, q=2)
@@ -71,7 +95,7 @@ def test_training_forward_matches_oracle_on_cpu():
     net = eabnet_amd.EaBNet(M=3, p=2, q=2)
     net.load_state_dict(P, strict=True)
     x = torch.from_numpy(paramgen.make_spec_input(2, 9, 161, 3, 161))
-    y = net(x)                                           # grad enabled -> autograd path
+    y = OperatorPath(net)(x)                             # grad enabled -> the comparator's operators
     assert y.requires_grad
     with torch.no_grad():
         ref = orc.eabnet_forward(P, x, p=2, q=2)
@@ -111,8 +135,9 @@ def _variants():
 @pytest.mark.parametrize("name", sorted(_variants()))
 def test_constructor_variants_keep_reference_keys_and_train(name):
     """Every constructor branch: the module's state dict (parameters AND BatchNorm buffers, in the
-    reference's order) and the differentiable path against the reference's output."""
+    reference's order), and the operator comparator (tests/operator_path.py) against the reference's output."""
     import numpy as np
+    from operator_path import OperatorPath
     import torch
     import paramgen
     import eabnet_amd
@@ -126,7 +151,7 @@ def test_constructor_variants_keep_reference_keys_and_train(name):
                         strict=True)
     net.eval()
     x = torch.from_numpy(paramgen.make_spec_input(2, 20, 161, e["M"], int(g["input_seed"])))
-    y = net(x)
+    y = OperatorPath(net)(x)
     ref = torch.from_numpy(g["out"])
     assert y.shape == ref.shape and y.requires_grad
     assert float((y.detach() - ref).abs().max() / ref.abs().max()) < 1e-5
@@ -135,15 +160,17 @@ def test_constructor_variants_keep_reference_keys_and_train(name):
 
 
 def test_batchnorm_training_mode_updates_running_statistics():
-    """norm_type='BN' in train mode follows nn.BatchNorm: batch statistics, momentum-0.1 update of
-    the buffers, step counter; this holds under no_grad too (never the eval-mode HIP tables)."""
+    """The comparator's norm_type='BN' in train mode follows nn.BatchNorm: batch statistics, momentum-0.1 update of
+    the buffers, step counter; this holds under no_grad too.  (The HIP programs' train mode is pinned on the GPU by
+    tests/golden/bn_train.npz and test_hip_training_batchnorm_train_mode_vs_oracle_autograd.)"""
     import torch
     import eabnet_amd
+    from operator_path import OperatorPath
     net = eabnet_amd.EaBNet(M=2, p=1, q=1, norm_type="BN").train()
     key = "en.meta_unet_list.0.in_conv.1.norm"
     before = net.state_dict()[f"{key}.running_mean"].clone()
     with torch.no_grad():
-        net(torch.randn(2, 6, 161, 2, 2))
+        OperatorPath(net)(torch.randn(2, 6, 161, 2, 2))
     sd = net.state_dict()
     assert int(sd[f"{key}.num_batches_tracked"]) == 1
     assert not torch.equal(sd[f"{key}.running_mean"], before)
@@ -158,9 +185,10 @@ def _gag_variants():
 
 @pytest.mark.parametrize("name", sorted(_gag_variants()))
 def test_gagnet_module_keys_and_training_path(name):
-    """eabnet_amd.GaGNet: the reference's state-dict inventory and the differentiable path against
+    """eabnet_amd.GaGNet: the reference's state-dict inventory, and the operator comparator against
     the reference's stage outputs (CPU, plain PyTorch)."""
     import numpy as np
+    from operator_path import OperatorPath
     import torch
     import paramgen
     import eabnet_amd
@@ -172,7 +200,7 @@ def test_gagnet_module_keys_and_training_path(name):
                          paramgen.make_params(eabnet_amd.gag_param_specs(net.cfg), int(g["param_seed"])).items()}, strict=True)
     net.eval()
     mk = lambda seed: torch.from_numpy(paramgen.make_spec_input(2, 14, 161, 1, seed)[..., 0, :]).permute(0, 3, 1, 2)  # noqa: E731
-    outs = net(mk(int(g["inpt_seed"])), mk(int(g["pre_seed"])))
+    outs = OperatorPath(net)(mk(int(g["inpt_seed"])), mk(int(g["pre_seed"])))
     assert len(outs) == net.q and outs[-1].requires_grad
     for j, o in enumerate(outs):
         ref = torch.from_numpy(g[f"out{j}"])
@@ -206,7 +234,8 @@ def test_two_stage_wrapper_keys_and_output_dictionary(monkeypatch):
     keys = list(net.state_dict())
     assert all(k.startswith(("eabnet.", "postnet.")) for k in keys)
     assert [k[7:] for k in keys if k.startswith("eabnet.")] == list(eabnet_amd.EaBNet(M=3, p=1, q=1).state_dict())
-    out = net(torch.randn(1, 6, 161, 3, 2))            # parameters require grad -> differentiable path (CPU is fine)
+    from operator_path import OperatorPath
+    out = OperatorPath(net)(torch.randn(1, 6, 161, 3, 2))      # parameters require grad -> the comparator's operators (CPU is fine)
     assert set(out) == {"esti0_stft", "esti1_stft_list", "esti_stft"}
     assert out["esti0_stft"].shape == (1, 2, 6, 161) and out["esti_stft"].shape == (1, 2, 6, 161)
     assert len(out["esti1_stft_list"]) == 2 and out["esti1_stft_list"][0].shape == (1, 2, 161, 6)
@@ -214,7 +243,7 @@ def test_two_stage_wrapper_keys_and_output_dictionary(monkeypatch):
     assert all(p.grad is None for p in net.eabnet.parameters())        # the post-filter sees esti0.detach()
     net.freeze_eabnet()
     assert not any(p.requires_grad for p in net.eabnet.parameters())
-    with pytest.raises(eabnet_amd._lib.EabError):      # frozen beam-former = inference = HIP program: no CPU fallback
+    with pytest.raises(eabnet_amd._lib.EabError):      # the module itself: HIP programs only, no CPU fallback
         net(torch.randn(1, 6, 161, 3, 2))
 
 

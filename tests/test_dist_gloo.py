@@ -84,8 +84,12 @@ def _ddp_worker(rank, world, port, q):
     import eabnet_amd
     from torch.nn.parallel import DistributedDataParallel as DDP
     assert dist.init("gloo")
+    from operator_path import OperatorPath
     net = eabnet_amd.EaBNet(M=2, p=1, q=1)
-    ddp = DDP(net)                                     # reference: DDP(net, device_ids=[device]) train_distributed.py:198
+    # reference: DDP(net, device_ids=[device]) train_distributed.py:198.  CPU ranks have no HIP programs: the differentiable
+    # forward is the PyTorch-operator comparator (tests/operator_path.py) on the module's own parameters -- what is under test
+    # here is the distributed plumbing (hooks, bucket all-reduce, identical replicas), which does not care
+    ddp = DDP(OperatorPath(net))
     opt = torch.optim.Adam(ddp.parameters(), lr=5e-4)
     losses = []
     for it in range(2):

@@ -30,18 +30,27 @@ def _model(M, seed, dev, **kw):
 
 
 # ------------------------------------------------------------------ front end
-@pytest.mark.parametrize("N,L", [(3, 2085), (2, 161), (1, 64000)])
-def test_stft_frame_indexing_bit_exact(dev, N, L):
+@pytest.mark.parametrize("B,M,L,n_fft,hop", [(1, 3, 2085, 320, 160), (2, 1, 161, 320, 160), (1, 8, 64000, 320, 160),
+                                             (2, 11, 64000, 320, 160), (1, 16, 8004, 320, 160), (2, 5, 4096, 256, 64),
+                                             (1, 9, 1003, 256, 64)])
+def test_stft_frame_indexing_bit_exact(dev, B, M, L, n_fft, hop):
+    """north_star: "bit-exact for STFT frame indexing" (train_distributed.py:83, torch.stft centre / reflect framing).
+    eab_stft_frames_f32 runs the PRODUCT kernel (stft_fft_kernel, the instance eab_stft_compress_f32 picks for these sizes)
+    compiled to store the rows it gathered instead of transforming them, so both of its gather paths are what is compared:
+    the four-samples-per-load path of interior frames (L and n_fft multiples of 4: 64000, 8004, 4096) and the reflected scalar
+    path (first / last frame of every utterance; every frame when L % 4 != 0: 2085, 161, 1003); M > 8 takes a second pass
+    over the microphones, M = 11 / 9 / 5 / 3 leave a partial pass."""
     from eabnet_amd import _lib
     from oracle import eabnet_oracle as orc
     lib = _lib.load()
-    wav = torch.from_numpy(paramgen.make_wave(1, N, L, 40)[0])
-    T = 1 + L // 160
+    wav = torch.from_numpy(paramgen.make_wave(B, M, L, 40 + M))
+    T = 1 + L // hop
     d_w = wav.to(dev)
-    frames = torch.empty(N, T, 320, device=dev)
-    _lib.check(lib.eab_stft_frames_f32(d_w.data_ptr(), frames.data_ptr(), N, L, 320, 160, None))
+    frames = torch.full((B, M, T, n_fft), float("nan"), device=dev)
+    _lib.check(lib.eab_stft_frames_f32(d_w.data_ptr(), frames.data_ptr(), B, M, L, n_fft, hop, None))
     torch.cuda.synchronize()
-    assert torch.equal(frames.cpu(), orc.stft_frames(wav, 320, 160))
+    want = orc.stft_frames(wav.reshape(B * M, L), n_fft, hop).reshape(B, M, T, n_fft)
+    assert torch.equal(frames.cpu(), want)
 
 
 @pytest.mark.parametrize("name", ["stft_B1_M2_L1600.npz", "stft_B2_M8_L4000.npz", "stft_B1_M3_L2085.npz",
@@ -468,8 +477,8 @@ def test_weights_are_repacked_after_update(dev):
 
 
 def test_training_forward_matches_hip_inference_and_steps(dev):
-    """Differentiable forward (PyTorch-ROCm operators, autograd_path.py) == HIP inference forward within
-    the parity bar, and one optimiser step of the reference's loop (train_distributed.py:218-230) runs."""
+    """Differentiable forward (the HIP training programs, eabnet_amd/train.py) == HIP inference forward within the parity
+    bar, and one optimiser step of the reference's loop (train_distributed.py:218-230) runs."""
     import eabnet_amd
     net = _model(4, 150, dev)
     x = torch.from_numpy(paramgen.make_spec_input(2, 30, 161, 4, 151)).to(dev)
@@ -478,10 +487,8 @@ def test_training_forward_matches_hip_inference_and_steps(dev):
         y_hip = net(x)
     net.train()
     y_tr = net(x)                                   # grad enabled, parameters require grad
-    assert y_tr.requires_grad
-    # MIOpen's fp32 convolution algorithms are looser than the 1e-4 inference bar (measured 2e-4 here);
-    # the path's math itself is pinned against the oracle at 1e-5 on CPU (tests/test_cabi.py)
-    assert_close(y_tr.detach().cpu().numpy(), y_hip.cpu().numpy(), 1e-3)
+    assert y_tr.requires_grad and net.training_backend == "hip"
+    assert_close(y_tr.detach().cpu().numpy(), y_hip.cpu().numpy(), TOL_HIP)
     opt = torch.optim.Adam(net.parameters(), lr=5e-4)
     loss = eabnet_amd.com_mag_mse_loss(y_tr, label, [30, 30])
     loss.backward()
@@ -491,6 +498,31 @@ def test_training_forward_matches_hip_inference_and_steps(dev):
     with torch.no_grad():                           # updated weights are re-packed for the HIP program
         y2 = net.eval()(x)
     assert not torch.equal(y2, y_hip) and torch.isfinite(y2).all()
+
+
+def test_differentiable_calls_outside_the_training_programs_are_refused(dev):
+    """One backend: what the HIP training programs do not cover raises instead of running anywhere else -- a gradient
+    w.r.t. the input spectrogram, BatchNorm in eval mode under autograd, CPU tensors -- for both networks."""
+    import eabnet_amd
+    from eabnet_amd import _lib
+    net = _model(2, 153, dev).train()
+    x = torch.from_numpy(paramgen.make_spec_input(1, 12, 161, 2, 154)).to(dev)
+    with pytest.raises(NotImplementedError, match="input requires grad"):
+        net(x.clone().requires_grad_(True))
+    with pytest.raises(_lib.EabError, match="no CPU fallback"):
+        net(x.cpu())
+    bn = _model(2, 155, dev, norm_type="BN")        # .eval()
+    with pytest.raises(NotImplementedError, match="eval mode"):
+        bn(x)
+    with torch.no_grad():
+        assert torch.isfinite(bn(x)).all()          # inference is what eval mode is for
+    gag = eabnet_amd.GaGNet(p=1, q=1, dilas=(1, 2)).to(dev).train()
+    a = _planar(1, 12, 156).to(dev)
+    with pytest.raises(NotImplementedError, match="requires grad"):
+        gag(a, a.clone().requires_grad_(True))
+    with pytest.raises(_lib.EabError, match="no CPU fallback"):
+        gag(a.cpu(), a.cpu())
+    assert not hasattr(net, "use_hip_training")
 
 
 # ------------------------------------------------------------------ post-filter (SURVEY §8f N1)
@@ -729,6 +761,69 @@ def test_two_stage_training_step_with_flat_allreduce(dev):
         assert rel <= 1e-5, rel                      # (atomics order in the weight gradients)
     finally:
         dist.destroy_process_group()
+
+
+def test_branch_programs_replay_across_a_process_group_lifetime(dev):
+    """The crashing combination of round 3 (hip::Graph::UpdateStreams <- hipGraphLaunch): a post-filter program with parallel
+    branches captured BEFORE a process group exists, replayed while it is alive (and after it is gone).  The branches replay
+    as separate single-stream hipGraphs now (eabnet_amd/graphs.py), which never enter the runtime's stream assignment; the
+    results stay bit-identical to direct single-stream launches, for inference and for a training step."""
+    import os
+    import torch.distributed as dist
+    import eabnet_amd
+    from eabnet_amd import graphs
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    torch.manual_seed(11)
+    net = eabnet_amd.GaGNet(p=1, q=2, dilas=(1, 2)).to(dev).eval()
+    mk = lambda seed: torch.from_numpy(np.ascontiguousarray(                       # noqa: E731
+        paramgen.make_spec_input(2, 24, 161, 1, seed)[..., 0, :].transpose(0, 3, 1, 2))).to(dev)
+    a, b = mk(801), mk(802)
+    with torch.no_grad():
+        y0 = [t.clone() for t in net(a, b)]                                        # captured here: no process group yet
+    bound = net._last[0]
+    assert isinstance(bound.graph, graphs.LaneGraphs) and bound.graph.n_graphs > 1, "branches must be separate graphs"
+    assert all(e[0] != graphs.RUN or e[1] in (0, 1, 2) for e in bound.graph.plan)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        t = torch.ones(4, device=dev)
+        dist.all_reduce(t)                                                         # the communicator (and its streams) exist
+        with torch.no_grad():
+            for _ in range(3):
+                y1 = net(a, b)
+        assert net._last[0] is bound, "the program captured before init_process_group is the one replayed"
+        assert all(torch.equal(u, v) for u, v in zip(y0, y1))
+        # training programs of the same network: captured while the group is alive, replayed after it is gone
+        net.train()
+        out = net(a, b)
+        sum(o.square().mean() for o in out).backward()
+        g_alive = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()
+        assert net.training_backend == "hip" and torch.isfinite(g_alive).all()
+    finally:
+        dist.destroy_process_group()
+    for p in net.parameters():
+        p.grad = None
+    out = net(a, b)
+    sum(o.square().mean() for o in out).backward()
+    g_after = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    rel = float((g_after - g_alive).norm() / g_alive.norm())
+    assert rel <= 1e-5, rel                                                        # (atomics order in the weight gradients)
+    with torch.no_grad():
+        y2 = net.eval()(a, b)
+    assert all(torch.equal(u, v) for u, v in zip(y0, y2))
+    # single-stream reference: the same program without branches
+    os.environ["EAB_GRAPH_BRANCHES"] = "0"
+    try:
+        ref = eabnet_amd.GaGNet(p=1, q=2, dilas=(1, 2)).to(dev).eval()
+        ref.load_state_dict(net.state_dict())
+        with torch.no_grad():
+            y3 = ref(a, b)
+        assert ref._last[0].graph.n_graphs == 1
+    finally:
+        del os.environ["EAB_GRAPH_BRANCHES"]
+    assert all(torch.equal(u, v) for u, v in zip(y0, y3))
 
 
 def _free_port() -> int:
@@ -1282,11 +1377,10 @@ def test_hip_training_batchnorm_train_mode_vs_oracle_autograd(dev, M, B, T, pq):
         np.testing.assert_allclose(net.get_buffer(f"{k}.norm.running_mean").cpu().numpy(), rm.numpy(), rtol=2e-5, atol=1e-6, err_msg=k)
         np.testing.assert_allclose(net.get_buffer(f"{k}.norm.running_var").cpu().numpy(), rv.numpy(), rtol=2e-5, atol=1e-6, err_msg=k)
         assert int(net.get_buffer(f"{k}.norm.num_batches_tracked")) == int(P[f"{k}.norm.num_batches_tracked"]) + 1
-    # eval mode under autograd keeps the operator path (running statistics), with a warning
+    # eval mode under autograd is refused (one backend: the training programs implement BatchNorm's train mode)
     net.eval()
-    with pytest.warns(RuntimeWarning):
-        y2 = net(x.to(dev))
-    assert y2.requires_grad and net.training_backend == "operators"
+    with pytest.raises(NotImplementedError, match="eval mode"):
+        net(x.to(dev))
 
 
 def _train_variants():
@@ -1543,13 +1637,13 @@ def test_hip_training_of_every_post_filter_variant_vs_oracle_autograd(dev, name)
 
 def test_hip_training_step_matches_operator_path(dev):
     """One optimiser step of the reference's loop (train_distributed.py:218-230: forward, loss, backward, clip, Adam)
-    on the HIP training programs against the same step on the PyTorch-ROCm operator path (autograd_path.py): same
+    on the HIP training programs against the same step on the PyTorch-ROCm operator comparator (tests/operator_path.py): same
     loss, same clipped-gradient norm, and the updated model gives the same inference output."""
     import copy
     import eabnet_amd
+    from operator_path import OperatorPath
     net = _model(4, 930, dev, p=2, q=1)
-    ref = copy.deepcopy(net)
-    ref.use_hip_training = False
+    ref = OperatorPath(copy.deepcopy(net))
     x = torch.from_numpy(paramgen.make_spec_input(2, 24, 161, 4, 931)).to(dev)
     label = torch.from_numpy(paramgen.make_spec_input(2, 24, 161, 1, 932)[..., 0, :]).permute(0, 3, 1, 2).contiguous().to(dev)
     out = []
@@ -1587,8 +1681,8 @@ def test_config3_full_size_three_adam_steps_vs_operator_path(dev):
                 p.copy_(torch.empty(p.shape).uniform_(0.5, 1.5, generator=g))
             elif n.endswith("norm.bias"):
                 p.copy_(torch.empty(p.shape).uniform_(-0.3, 0.3, generator=g))
-    ref = copy.deepcopy(net)
-    ref.use_hip_training = False
+    from operator_path import OperatorPath
+    ref = OperatorPath(copy.deepcopy(net))
     args = argparse.Namespace(mics=M, sr=16000, wav_len=6.0, win_size=0.020, win_shift=0.010, fft_num=320)
     wav = (0.05 * torch.randn(B, M, L, generator=g)).to(dev)
     tgt = (0.05 * torch.randn(B, 1, L, generator=g)).to(dev)
@@ -1611,7 +1705,7 @@ def test_config3_full_size_three_adam_steps_vs_operator_path(dev):
             ls.append(float(loss))
         losses.append(ls)
         torch.cuda.empty_cache()
-    assert net.training_backend == "hip" and ref.training_backend == "operators"
+    assert net.training_backend == "hip" and ref.net.training_backend is None
     for a, b in zip(*losses):
         assert abs(a - b) <= 1e-4 * abs(b), losses
     assert all(np.isfinite(losses[0])) and bool(torch.isfinite(grads[0]).all())
@@ -1703,10 +1797,10 @@ def test_bf16_training_gradients_vs_fp64_oracle_and_the_references_own_bf16_mode
             y = net(x.to(dev))
             assert net.training_backend == "hip"
         else:
-            net.use_hip_training = False
+            from operator_path import forward_autograd
             with torch.autocast("cuda", dtype=torch.bfloat16):
-                y = net(x.to(dev))
-            assert net.training_backend == "operators"
+                y = forward_autograd(net, x.to(dev))
+            assert net.training_backend is None
         eabnet_amd.com_mag_mse_loss(y.float(), label.to(dev), frames).backward()
         return {k: net.get_parameter(k).grad.detach().cpu().double() for k in ref}
     g_hip, g_ac = grads_of(True), grads_of(False)

@@ -1,6 +1,7 @@
 """In-kernel phase timing of the small-tile convolution launches (csrc/conv_st.hip): every workgroup stamps s_memtime at
 start / tables ready / A burst stored / barrier passed / main loop done / stores drained into a debug buffer
-(eab_conv_desc.glu_dump, unused by that kernel otherwise).  Prints per launch kind the median phase durations in cycles.
+(eab_conv_desc.glu_dump, unused by that kernel otherwise).  Needs a diagnostic build of the library:
+`make -C eabnet_amd/csrc clean && make -C eabnet_amd/csrc -j8 EXTRA=-DEAB_ST_STAMPS` (the production build refuses a glu_dump here).  Prints per launch kind the median phase durations in cycles.
     python tools/diag_st_stamps.py [B] [T]"""
 import os, sys, collections
 import numpy as np
