@@ -50,6 +50,7 @@ class ConvDesc(C.Structure):
         ("ph1_dt", C.c_int32 * MAX_TAPS), ("ph1_ioff", C.c_int32 * MAX_TAPS),
         ("f2_w", C.c_void_p), ("f2_dst", C.c_void_p), ("f2_stats", C.c_void_p), ("f2_stat_slope0", C.c_void_p),
         ("f2_stat_slope1", C.c_void_p), ("f2_N", C.c_int32), ("f2_nsets", C.c_int32), ("f2_stat_tiles", C.c_int32),
+        ("p2_mask1", C.c_int32),
     ]
 
 

@@ -38,6 +38,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define CG_PLAIN 0
 #define CG_GLU 1     // value/gate columns of ONE GEMM (GateConv2d / GateConvTranspose2d)
 #define CG_DUAL 2    // value/gate columns see the SAME source through two transforms (S-TCM branches)
+#define CG_PH2 3     // EAB_EPI_PHASE2: the two output-column phases of a stride-2 transposed convolution from ONE staged input
+                     // patch: column pairs (phase 0, phase 1) of a channel share a lane like (value, gate) of the GLU form
 #define CG_XFC 128   // max channels of a source that carries a fused transform
 
 #define CG_PMAX 352  // input positions of one patch (PATCH mode): 352 * 80 B = 27.5 KB, three workgroups per CU
@@ -117,11 +119,15 @@ __device__ __forceinline__ void cg_split2(float x0, float x1, unsigned& hi, unsi
 }
 
 template <int MI, int NI, int KU, int MODE, int XF, bool VEC, int PREC, bool PATCH>
-__global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE == CG_GLU) ? 3 : 1) void conv_gemm_kernel(const eab_conv_desc d) {
+__global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE == CG_GLU) ? 3 : (MODE == CG_PH2 ? 2 : 1)) void conv_gemm_kernel(const eab_conv_desc d) {
+    // (workgroups per CU the register budget is cut for: three for the gated 128x128 tiles -- 168 registers, no spills --, two
+    // for the phase-pair form, whose fused transform and second store stream do not fit 168)
+    static_assert(MODE != CG_PH2 || (PATCH && NI == 2), "phase-pair form: patch pipeline, one column block per phase and wave");
     static_assert(!PATCH || (KU == 1 && MODE != CG_DUAL && VEC), "patch mode: one unit per stage, single transform");
     constexpr bool H3 = PREC == EAB_PREC_F16X3;
     constexpr bool BF = PREC == EAB_PREC_BF16;       // fp32 in memory, operands rounded to bf16 on their way into LDS, ONE bf16 MFMA
-    constexpr bool GLU = MODE != CG_PLAIN;          // gated epilogue (value tile, gate tile per lane)
+    constexpr bool PH2 = MODE == CG_PH2;            // (phase 0, phase 1) column pair per lane; own epilogue
+    constexpr bool GLU = MODE != CG_PLAIN;          // paired columns per lane: gated epilogue (value tile, gate tile) / phase pair
     constexpr bool DUAL = MODE == CG_DUAL;
     using Smem = CgSmem<MI, NI, KU, MODE, PATCH>;
     constexpr int BM = Smem::BM, BN = Smem::BN, LDK = Smem::LDK;
@@ -365,21 +371,23 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
                 }
             }
         };
-        auto pcompute = [&](int cur, int tap) {
+        // ne = column blocks that take part (phase-pair form: a tap that feeds phase 0 only skips the phase-1 block)
+        auto pcompute_n = [&](int cur, int tap, auto ne_c) {
+            constexpr int NE = decltype(ne_c)::value;
             const int toff = (sm.dt[tap] * Fp + sm.ioff[tap]) * LDK;  // per-tap shift inside the patch (wave-uniform)
             if (BF) {
-                bf16x8 ab[MI], bb[NI];
+                bf16x8 ab[MI], bb[NE];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) ab[mi] = *reinterpret_cast<const bf16x8*>(&sm.a[fa[mi] + toff]);
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) bb[ni] = *reinterpret_cast<const bf16x8*>(&sm.b[cur][b_base + ni * 32 * LDK]);
+                for (int ni = 0; ni < NE; ++ni) bb[ni] = *reinterpret_cast<const bf16x8*>(&sm.b[cur][b_base + ni * 32 * LDK]);
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
+                    for (int ni = 0; ni < NE; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[mi], bb[ni], acc[mi][ni], 0, 0, 0);
             } else if (H3) {
-                h16x8 ah[MI], al[MI], bh[NI], bl[NI];
+                h16x8 ah[MI], al[MI], bh[NE], bl[NE];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     const char* pa = reinterpret_cast<const char*>(&sm.a[fa[mi] + toff]);
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
                     al[mi] = *reinterpret_cast<const h16x8*>(pa + 32);
                 }
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
+                for (int ni = 0; ni < NE; ++ni) {
                     const char* pb = reinterpret_cast<const char*>(&sm.b[cur][b_base + ni * 32 * LDK]);
                     bh[ni] = *reinterpret_cast<const h16x8*>(pb);
                     bl[ni] = *reinterpret_cast<const h16x8*>(pb + 32);
@@ -395,7 +403,7 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
+                    for (int ni = 0; ni < NE; ++ni) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
@@ -403,21 +411,26 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
             } else {
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
-                    f32x4 af[MI], bf[NI];
+                    f32x4 af[MI], bf[NE];
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const f32x4*>(&sm.a[fa[mi] + toff + g * 8]);
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
+                    for (int ni = 0; ni < NE; ++ni)
                         bf[ni] = *reinterpret_cast<const f32x4*>(&sm.b[cur][b_base + ni * 32 * LDK + g * 8]);
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                            for (int ni = 0; ni < NI; ++ni)
+                            for (int ni = 0; ni < NE; ++ni)
                                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][k], bf[ni][k], acc[mi][ni], 0, 0, 0);
                 }
             }
+        };
+        const unsigned p2mask = PH2 ? (unsigned)d.p2_mask1 : ~0u;
+        auto pcompute = [&](int cur, int tap) {
+            if (PH2 && !((p2mask >> tap) & 1u)) pcompute_n(cur, tap, std::integral_constant<int, 1>{});   // (wave-uniform)
+            else pcompute_n(cur, tap, std::integral_constant<int, NI>{});
         };
 
         patch_fetch(0);
@@ -749,6 +762,60 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
 
     const unsigned row_bytes = (unsigned)(d.Fout * Cout) * 4u, step_bytes = (unsigned)(d.ostride * Cout) * 4u;
     const unsigned phase_bytes = (unsigned)(d.ophase * Cout) * 4u;
+    if constexpr (PH2) {
+        // ---- phase-pair epilogue (EAB_EPI_PHASE2): row q = (t, o) of the tile owns out[t][2o] (accumulator block 0) and
+        // out[t][2o+1] (block 1; it exists while 2o+1 < Fout, i.e. not for the last o of a frame when Fout is odd).  Both
+        // belong to channel ch[0], so the InstanceNorm partial of the channel takes both (shifted single pass as below; the
+        // shift is the lane's first phase-0 value -- a row past the tile's end repeats a valid row there, any finite shift
+        // gives the same (mean, M2)).  Straight-line code; FULL = no row of the tile lies past the end.
+        const float a = st_slope[0][0];
+        const float k0 = eab_prelu(acc[0][0][0] + bias_v[0], a);
+        const unsigned chan_bytes = (unsigned)Cout * 4u;
+        float su = 0.0f, sq = 0.0f, cnt = 0.0f;
+        auto ph2_loop = [&](auto full_c) {
+            constexpr bool FULL = decltype(full_c)::value;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int qg = q0 + (wm * MI + mi) * 32 + 8 * r4 + 4 * lh;     // rows 4*r4 + j, j = 0..3: consecutive q
+                    const int t = cg_div((FULL || qg < Q) ? qg : 0, d.No, inv_no);
+                    int o = ((FULL || qg < Q) ? qg : 0) - t * d.No;
+                    unsigned row_start = (unsigned)t * row_bytes;
+                    unsigned cur = row_start + (unsigned)o * step_bytes;            // byte offset of out[t][2o][0]
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 4 * r4 + j;
+                        const bool ok0 = FULL || qg + j < Q;
+                        const bool ok1 = ok0 && 2 * o + 1 < d.Fout;
+                        const float v0 = acc[mi][0][r] + bias_v[0], v1 = acc[mi][1][r] + bias_v[1];
+                        const unsigned o0 = cur + 4u * ch[0];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), r_dst, ok0 ? o0 : CG_OOB, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), r_dst, ok1 ? o0 + chan_bytes : CG_OOB, 0, 0);
+                        const float e0 = eab_prelu(v0, a) - k0, e1 = eab_prelu(v1, a) - k0;
+                        const float m0 = FULL ? e0 : (ok0 ? e0 : 0.0f), m1 = ok1 ? e1 : 0.0f;
+                        su += m0;
+                        sq = fmaf(m0, m0, sq);
+                        su += m1;
+                        sq = fmaf(m1, m1, sq);
+                        cnt += (FULL ? 1.0f : (ok0 ? 1.0f : 0.0f)) + (ok1 ? 1.0f : 0.0f);
+                        cur += step_bytes;
+                        if (++o == d.No) {
+                            o = 0;
+                            row_start += row_bytes;
+                            cur = row_start;
+                        }
+                    }
+                }
+            }
+        };
+        if (q0 + BM <= Q) ph2_loop(std::true_type{});
+        else ph2_loop(std::false_type{});
+        skk[0][0] = k0;
+        ssum[0][0] = su;
+        ssq[0][0] = sq;
+        scount = cnt;
+    } else {
     // Fast path (workgroup-uniform): a full tile with the plain / gated epilogue and at most one statistics set -- every
     // 2-D convolution of the inference program except the last tile of a batch element.  Straight-line code: no per-row
     // masks, no per-element dispatch on the epilogue kind.  Values are computed by the same expressions as below (a row's
@@ -925,6 +992,7 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
         }
     }
 
+    }
     if (d.stats) {
         // per lane: (n, mean, M2) from the shifted sums; then lanes l and l^32 (same columns), then
         // the two wm waves through LDS; fixed order everywhere => bit-reproducible partials.
@@ -1062,6 +1130,9 @@ static int cg_launch(const eab_conv_desc* d, hipStream_t s) {
             return EAB_EUNSUPPORTED;
         }
     }
+    if constexpr (MODE == CG_PH2) {
+        return EAB_EUNSUPPORTED;                 // the phase-pair form exists in the patch pipeline only
+    } else {
     if (d->precision == EAB_PREC_F16X3) {
         if constexpr (VEC)
             hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, KU, MODE, XF, VEC, EAB_PREC_F16X3, false>), grid,
@@ -1079,6 +1150,7 @@ static int cg_launch(const eab_conv_desc* d, hipStream_t s) {
                            s, *d);
     }
     EAB_RETURN_LAUNCH_STATUS();
+    }
 }
 
 // worst-case number of input positions a BM-row tile touches (the kernel's P)
@@ -1127,7 +1199,7 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
         EAB_CHECK_ARG(d->dt[j] < (1 << 20) && d->dt[j] > -(1 << 20));
         EAB_CHECK_ARG(d->dt[j] <= 0 || d->korder != EAB_KORDER_CHUNK);
     }
-    EAB_CHECK_ARG(d->epi >= EAB_EPI_LINEAR && d->epi <= EAB_EPI_DUALGATE);
+    EAB_CHECK_ARG(d->epi >= EAB_EPI_LINEAR && d->epi <= EAB_EPI_PHASE2);
     EAB_CHECK_ARG(d->precision == EAB_PREC_F32 || d->precision == EAB_PREC_F16X3 || d->precision == EAB_PREC_BF16);
     EAB_CHECK_ARG(d->korder == EAB_KORDER_TAP || d->korder == EAB_KORDER_CHUNK || d->korder == EAB_KORDER_FRAG);
     EAB_CHECK_ARG(d->korder == EAB_KORDER_FRAG || d->ph1_No == 0);
@@ -1141,7 +1213,17 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
     }
     const bool dual = d->epi == EAB_EPI_DUALGATE;
     const bool glu = d->epi == EAB_EPI_GLU;
-    EAB_CHECK_ARG(d->Cout == ((glu || dual) ? d->N / 2 : d->N));
+    const bool ph2 = d->epi == EAB_EPI_PHASE2;
+    EAB_CHECK_ARG(d->Cout == ((glu || dual || ph2) ? d->N / 2 : d->N));
+    if (ph2) {
+        // phase pair of a stride-2 transposed convolution: patch pipeline only, rows (t, o) with out[t][2o], out[t][2o+1];
+        // one InstanceNorm set at most, no aux / running-sum operand, no streaming window (the small-tile kernel serves those)
+        EAB_CHECK_ARG(d->korder == EAB_KORDER_CHUNK && d->N == 128 && d->ostride == 2 && d->ophase == 0 && d->istride == 1);
+        EAB_CHECK_ARG(2 * d->No - 1 <= d->Fout && d->Fout <= 2 * d->No && d->nsets <= 1 && !d->dst_acc && !d->aux && !d->win.pos);
+        EAB_CHECK_ARG((d->p2_mask1 & 1) == 1 && (unsigned)d->p2_mask1 < (1u << d->ntaps) && !d->fz_counter && !d->glu_dump);
+    } else {
+        EAB_CHECK_ARG(d->p2_mask1 == 0);
+    }
     // one batch element of a source / of the output must be addressable with a 31-bit byte
     // offset, and rows per batch element must stay exact in the fp32-reciprocal division
     const long long per_b = (long long)d->T * d->Fin * (d->C0 > d->C1 ? d->C0 : d->C1) * 4;
@@ -1188,6 +1270,12 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
     if (d->korder == EAB_KORDER_CHUNK) ku = 1;
     if (ku == 4 && !(mi == 1 && !glu && vec)) ku = 1;       // KU = 4 exists for the 64-row plain / dual tiles only
     if (ku == 2 && (!vec || dual)) ku = 1;
+    if (ph2) {
+        if (!vec || xf == EAB_XF_PRELU_NORM) return EAB_EUNSUPPORTED;
+        if (xf == EAB_XF_NORM_PRELU)
+            return mi == 2 ? cg_launch<2, 2, 1, CG_PH2, EAB_XF_NORM_PRELU, true>(d, s) : cg_launch<1, 2, 1, CG_PH2, EAB_XF_NORM_PRELU, true>(d, s);
+        return mi == 2 ? cg_launch<2, 2, 1, CG_PH2, EAB_XF_NONE, true>(d, s) : cg_launch<1, 2, 1, CG_PH2, EAB_XF_NONE, true>(d, s);
+    }
     if (dual) {
         if (d->N != 128 || mi != 1 || xf != EAB_XF_PRELU_NORM) return EAB_EUNSUPPORTED;
         return cg_pick_ku<1, 2, CG_DUAL, EAB_XF_PRELU_NORM, true>(d, s, ku == 2 ? 1 : ku);

@@ -84,9 +84,10 @@ class LaneGraphs:
         self.device, self.plan, self.launch = device, plan, launch
         self.side: Dict[int, torch.cuda.Stream] = {}
         self.graphs: Dict[Tuple[int, int], torch.cuda.CUDAGraph] = {}
-        for e in plan:
-            if e[0] == RUN and e[1] != 0 and e[1] not in self.side:
-                self.side[e[1]] = torch.cuda.Stream(device=device)
+        for e in plan:                          # every lane a run or a mark names (a forked lane may carry no op)
+            for l in ([e[1]] if e[0] == RUN else e[1]):
+                if l != 0 and l not in self.side:
+                    self.side[l] = torch.cuda.Stream(device=device)
 
     @property
     def n_graphs(self) -> int:

@@ -175,7 +175,7 @@ class _Bound:
                 d.fz_eps = float(op.fz_eps)
                 for f in ("C0", "C1", "xf_mode", "N", "Kpad", "B", "T", "Fin", "Fout", "No", "ostride", "ophase",
                           "istride", "epi", "Cout", "nsets", "stat_tiles", "stat_tile0", "bm", "fin_tiles",
-                          "fin_nsets", "fin_count", "precision", "korder"):
+                          "fin_nsets", "fin_count", "precision", "korder", "p2_mask1"):
                     setattr(d, f, int(getattr(op, f)))
                 d.fin_eps = float(op.fin_eps)
                 d.ntaps = len(op.dt)

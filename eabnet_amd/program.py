@@ -30,7 +30,7 @@ from .spec import GagConfig, NetConfig, gag_param_specs, param_specs, unet_decod
 
 # mirrors of the C enums (include/eabnet_hip.h)
 XF_NONE, XF_NORM_PRELU, XF_PRELU_NORM = 0, 1, 2
-EPI_LINEAR, EPI_GLU, EPI_RELU, EPI_MULSIG, EPI_ADD, EPI_DUALGATE = 0, 1, 2, 3, 4, 5
+EPI_LINEAR, EPI_GLU, EPI_RELU, EPI_MULSIG, EPI_ADD, EPI_DUALGATE, EPI_PHASE2 = 0, 1, 2, 3, 4, 5, 6
 OP_CONV, OP_IN_FINALIZE, OP_NORM_ACT, OP_LSTM64, OP_BFW_FS, OP_MEMSET0, OP_GAG_PACK, OP_GAG_CRM = 1, 2, 3, 4, 5, 6, 7, 8
 OP_CLN_STATS, OP_CLN_APPLY, OP_GATE_ROWS = 33, 34, 35
 OP_CONV_CHAIN = 9        # run-time only (model._Bound): a run of small-tile launches executed by one launch (csrc/conv_st.hip)
@@ -148,6 +148,8 @@ class ConvOp:
     f2_N: int = 0
     f2_nsets: int = 0
     f2_stat_tiles: int = 0
+    # EPI_PHASE2: bit j = tap j also feeds the phase-1 columns (eab_conv_desc.p2_mask1)
+    p2_mask1: int = 0
 
 
 @dataclass
@@ -478,6 +480,9 @@ class Lowering:
             raise ValueError(f"precision must be 'f32', 'f16x3' or 'bf16', got {precision!r}")
         self.precision = precision
         self.patch = os.environ.get("EAB_PATCH", "1") != "0"      # tuning knob: 0 = gather pipeline everywhere
+        # both output-column phases of a unit transposed convolution in one launch on one staged patch (EPI_PHASE2); 0 = one
+        # gather launch per phase (rounds 1-3)
+        self.phase2 = os.environ.get("EAB_PHASE2", "1") != "0"
         # small-tile kernel (csrc/conv_st.hip; exact fp32 or bf16 products) for the latency-bound launches: the S-TCN and the 64-column unit
         # convolutions with at most `st_maxno` output columns; EAB_ST=0 puts everything back on conv_gemm_kernel
         self.st = os.environ.get("EAB_ST", "1") != "0" and precision in ("f32", "bf16")
@@ -606,7 +611,8 @@ class Lowering:
                   dst: Ref, stats: Optional[Ref] = None, nsets: int = 0, stat_slopes=(None, None),
                   stat_tiles: int = 0, stat_tile0: int = 0, bm: Optional[int] = None, aux: Optional[Ref] = None,
                   dst_acc: Optional[Ref] = None, fin: Optional[dict] = None, slope1: Optional[Ref] = None,
-                  xf1: Optional[Ref] = None, patch_ok: bool = True, st: bool = False, ph1: Optional[dict] = None) -> ConvOp:
+                  xf1: Optional[Ref] = None, patch_ok: bool = True, st: bool = False, ph1: Optional[dict] = None,
+                  p2_mask1: int = 0) -> ConvOp:
         """fin = dict(stats, tiles, nsets, count, norms=[...]) asks the kernel to reduce the
         producer's InstanceNorm partials itself (single source, transform order from srcs[0].mode);
         slope1 (+ xf1 when the table is static) = second transform of the SAME source for EPI_DUALGATE.
@@ -657,6 +663,9 @@ class Lowering:
                     break
             if korder == KORDER_CHUNK and bm_p != bm:
                 korder = KORDER_TAP        # tile counts of the statistics were planned for bm
+        if epi == EPI_PHASE2:              # phase pair of a transposed convolution: exists in the patch pipeline only
+            assert not st and N == 128 and patch_positions(bm, No, s0.F, istride, dt, ioff) <= PATCH_MAX and mode != XF_PRELU_NORM
+            korder = KORDER_CHUNK
         if korder == KORDER_CHUNK:
             key = next(k for k, r in self.W.index.items() if r == w)
             wt = self.W.chunks_by_name[key].reshape(N, len(dt), upt, 16)
@@ -684,12 +693,16 @@ class Lowering:
                     slope0=s0.slope, slope1=sl1, C0=C0, C1=C1, xf_mode=mode, w=w, bias=bias,
                     N=N, Kpad=Kpad, B=self.B, T=self.T, Fin=s0.F, Fout=Fout, No=No, ostride=ostride, ophase=ophase,
                     istride=istride, dt=list(dt), ioff=list(ioff), epi=epi, aux=aux, dst=dst, dst_acc=dst_acc,
-                    Cout=N // 2 if epi in (EPI_GLU, EPI_DUALGATE) else N, stats=stats, nsets=nsets,
+                    Cout=N // 2 if epi in (EPI_GLU, EPI_DUALGATE, EPI_PHASE2) else N, stats=stats, nsets=nsets,
                     stat_slope0=stat_slopes[0], stat_slope1=stat_slopes[1], stat_tiles=stat_tiles,
                     stat_tile0=stat_tile0, bm=bm, name=name, precision=prec, korder=korder, win=bool(self.chunk),
-                    **finkw, **ph1kw)
+                    p2_mask1=p2_mask1, **finkw, **ph1kw)
         self.ops.append(op)
-        self.flops += 2 * self.B * self.T * No * N * len(dt) * (C0 + C1)
+        if epi == EPI_PHASE2:              # phase-1 columns take the masked taps only, and one column fewer when Fout is odd
+            n1 = bin(p2_mask1).count("1")
+            self.flops += 2 * self.B * self.T * (N // 2) * (C0 + C1) * (No * len(dt) + (Fout // 2) * n1)
+        else:
+            self.flops += 2 * self.B * self.T * No * N * len(dt) * (C0 + C1)
         return op
 
     def fuse_finalize(self, ops: Sequence[ConvOp], C: int, norms: Sequence[str]) -> List[Ref]:
@@ -817,7 +830,41 @@ class Lowering:
             wref = self.W.add(f"{wkey}.weight#{tag}.ph{ph}", wp)
             phases.append(dict(w=wref, Kpad=wp.shape[1], No=No[ph], ophase=ph, dt=[-a for a, _ in taps],
                                ioff=[-(c - ph) // 2 for _, c in taps]))
-        if st:
+        # (InstanceNorm configurations only: BatchNorm / cLN programs can be streamed, and a streamed program must run the
+        # kernels -- the summation orders -- of its offline twin; those keep one launch per phase)
+        fused = (not st and not glu and self.phase2 and self.patch and not self.chunk and not self.bn and not self.cln
+                 and N == 64 and Cin % 4 == 0 and all(s.C % 4 == 0 for s in srcs))
+        if fused:
+            # ONE launch for both output-column phases on ONE staged input patch (EPI_PHASE2, conv_gemm.hip): virtual
+            # convolution with 2N columns (phase-0 rows, phase-1 rows of a channel paired like value / gate of the GLU form)
+            # over the union of the two phases' taps; a tap that only phase 0 uses has zero phase-1 rows, skipped in the kernel.
+            # The input is fetched and transformed once instead of once per (phase, tap): 3 -> 1 for the (1,3) unit kernels.
+            shifts = sorted({(a, c // 2) for a in range(kt) for c in range(kf)})      # (kt index, input shift o - fi)
+            wv = np.zeros((2 * N, Cin, len(shifts)), dtype=np.float32)
+            mask1 = 0
+            for j, (a, sft) in enumerate(shifts):
+                wv[:N, :, j] = wn[:, :, a * kf + 2 * sft]                              # phase 0: kf = 2 * shift
+                if 2 * sft + 1 < kf:
+                    wv[N:, :, j] = wn[:, :, a * kf + 2 * sft + 1]                      # phase 1: kf = 2 * shift + 1
+                    mask1 |= 1 << j
+            dts, ios = [-a for a, _ in shifts], [-sft for _, sft in shifts]
+            bm_f = self.pick_bm(No[0])
+            fused = (mask1 & 1) == 1 and patch_positions(bm_f, No[0], Fin, 1, dts, ios) <= PATCH_MAX
+        if fused:
+            order2 = glu_row_order(2 * N)
+            wp = pack_taps(wv[order2], list(range(len(shifts))))
+            wref = self.W.add(f"{wkey}.weight#phase2", wp)
+            b2 = np.concatenate([self.P[f"{wkey}.bias"]] * 2)[order2]
+            bref2 = self.W.add(f"{wkey}.bias#phase2", b2)
+            bm = bm_f
+            tiles = [conv_tiles(self.T, No[0], bm)]
+            if stats is not None:              # re-plan the partials for the fused launch's tiles (the region above was the
+                self.act_size = stats.off      # most recent allocation: give it back)
+                stats = self.alloc(self.B * tiles[0] * Cout * 4)
+            phase_ops.append(self.emit_conv(name, srcs, wref, bref2, 2 * N, wp.shape[1], Fout, No[0], 2, 0, 1, dts, ios, EPI_PHASE2,
+                                            dst, stats, 1 if stats else 0, (None, None), tiles[0] if stats else 0, 0, bm,
+                                            p2_mask1=mask1))
+        elif st:
             # small-tile kernel: both output-column phases in ONE launch (tiles of phase 0, then of phase 1, per utterance)
             p0, p1 = phases
             phase_ops.append(self.emit_conv(name, srcs, p0["w"], bref, N, p0["Kpad"], Fout, No[0], 2, 0, 1, p0["dt"], p0["ioff"],

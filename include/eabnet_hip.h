@@ -178,6 +178,15 @@ int eab_filter_sum_f32(const float* w, const float* x, float* y, int B, int T, i
                                * columns [0,Cout) see src0 through transform 0 (xf0/slope0), columns
                                * [Cout,2Cout) through transform 1 (xf1/slope1) of the SAME tensor;
                                * out[c] = acc[c] * sigmoid(acc[Cout + c]); rows interleaved as for GLU */
+#define EAB_EPI_PHASE2  6     /* Both output-column phases of a stride-2 transposed convolution (Deconv2dunit,
+                               * EaBNet.py:423,425) in ONE launch on ONE staged input patch (EAB_KORDER_CHUNK only):
+                               * N = 2*Cout; rows interleaved as for GLU with "value" = phase 0 and "gate" = phase 1.
+                               * Row (t, o), o < No = ceil(Fout/2), of the launch writes
+                               *     out[t][2o][c]   = acc[c]          (phase 0)
+                               *     out[t][2o+1][c] = acc[Cout + c]   (phase 1; only while 2o+1 < Fout)
+                               * ostride = 2, ophase = 0, istride = 1.  p2_mask1 bit j = tap j also feeds phase 1 (the
+                               * phase-1 rows of `w` are zero for the other taps and the kernel skips those products);
+                               * bit 0 must be set.  The statistics partial of a tile covers both phases. */
 
 typedef struct eab_conv_desc {
     /* sources, channels-last [B][T][Fin][C*]; src1 == NULL when there is no concat */
@@ -283,6 +292,8 @@ typedef struct eab_conv_desc {
     const float* f2_stat_slope0;
     const float* f2_stat_slope1;
     int32_t f2_N, f2_nsets, f2_stat_tiles;
+    /* EAB_EPI_PHASE2 only: which taps also feed the phase-1 columns (bit j = tap j); 0 otherwise */
+    int32_t p2_mask1;
 } eab_conv_desc;
 
 #define EAB_PREC_F32   0

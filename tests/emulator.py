@@ -194,6 +194,39 @@ class Emulator:
                 left = (np.arange(op.N) % 64) < 32
                 acc[..., left] += mm(G, np.nonzero(left)[0], j)
                 acc[..., ~left] += mm(G2, np.nonzero(~left)[0], j)
+        if op.epi == prg.EPI_PHASE2:
+            # both output-column phases of a stride-2 transposed convolution from one launch: row (t, o) writes
+            # out[t][2o] (packed "value" columns) and out[t][2o+1] (packed "gate" columns, while 2o+1 < Fout); phase-1 rows of
+            # the weights are zero for the taps outside p2_mask1 (checked: the kernel skips those products)
+            c = np.arange(op.N // 2)
+            rv = (c // 32) * 64 + c % 32
+            for j in range(ntaps):
+                if not (op.p2_mask1 >> j) & 1:
+                    assert not np.any(W[rv + 32, j]), "phase-1 weights of a masked tap must be zero"
+            assert op.ostride == 2 and op.ophase == 0 and op.aux is None and op.dst_acc is None and op.nsets <= 1
+            v0, v1 = acc[..., rv], acc[..., rv + 32]
+            Cout = op.N // 2
+            assert Cout == op.Cout
+            dst = self.v(op.dst, (B, T, op.Fout, Cout))
+            n1 = op.Fout // 2
+            dst[:, :, 0:2 * No:2] = v0
+            dst[:, :, 1:2 * n1:2] = v1[:, :, :n1]
+            if op.stats is not None:
+                st = self.v(op.stats, (B, op.stat_tiles, op.nsets, Cout, 4))
+                ok1 = np.tile(2 * np.arange(No) + 1 < op.Fout, T)                 # per row q = t*No + o
+                r0, r1 = v0.reshape(B, T * No, Cout), v1.reshape(B, T * No, Cout)
+                if op.stat_slope0 is not None:
+                    a = self.v(op.stat_slope0, (Cout,))
+                    r0, r1 = _prelu(r0, a), _prelu(r1, a)
+                for t in range(prg.conv_tiles(T, No, op.bm)):
+                    sl = slice(t * op.bm, (t + 1) * op.bm)
+                    blk = np.concatenate([r0[:, sl], r1[:, sl][:, ok1[sl]]], axis=1).astype(np.float64)
+                    mu = blk.mean(1)
+                    st[:, op.stat_tile0 + t, 0, :, 0] = blk.shape[1]
+                    st[:, op.stat_tile0 + t, 0, :, 1] = mu
+                    st[:, op.stat_tile0 + t, 0, :, 2] = ((blk - mu[:, None]) ** 2).sum(1)
+                    st[:, op.stat_tile0 + t, 0, :, 3] = 0.0
+            return
         if op.epi in (prg.EPI_GLU, prg.EPI_DUALGATE):
             c = np.arange(op.N // 2)
             rv = (c // 32) * 64 + c % 32

@@ -80,6 +80,17 @@ def test_plan_of_the_post_filter_programs(squeezed):
         plan = graphs.plan_segments(len(ops), tp.lanes[which], tp.sync[which])
         _check_plan(plan, len(ops), tp.lanes[which])
         assert any(e[0] == graphs.RUN and e[1] != 0 for e in plan)
+        # every lane a mark names gets a stream, also one that carries no op (the squeezed gaze block forks a lane it never uses)
+        named = {l for e in plan if e[0] != graphs.RUN for l in e[1]}
+        assert named <= _lanes_with_streams(plan)
+
+
+def _lanes_with_streams(plan):
+    """the lanes graphs.LaneGraphs creates side streams for (its constructor's rule, without a GPU)"""
+    out = set()
+    for e in plan:
+        out |= {l for l in ([e[1]] if e[0] == graphs.RUN else e[1]) if l != 0}
+    return out
 
 
 def test_branch_switch_no_longer_depends_on_a_process_group(monkeypatch):
