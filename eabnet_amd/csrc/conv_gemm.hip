@@ -483,7 +483,60 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
         tap_b0[p] = tap_b1[p] = 0u;
     }
     int g_tap = -1, g_c0 = 0;                              // tap and first channel of the next unit to fetch (u = g_tap*UPT + g_c0/16)
+    // LEAN (one unit per stage, float4 gathers, one transform): the per-stage address work is moved to where it changes.
+    // Everything that depends on the unit alone -- which source, the channel offset inside it, the weight column -- is
+    // workgroup-uniform and goes into the scalar offset operand of the buffer loads (soffset is not part of the range check,
+    // so an out-of-range row stays out of range); the per-row byte offset of a tap's source position, with the thread's own
+    // 16-byte channel group folded in, is computed once per tap.  Per stage that leaves one compare and one select per row
+    // (rounds 1-3: ~30 vector instructions per stage, more than the MFMAs of a 64-column tile cost).  Same loads, same values.
+    constexpr bool LEAN = KU == 1 && VEC && !DUAL;
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, (unsigned)d.N * d.Kpad * 4u, 0x00020000);
+    unsigned w_off[NI];
+#pragma unroll
+    for (int p = 0; p < NI; ++p) w_off[p] = (unsigned)((n_blk + srow + 64 * p) * d.Kpad + skq * 4) * 4u;
     auto fetch = [&](int stage, Stage& rg) {
+        if constexpr (LEAN) {
+            const int u = stage;                                // (callers never ask for a stage past the last unit)
+            if (u == 0) {
+                g_tap = 0;
+                g_c0 = 0;
+            } else {
+                g_c0 += 16;
+                if (g_c0 >= (UPT << 4)) {
+                    g_c0 = 0;
+                    ++g_tap;
+                }
+            }
+            if (g_c0 == 0) {                                    // (workgroup-uniform) first unit of a tap
+                const int dt = sm.dt[g_tap], io = sm.ioff[g_tap];
+#pragma unroll
+                for (int p = 0; p < MI; ++p) {
+                    const int tt = a_t[p] + dt, fi = a_f0[p] + io;
+                    tap_ok[p] = a_ok[p] && tt >= 0 && tt < d.T && fi >= 0 && fi < d.Fin;
+                    const unsigned pos = (unsigned)(a_tf[p] + dt * d.Fin + io);
+                    tap_b0[p] = pos * (unsigned)(d.C0 * 4) + (unsigned)(skq * 16);
+                    tap_b1[p] = pos * (unsigned)(d.C1 * 4) + (unsigned)(skq * 16);
+                }
+            }
+            const bool second = (d.C1 > 0) && (g_c0 >= d.C0);  // workgroup-uniform
+            const int Cs = second ? d.C1 : d.C0;
+            const int cu = second ? g_c0 - d.C0 : g_c0;         // first channel of the unit inside its source (uniform)
+            const bool cok = cu + skq * 4 < Cs;                 // (false only in the padded tail of a source with C % 16 != 0)
+#pragma unroll
+            for (int p = 0; p < MI; ++p) {
+                const bool ok = tap_ok[p] && cok;
+                rg.st_ok[0][p] = ok;
+                const unsigned off = ok ? (second ? tap_b1[p] : tap_b0[p]) : CG_OOB;
+                const u32x4 v = second ? __builtin_amdgcn_raw_buffer_load_b128(rs1, off, cu * 4, 0)
+                                       : __builtin_amdgcn_raw_buffer_load_b128(rs0, off, cu * 4, 0);
+                rg.ra[0][p] = __builtin_bit_cast(f32x4, v);
+            }
+            rg.r_tc[0] = ((second ? 1 : 0) << 8) | cu;          // uniform: (table, first channel of the unit)
+#pragma unroll
+            for (int p = 0; p < NI; ++p)
+                rg.rb[0][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, w_off[p], u * 64, 0));
+            return;
+        }
 #pragma unroll
         for (int ku = 0; ku < KU; ++ku) {
             const int u = stage * KU + ku;
@@ -549,7 +602,24 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
 #pragma unroll
         for (int ku = 0; ku < KU; ++ku) {
             f32x4 sh01[2], sh23[2], sl[2];
+            bool all_ok = false;
             if (XF != EAB_XF_NONE) {
+                if constexpr (LEAN) {
+                    // r_tc is workgroup-uniform (table, first channel of the unit): the table addresses are the thread's own
+                    // channel group (fixed) plus a scalar -- two vector adds instead of ten.  (A channel past the end of a
+                    // source with C % 16 != 0 indexes an initialised table entry and its row is zeroed by st_ok.)
+                    const int tb = rg.r_tc[ku] >> 8, cu = rg.r_tc[ku] & 0xFF;
+                    const char* px = reinterpret_cast<const char*>(&sm.xft[0][skq * 4][0]) + (tb * CG_XFC + cu) * 8;
+                    const char* ps = reinterpret_cast<const char*>(&sm.xsl[0][skq * 4]) + (tb * CG_XFC + cu) * 4;
+                    sh01[0] = *reinterpret_cast<const f32x4*>(px);
+                    sh23[0] = *reinterpret_cast<const f32x4*>(px + 16);
+                    sl[0] = *reinterpret_cast<const f32x4*>(ps);
+                    // every row of every lane real (all but the tiles at the rim of the tensor): no zero-selects at all
+                    bool ok_all = true;
+#pragma unroll
+                    for (int p = 0; p < MI; ++p) ok_all = ok_all && rg.st_ok[ku][p];
+                    all_ok = __builtin_amdgcn_ballot_w64(ok_all) == __builtin_amdgcn_ballot_w64(true);   // (wave-uniform)
+                } else {
                 const int cc = rg.r_tc[ku] & 0xFF;
 #pragma unroll
                 for (int k = 0; k < (DUAL ? 2 : 1); ++k) {
@@ -558,6 +628,7 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
                     sh23[k] = *reinterpret_cast<const f32x4*>(&sm.xft[tb][cc + 2][0]);
                     sl[k] = *reinterpret_cast<const f32x4*>(&sm.xsl[tb][cc]);
                 }
+                }
             }
 #pragma unroll
             for (int p = 0; p < MI; ++p) {
@@ -565,8 +636,11 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
                 for (int k = 0; k < (DUAL ? 2 : 1); ++k) {
                     f32x4 v = rg.ra[ku][p];
                     if (XF != EAB_XF_NONE) {
-                        const f32x4 x = cg_xform<XF>(v, sh01[k], sh23[k], sl[k]);
-                        v = rg.st_ok[ku][p] ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+                        v = cg_xform<XF>(v, sh01[k], sh23[k], sl[k]);
+                        if (!all_ok) {                           // scalar branch (the asm keeps it one: four selects otherwise)
+                            asm volatile("; rim" ::: "memory");
+                            v = rg.st_ok[ku][p] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
                     }
                     float* arow = &sm.a[(k * 2 + buf) * Smem::ATILE + (srow + 64 * p) * LDK + ku * 16];
                     if (BF) {
