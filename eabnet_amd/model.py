@@ -636,10 +636,17 @@ class Pipeline:
         while pipe.outstanding: y = pipe.collect()
     """
 
-    def __init__(self, model: nn.Module, depth: int = 2, front_end: Optional[tuple] = None):
+    def __init__(self, model: nn.Module, depth: int = 2, front_end: Optional[tuple] = None, prepare=None):
+        """front_end = (fft_num, hop, window): ``submit(wav)`` takes (B, M, L) waves -- on the device, or in HOST memory: the
+        upload then goes through the pinned staging ring on its own copy stream and overlaps the batches already in flight.
+        prepare = the ``args`` of ``prepare_data`` (train_distributed.py:68-95): ``submit(x, target)`` takes what the
+        reference's loader yields (host or device), runs ``prepare_data`` on the slot's stream and ``collect()`` returns
+        ``(model(noisy_stft), target_stft)`` -- the reference's step with its host-to-device copies hidden behind compute."""
         if depth < 1:
             raise ValueError("depth must be >= 1")
-        self.model, self.depth, self.front_end = model, depth, front_end
+        if front_end is not None and prepare is not None:
+            raise ValueError("front_end and prepare are alternatives")
+        self.model, self.depth, self.front_end, self.prepare = model, depth, front_end, prepare
         self._replicas = [_replica(model) for _ in range(depth)] if depth > 1 else [model]
         if depth > 1:
             # with several batches in flight the post-filter's three S-TCM chains run back to back: the
@@ -669,13 +676,21 @@ class Pipeline:
                 yield from Pipeline._tensors(v)
 
     def submit(self, *inputs: torch.Tensor) -> None:
-        """Enqueue one batch (the model's positional inputs); returns immediately.  At most ``depth`` batches
-        may be outstanding."""
+        """Enqueue one batch (the model's positional inputs, or the front end's: see __init__); returns immediately.  At most
+        ``depth`` batches may be outstanding.  Host tensors are accepted where a front end takes them (waves): they are staged
+        through the pinned ring, so the caller may refill its buffer as soon as submit returns."""
         if self.outstanding >= self.depth:
             raise RuntimeError("collect() a result before submitting more than `depth` batches")
-        if not inputs or not all(x.is_cuda for x in inputs):
-            raise _lib.EabError("Pipeline.submit needs CUDA (ROCm) tensors; there is no CPU fallback by design.")
-        device = inputs[0].device
+        if not inputs:
+            raise ValueError("nothing to submit")
+        takes_host = self.front_end is not None or self.prepare is not None
+        if not takes_host and not all(x.is_cuda for x in inputs):
+            raise _lib.EabError("Pipeline.submit needs CUDA (ROCm) tensors (host waves only with front_end= / prepare=); "
+                                "there is no CPU fallback by design.")
+        dev_in = next((x.device for x in inputs if x.is_cuda), None)
+        device = dev_in if dev_in is not None else next(self.model.parameters()).device
+        if device.type != "cuda":
+            raise _lib.EabError("Pipeline runs on MI355X only: move the module to 'cuda'. There is no CPU fallback by design.")
         with torch.cuda.device(device):
             if not self._streams:
                 # one set of streams per (device, depth) for the whole process: HIP maps streams onto a few
@@ -688,20 +703,31 @@ class Pipeline:
             slot = self._n % self.depth
             self._n += 1
             st = self._streams[slot]
-            st.wait_stream(torch.cuda.current_stream())            # the inputs were produced on the caller's stream
+            st.wait_stream(torch.cuda.current_stream())            # device inputs were produced on the caller's stream
+            extra = None
             with torch.cuda.stream(st), torch.no_grad():
                 for x in inputs:
-                    x.record_stream(st)
-                if self.front_end is not None:
+                    if x.is_cuda:
+                        x.record_stream(st)
+                if self.prepare is not None:
+                    if len(inputs) != 2:
+                        raise ValueError("prepare=: submit(x (B,M,L), target (B,1,L))")
+                    noisy, extra = prepare_data(inputs[0], inputs[1], device, self.prepare)     # uploads + both STFTs on `st`
+                    inputs = (noisy,)
+                elif self.front_end is not None:
                     fft_num, hop, window = self.front_end
-                    inputs = (stft_compress(inputs[0], fft_num, hop, window),) + tuple(inputs[1:])
+                    wav, consumed = _upload(inputs[0], device)     # (device tensors pass through)
+                    spec = stft_compress(wav, fft_num, hop, window)
+                    if consumed is not None:
+                        consumed.record(st)                        # the staged wave has no reader after the STFT
+                    inputs = (spec,) + tuple(inputs[1:])
                 rep = self._replicas[slot]
                 if rep is not self.model:
                     _sync_knobs(self.model, rep)                   # precision / use_graph / train-eval follow the model
                 out = rep(*inputs)
                 ev = torch.cuda.Event()
                 ev.record(st)
-            self._pending.append((out, ev, inputs))
+            self._pending.append((out if extra is None else (out, extra), ev, inputs))
 
     def calibrate(self, *inputs: torch.Tensor, tries: int = 4, steps: int = 6) -> float:
         """Optional, once per process and depth: whether two streams overlap depends on how the runtime maps them
@@ -710,7 +736,7 @@ class Pipeline:
         import time
         if self.depth == 1:
             return 0.0
-        device = inputs[0].device
+        device = next((x.device for x in inputs if x.is_cuda), None) or next(self.model.parameters()).device
         key = (str(device), self.depth)
         best, best_streams = None, None
         for attempt in range(tries):
@@ -1018,7 +1044,8 @@ class _HostStager:
     # and has to block until the read has finished, because nothing else protects a caller's pinned buffer from being refilled.
     always_stage = True
 
-    def __init__(self, device: torch.device, depth: int = 3):
+    def __init__(self, device: torch.device, depth: int = 4):
+        # (one slot more than the deepest Pipeline keeps in flight: a slot is refilled only when its batch has been consumed)
         self.device, self.depth, self.k = device, depth, 0
         self.slots: Dict[tuple, list] = {}
         self.stream = torch.cuda.Stream(device=device)
@@ -1105,6 +1132,31 @@ def prepare_data(x: torch.Tensor, target: torch.Tensor, device, args):
     return noisy_stft, target_stft
 
 
+_NOLA: Dict[tuple, bool] = {}
+
+
+def _check_nola(window: torch.Tensor, fft_num: int, hop: int, T: int) -> None:
+    """torch.istft's window-overlap condition, on the host, before the kernel divides by the envelope: the squared-window
+    overlap-add over the frames that exist must stay above 1e-11 at every output sample (a short zero-padded window with a
+    large hop leaves gaps).  The envelope's two rims and its periodic interior are those of a signal of 2R+2 frames."""
+    key = (window.data_ptr(), window._version, str(window.device), window.numel(), fft_num, hop, min(T, 2 * (fft_num // hop) + 2))
+    ok = _NOLA.get(key)
+    if ok is None:
+        w2 = window.detach().to("cpu", torch.float64).numpy() ** 2          # (already zero-padded to fft_num by the caller)
+        Te = key[-1]
+        env = np.zeros(fft_num + hop * (Te - 1))
+        for t in range(Te):
+            env[t * hop:t * hop + fft_num] += w2
+        trimmed = env[fft_num // 2:fft_num // 2 + hop * (Te - 1)]
+        ok = bool(trimmed.size == 0 or np.abs(trimmed).min() > 1e-11)
+        if len(_NOLA) > 64:
+            _NOLA.clear()
+        _NOLA[key] = ok
+    if not ok:
+        raise RuntimeError("istft: window overlap add min is below 1e-11 (the NOLA condition of torch.istft fails for this "
+                           f"window / hop: fft_num={fft_num}, win_shift={hop})")
+
+
 def istft(esti_stft: torch.Tensor, fft_num: int, win_shift: int, window: torch.Tensor) -> torch.Tensor:
     """The reference's back end (enhance.py:59-62, test.py:189-191, train_distributed.py:128-130)
     ``torch.istft(view_as_complex(esti.permute(0,3,2,1)), fft_num, win_shift, win_size, hann)`` in one
@@ -1124,6 +1176,7 @@ def istft(esti_stft: torch.Tensor, fft_num: int, win_shift: int, window: torch.T
                                   "(fft_num / win_shift in 1..8; the reference's 320/160 is 2)")
     lib = _lib.load()
     B, _, T, _ = esti_stft.shape
+    _check_nola(window, fft_num, win_shift, T)
     x = esti_stft.detach().to(torch.float32).contiguous()
     window = _device_window(window, x.device)
     wav = torch.empty((B, win_shift * (T - 1)), dtype=torch.float32, device=x.device)

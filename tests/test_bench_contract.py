@@ -36,6 +36,16 @@ def test_committed_bench_line_has_the_contract_fields():
         assert tr[k]["check"]["ok"] and tr[k]["check"]["hip_programs_engaged"] and tr[k]["ms_per_step"] > 0
 
 
+def test_bench_source_emits_every_contract_field():
+    """The artifact above could stay green while bench.py drops a field: every key of the contract (and of the two objects this
+    tier adds) must be written by bench.py itself."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "workload", "bound", "achieved", "peak", "frac", "traffic",
+              "cores", "kind", "sample", "pcie_inclusive", "training"):
+        assert re.search(r'["\']%s["\']\s*[:\]]' % re.escape(k), src), f"bench.py never writes {k!r}"
+
+
 def test_bench_accepts_the_drivers_flags_and_reads_the_rendezvous_from_the_environment():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for flag in ("--gpus", "--steps", "--warmup"):

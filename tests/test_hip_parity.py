@@ -1086,6 +1086,49 @@ def test_pipeline_executor_is_bit_identical_and_ordered(dev, depth, front):
         assert all(torch.equal(g, w) for g, w in zip(pipe.map(odd), want3))
 
 
+@pytest.mark.parametrize("mode", ["front_end", "prepare"])
+def test_pipeline_takes_host_waves_and_overlaps_their_upload(dev, mode):
+    """Host input pipelining (train_distributed.py:76-77 are two blocking .to(device) calls per step): Pipeline.submit takes
+    the waves in HOST memory -- pageable or pinned --, stages them through the pinned ring on the copy stream and runs the
+    front end on the slot's stream; results are bit-identical to the blocking calls, in order, and the caller may overwrite its
+    buffers as soon as submit returns (more batches than ring slots, so slots are re-used while earlier batches are in flight)."""
+    import eabnet_amd
+    net = _model(4, 231, dev, p=1, q=1)
+    args = type("A", (), dict(mics=4, sr=16000, wav_len=0.5, win_size=0.020, win_shift=0.010, fft_num=320))
+    win = torch.hann_window(320)
+    waves = [torch.from_numpy(paramgen.make_wave(2, 4, 8000, 700 + i)) for i in range(9)]
+    want = []
+    with torch.no_grad():
+        for w in waves:
+            noisy, tgt = eabnet_amd.prepare_data(w, w[:, :1], dev, args)
+            want.append((net(noisy).clone(), tgt.clone()))
+    pipe = (eabnet_amd.Pipeline(net, depth=3, prepare=args) if mode == "prepare"
+            else eabnet_amd.Pipeline(net, depth=3, front_end=(320, 160, win)))
+    got = []
+    for i, w in enumerate(waves):
+        if pipe.outstanding == pipe.depth:
+            got.append(pipe.collect())
+        buf = w.clone().pin_memory() if i % 2 else w.clone()          # pinned and pageable sources alternate
+        tgt = buf[:, :1].clone()
+        if mode == "prepare":
+            pipe.submit(buf, tgt)
+        else:
+            pipe.submit(buf)
+        buf.fill_(1e6)                                               # the caller recycles its buffers immediately
+        tgt.fill_(-1e6)
+    while pipe.outstanding:
+        got.append(pipe.collect())
+    torch.cuda.synchronize()
+    assert len(got) == len(want)
+    for g, (y, t) in zip(got, want):
+        if mode == "prepare":
+            assert torch.equal(g[0], y) and torch.equal(g[1], t)
+        else:
+            assert torch.equal(g, y)
+    with pytest.raises(eabnet_amd._lib.EabError):                    # host tensors only where a front end takes them
+        eabnet_amd.Pipeline(net, depth=2).submit(torch.zeros(1, 10, 161, 4, 2))
+
+
 def test_pipeline_executor_two_stage_model(dev):
     """The same executor over EaBNetWithPostNet (dictionary outputs, two programs per replica) and over GaGNet
     (two inputs), f16x3 knob set after construction."""
@@ -1965,6 +2008,21 @@ def test_prepare_data_is_done_with_a_pinned_source_when_it_returns(dev, stage):
             assert torch.equal(noisy, want_n) and torch.equal(tgt, want_t)
     finally:
         mdl._HostStager.always_stage = saved
+
+
+def test_istft_refuses_a_window_that_violates_nola(dev):
+    """torch.istft raises when the squared-window overlap-add has a gap (window overlap add min); the HIP back end would divide
+    by zero there, so the wrapper checks the same condition on the host and raises too -- for a short zero-padded window with
+    a large hop and for a Hann window without overlap."""
+    import eabnet_amd
+    x = torch.randn(1, 2, 12, 161, device=dev)
+    with pytest.raises(RuntimeError, match="NOLA"):
+        eabnet_amd.istft(x, 320, 160, torch.hann_window(100))
+    with pytest.raises(RuntimeError):
+        torch.istft(torch.view_as_complex(x.permute(0, 3, 2, 1).contiguous()).cpu(), 320, 160, 100, torch.hann_window(100))
+    with pytest.raises(RuntimeError, match="NOLA"):
+        eabnet_amd.istft(torch.randn(1, 2, 12, 129, device=dev), 256, 256, torch.hann_window(256))
+    assert torch.isfinite(eabnet_amd.istft(x, 320, 160, torch.hann_window(320))).all()
 
 
 @pytest.mark.parametrize("n_fft,hop,win", [(320, 80, 320), (256, 64, 256), (512, 128, 400), (320, 40, 320), (320, 160, 200), (256, 256, 256)])
