@@ -50,7 +50,7 @@ class ConvDesc(C.Structure):
         ("ph1_dt", C.c_int32 * MAX_TAPS), ("ph1_ioff", C.c_int32 * MAX_TAPS),
         ("f2_w", C.c_void_p), ("f2_dst", C.c_void_p), ("f2_stats", C.c_void_p), ("f2_stat_slope0", C.c_void_p),
         ("f2_stat_slope1", C.c_void_p), ("f2_N", C.c_int32), ("f2_nsets", C.c_int32), ("f2_stat_tiles", C.c_int32),
-        ("p2_mask1", C.c_int32),
+        ("p2_mask1", C.c_int32), ("src_bf16", C.c_int32),
     ]
 
 
@@ -61,7 +61,7 @@ class WgradDesc(C.Structure):
         ("B", C.c_int32), ("T", C.c_int32), ("Fin", C.c_int32), ("Fz", C.c_int32), ("No", C.c_int32),
         ("ostride", C.c_int32), ("ophase", C.c_int32), ("istride", C.c_int32),
         ("ntaps", C.c_int32), ("dt", C.c_int32 * MAX_TAPS), ("ioff", C.c_int32 * MAX_TAPS),
-        ("rows_per_wg", C.c_int32), ("precision", C.c_int32),
+        ("rows_per_wg", C.c_int32), ("precision", C.c_int32), ("bf16_mask", C.c_int32),
     ]
 
 
@@ -118,6 +118,7 @@ _SIGS = {
     "eab_train_norm_act_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "eab_train_norm_bwd_f32": (C.c_int, [C.c_void_p] * 12 + [C.c_int] * 4 + [C.c_void_p]),
     "eab_glu_bwd_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_longlong, C.c_int, C.c_void_p]),
+    "eab_glu_bwd_ex_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_longlong, C.c_int, C.c_int, C.c_void_p]),
     "eab_gate_fwd_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_longlong, C.c_void_p]),
     "eab_gate_bwd_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong, C.c_void_p]),
     "eab_add_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_longlong, C.c_void_p]),

@@ -34,6 +34,7 @@
 #define CG_OOB 0x80000000u   // > any legal byte offset inside one batch element (host checks < 2^31)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #define CG_PLAIN 0
 #define CG_GLU 1     // value/gate columns of ONE GEMM (GateConv2d / GateConvTranspose2d)
@@ -214,12 +215,17 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
     const int NS = (NU + KU - 1) / KU;              // pipeline stages
 
     // one buffer descriptor per source, spanning this workgroup's batch element
-    const unsigned bytes0 = (unsigned)d.T * d.Fin * d.C0 * 4u;
-    const unsigned bytes1 = (unsigned)d.T * d.Fin * d.C1 * 4u;
-    const __amdgpu_buffer_rsrc_t rs0 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.src0) + (size_t)b * d.T * d.Fin * d.C0, 0, bytes0, 0x00020000);
+    // (src_bf16, bf16 products only: a source stored as bf16 [B][T][Fin][C] -- the training programs' normalised activations and
+    // convolution-output gradients, which this precision rounds to bf16 on their way into LDS anyway: same operands, half the
+    // bytes, no conversion.  esz = bytes per element of the source.)
+    const unsigned esz0 = (BF && (d.src_bf16 & 1)) ? 2u : 4u, esz1 = (BF && (d.src_bf16 & 2)) ? 2u : 4u;
+    const unsigned bytes0 = (unsigned)d.T * d.Fin * d.C0 * esz0;
+    const unsigned bytes1 = (unsigned)d.T * d.Fin * d.C1 * esz1;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(d.src0)) + (size_t)b * bytes0, 0, bytes0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(d.src1 ? d.src1 + (size_t)b * d.T * d.Fin * d.C1 : d.src0), 0, d.src1 ? bytes1 : 0u, 0x00020000);
+        const_cast<char*>(reinterpret_cast<const char*>(d.src1 ? d.src1 : d.src0)) + (d.src1 ? (size_t)b * bytes1 : 0), 0,
+        d.src1 ? bytes1 : 0u, 0x00020000);
 
     // ---- per-thread staging coordinates ------------------------------------------
     const int srow = tid >> 2;      // 0..63
@@ -514,24 +520,31 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
                     const int tt = a_t[p] + dt, fi = a_f0[p] + io;
                     tap_ok[p] = a_ok[p] && tt >= 0 && tt < d.T && fi >= 0 && fi < d.Fin;
                     const unsigned pos = (unsigned)(a_tf[p] + dt * d.Fin + io);
-                    tap_b0[p] = pos * (unsigned)(d.C0 * 4) + (unsigned)(skq * 16);
-                    tap_b1[p] = pos * (unsigned)(d.C1 * 4) + (unsigned)(skq * 16);
+                    tap_b0[p] = (pos * (unsigned)d.C0 + (unsigned)(skq * 4)) * esz0;
+                    tap_b1[p] = (pos * (unsigned)d.C1 + (unsigned)(skq * 4)) * esz1;
                 }
             }
             const bool second = (d.C1 > 0) && (g_c0 >= d.C0);  // workgroup-uniform
             const int Cs = second ? d.C1 : d.C0;
             const int cu = second ? g_c0 - d.C0 : g_c0;         // first channel of the unit inside its source (uniform)
             const bool cok = cu + skq * 4 < Cs;                 // (false only in the padded tail of a source with C % 16 != 0)
+            const bool half = BF && (second ? esz1 : esz0) == 2u;   // (uniform) this unit's source is stored as bf16
 #pragma unroll
             for (int p = 0; p < MI; ++p) {
                 const bool ok = tap_ok[p] && cok;
                 rg.st_ok[0][p] = ok;
                 const unsigned off = ok ? (second ? tap_b1[p] : tap_b0[p]) : CG_OOB;
-                const u32x4 v = second ? __builtin_amdgcn_raw_buffer_load_b128(rs1, off, cu * 4, 0)
-                                       : __builtin_amdgcn_raw_buffer_load_b128(rs0, off, cu * 4, 0);
-                rg.ra[0][p] = __builtin_bit_cast(f32x4, v);
+                if (half) {                                     // four bf16 of the row: already the LDS image of the unit's quarter
+                    const u32x2 v = second ? __builtin_amdgcn_raw_buffer_load_b64(rs1, off, cu * 2, 0)
+                                           : __builtin_amdgcn_raw_buffer_load_b64(rs0, off, cu * 2, 0);
+                    rg.ra[0][p] = __builtin_bit_cast(f32x4, u32x4{v[0], v[1], 0u, 0u});
+                } else {
+                    const u32x4 v = second ? __builtin_amdgcn_raw_buffer_load_b128(rs1, off, cu * 4, 0)
+                                           : __builtin_amdgcn_raw_buffer_load_b128(rs0, off, cu * 4, 0);
+                    rg.ra[0][p] = __builtin_bit_cast(f32x4, v);
+                }
             }
-            rg.r_tc[0] = ((second ? 1 : 0) << 8) | cu;          // uniform: (table, first channel of the unit)
+            rg.r_tc[0] = ((half ? 1 : 0) << 9) | ((second ? 1 : 0) << 8) | cu;   // uniform: (stored as bf16, table, first channel)
 #pragma unroll
             for (int p = 0; p < NI; ++p)
                 rg.rb[0][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, w_off[p], u * 64, 0));
@@ -608,7 +621,7 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
                     // r_tc is workgroup-uniform (table, first channel of the unit): the table addresses are the thread's own
                     // channel group (fixed) plus a scalar -- two vector adds instead of ten.  (A channel past the end of a
                     // source with C % 16 != 0 indexes an initialised table entry and its row is zeroed by st_ok.)
-                    const int tb = rg.r_tc[ku] >> 8, cu = rg.r_tc[ku] & 0xFF;
+                    const int tb = (rg.r_tc[ku] >> 8) & 1, cu = rg.r_tc[ku] & 0xFF;
                     const char* px = reinterpret_cast<const char*>(&sm.xft[0][skq * 4][0]) + (tb * CG_XFC + cu) * 8;
                     const char* ps = reinterpret_cast<const char*>(&sm.xsl[0][skq * 4]) + (tb * CG_XFC + cu) * 4;
                     sh01[0] = *reinterpret_cast<const f32x4*>(px);
@@ -644,7 +657,10 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
                     }
                     float* arow = &sm.a[(k * 2 + buf) * Smem::ATILE + (srow + 64 * p) * LDK + ku * 16];
                     if (BF) {
-                        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(arow) + skq * 8) = make_uint2(cg_bf2(v[0], v[1]), cg_bf2(v[2], v[3]));
+                        const u32x4 raw = __builtin_bit_cast(u32x4, v);
+                        const bool half = LEAN && ((rg.r_tc[ku] >> 9) & 1);      // (uniform) bf16 in memory: stored as fetched
+                        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(arow) + skq * 8) =
+                            half ? make_uint2(raw[0], raw[1]) : make_uint2(cg_bf2(v[0], v[1]), cg_bf2(v[2], v[3]));
                     } else if (H3) {
                         // unit layout in LDS (64 B): 16 fp16 hi | 16 fp16 lo; this thread owns channels 4*skq..+3
                         unsigned h01, l01, h23, l23;
@@ -1304,6 +1320,13 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
     EAB_CHECK_ARG(per_b < (1ll << 31) && (long long)d->T * d->Fout * d->Cout * 4 < (1ll << 31));
     EAB_CHECK_ARG((long long)d->T * d->No < (1ll << 22));
     EAB_CHECK_ARG(d->xf_mode >= EAB_XF_NONE && d->xf_mode <= EAB_XF_PRELU_NORM);
+    if (d->src_bf16) {
+        // sources stored as bf16: bf16 products, the tap-ordered gather pipeline with one unit per stage (2-D layers), no fused
+        // transform (the training programs' materialised activations and gradients), channel counts in whole units
+        EAB_CHECK_ARG((d->src_bf16 & ~3) == 0 && d->precision == EAB_PREC_BF16 && d->korder == EAB_KORDER_TAP);
+        EAB_CHECK_ARG(d->xf_mode == EAB_XF_NONE && d->fin_stats == nullptr && d->Fin > 1 && d->epi != EAB_EPI_DUALGATE);
+        EAB_CHECK_ARG(d->C0 % 16 == 0 && d->C1 % 16 == 0 && (!(d->src_bf16 & 2) || d->src1));
+    }
     const bool fin = d->fin_stats != nullptr;
     if (fin) {
         EAB_CHECK_ARG(d->xf_mode != EAB_XF_NONE && !d->xf0 && !d->xf1 && d->C1 == 0);

@@ -149,7 +149,7 @@ extern "C" int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream
                                                          stream);
                 break;
             case EAB_OP_GLU_BWD:
-                rc = eab_glu_bwd_f32(EAB_P(0), EAB_P(1), EAB_W(2), EAB_N64(0), o.i[2], stream);
+                rc = eab_glu_bwd_ex_f32(EAB_P(0), EAB_P(1), EAB_W(2), EAB_N64(0), o.i[2], o.i[3], stream);
                 break;
             case EAB_OP_GATE_FWD:
                 rc = eab_gate_fwd_f32(EAB_P(0), EAB_P(1), EAB_W(2), EAB_N64(0), stream);

@@ -13,6 +13,13 @@
 // All tensors channels-last [B][P][C] fp32 (P = T*F positions); roofline "hbm" for every kernel in this file.
 #include "common.h"
 
+// two fp32 -> packed bf16, round to nearest even (v_cvt_pk_bf16_f32): the rounding the bf16 contractions apply to their operands
+typedef __bf16 tr_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned tr_bf2(float x0, float x1) {
+    const tr_bf16x2 v = {(__bf16)x0, (__bf16)x1};
+    return __builtin_bit_cast(unsigned, v);
+}
+
 #define TR_THREADS 256
 
 // ---------------------------------------------------------------------------------------------------
@@ -206,7 +213,8 @@ extern "C" int eab_train_in1d_multi_f32(const float* x, const float* slope, int 
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TR_THREADS) void tr_norm_act_kernel(const float* __restrict__ x, const float* __restrict__ xf,
                                                                  const float* __restrict__ slope, const float* __restrict__ add,
-                                                                 float* __restrict__ y, int P, int C, int mode) {
+                                                                 float* __restrict__ y, int P, int C, int mode_flags) {
+    const int mode = mode_flags & 0xFF;
     const unsigned C4 = (unsigned)C >> 2, n4 = (unsigned)P * C4, b = blockIdx.y;
     const size_t base = (size_t)b * n4;
     for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < n4; r += gridDim.x * blockDim.x) {
@@ -226,7 +234,10 @@ __global__ __launch_bounds__(TR_THREADS) void tr_norm_act_kernel(const float* __
             const f32x4 a = reinterpret_cast<const f32x4*>(add)[base + r];
             o += a;
         }
-        reinterpret_cast<f32x4*>(y)[base + r] = o;
+        if (mode_flags & EAB_STORE_BF16)          // the tensor is read by bf16 contractions only: store what they would round to
+            reinterpret_cast<uint2*>(y)[base + r] = make_uint2(tr_bf2(o[0], o[1]), tr_bf2(o[2], o[3]));
+        else
+            reinterpret_cast<f32x4*>(y)[base + r] = o;
     }
 }
 
@@ -240,11 +251,13 @@ static inline unsigned tr_grid_x(long long n4, int B) {
 extern "C" int eab_train_norm_act_f32(const float* x, const float* xf, const float* slope, const float* add, float* y, int B,
                                       int P, int C, int mode, eab_stream_t stream) {
     EAB_CHECK_ARG(x && slope && y && B > 0 && P > 0 && C > 0 && (C % 4) == 0 && B <= 65535);
+    const int flags = mode & EAB_STORE_BF16;                         // y stored as bf16 (2-byte elements)
+    mode &= ~EAB_STORE_BF16;
     EAB_CHECK_ARG(mode == EAB_XF_NORM_PRELU || mode == EAB_XF_PRELU_NORM);
     EAB_CHECK_ARG(xf || mode == EAB_XF_NORM_PRELU);                  // xf == NULL: y = prelu(x) [+ add]
     EAB_CHECK_ARG((long long)P * (C / 4) < (1ll << 31));
     hipLaunchKernelGGL(tr_norm_act_kernel, dim3(tr_grid_x((long long)P * (C / 4), B), B), dim3(TR_THREADS), 0, eab_stream(stream),
-                       x, xf, slope, add, y, P, C, mode);
+                       x, xf, slope, add, y, P, C, mode | flags);
     EAB_RETURN_LAUNCH_STATUS();
 }
 
@@ -329,7 +342,7 @@ __global__ __launch_bounds__(TR_THREADS) void norm_bwd_apply_kernel(const float*
                                                                     float* __restrict__ sums, const float* __restrict__ acc_in,
                                                                     float* __restrict__ dx, float* __restrict__ dgamma,
                                                                     float* __restrict__ dbeta, float* __restrict__ dslope, int P, int C,
-                                                                    int mode, int chunk) {
+                                                                    int mode, int chunk, int dx_bf16) {
     __shared__ f32x4 red[NB_ROWS][16];
     const int b = blockIdx.z, cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int c = blockIdx.y * 64 + cl * 4;
@@ -383,7 +396,10 @@ __global__ __launch_bounds__(TR_THREADS) void norm_bwd_apply_kernel(const float*
                 }
             }
             if (acc_in) r += *reinterpret_cast<const f32x4*>(&acc_in[e]);
-            *reinterpret_cast<f32x4*>(&dx[e]) = r;
+            if (dx_bf16)                                   // read by bf16 contractions only (wgrad, dgrad): half the bytes
+                *reinterpret_cast<uint2*>(reinterpret_cast<char*>(dx) + e * 2) = make_uint2(tr_bf2(r[0], r[1]), tr_bf2(r[2], r[3]));
+            else
+                *reinterpret_cast<f32x4*>(&dx[e]) = r;
         }
     }
     if (mode == EAB_XF_PRELU_NORM) {
@@ -504,7 +520,9 @@ extern "C" int eab_train_norm_bwd_f32(const float* dy, const float* x, const flo
     EAB_CHECK_ARG(dy && x && slope && sums && dx && dslope);
     EAB_CHECK_ARG(mr ? (gamma && beta && dgamma && dbeta) : true);
     const bool zeroed = (mode & EAB_NB_SUMS_ZEROED) != 0;          // the caller guarantees sums == 0 on entry
-    mode &= ~EAB_NB_SUMS_ZEROED;
+    const int dx_bf16 = (mode & EAB_STORE_BF16) ? 1 : 0;           // dx stored as bf16 (needs acc_in == NULL)
+    mode &= ~(EAB_NB_SUMS_ZEROED | EAB_STORE_BF16);
+    EAB_CHECK_ARG(!dx_bf16 || acc_in == nullptr);
     EAB_CHECK_ARG(mr || mode == EAB_XF_NORM_PRELU);
     if (!mr) dgamma = dbeta = nullptr;
     EAB_CHECK_ARG(B > 0 && P > 0 && C > 0 && (C % 4) == 0 && B <= 65535 && (mode == EAB_XF_NORM_PRELU || mode == EAB_XF_PRELU_NORM));
@@ -520,7 +538,7 @@ extern "C" int eab_train_norm_bwd_f32(const float* dy, const float* x, const flo
     // PRELU_NORM when its slope sums can go straight into dslope (<= 256 workgroups per address: the S-TCN's slabs)
     const bool merged = mode == EAB_XF_NORM_PRELU || (long long)grid.x * B <= 256;
     hipLaunchKernelGGL(norm_bwd_apply_kernel, grid, dim3(TR_THREADS), 0, s, dy, x, mr, gamma, beta, slope, sums, acc_in, dx,
-                       merged ? dgamma : nullptr, dbeta, dslope, P, C, mode, chunk);
+                       merged ? dgamma : nullptr, dbeta, dslope, P, C, mode, chunk, dx_bf16);
     if (!merged) hipLaunchKernelGGL(norm_bwd_params_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, B, C, dgamma, dbeta, dslope);
     EAB_RETURN_LAUNCH_STATUS();
 }
@@ -555,7 +573,7 @@ extern "C" int eab_train_norm_bwd_multi_f32(const float* dy0, const float* dy1, 
 // division of the generic form costs more VALU work than the rest of the loop body)
 template <int GENERIC>
 __global__ __launch_bounds__(TR_THREADS) void glu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dump,
-                                                             float* __restrict__ dz, long long rows, int N, int lg4) {
+                                                             float* __restrict__ dz, long long rows, int N, int lg4, int dz_bf16) {
     const int Cout = N >> 1, N4 = N >> 2;
     const long long n4 = rows * N4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
@@ -569,21 +587,31 @@ __global__ __launch_bounds__(TR_THREADS) void glu_bwd_kernel(const float* __rest
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = half ? d[j] * ot[j] * me[j] * (1.0f - me[j]) : d[j] * ot[j];
-        *reinterpret_cast<f32x4*>(&dz[row * N + r]) = o;
+        if (dz_bf16)
+            *reinterpret_cast<uint2*>(reinterpret_cast<char*>(dz) + (row * N + r) * 2) = make_uint2(tr_bf2(o[0], o[1]), tr_bf2(o[2], o[3]));
+        else
+            *reinterpret_cast<f32x4*>(&dz[row * N + r]) = o;
     }
 }
 
-extern "C" int eab_glu_bwd_f32(const float* dy, const float* dump, float* dz, long long rows, int N, eab_stream_t stream) {
-    EAB_CHECK_ARG(dy && dump && dz && rows > 0 && N > 0 && (N % 64) == 0);
+extern "C" int eab_glu_bwd_ex_f32(const float* dy, const float* dump, float* dz, long long rows, int N, int flags,
+                                  eab_stream_t stream) {
+    EAB_CHECK_ARG(dy && dump && dz && rows > 0 && N > 0 && (N % 64) == 0 && (flags & ~EAB_STORE_BF16) == 0);
+    const int dz_bf16 = (flags & EAB_STORE_BF16) ? 1 : 0;            // dz stored as bf16 (read by bf16 wgrad / dgrad only)
     long long g = (rows * (N / 4) + TR_THREADS - 1) / TR_THREADS;
     if (g > 8192) g = 8192;
     const int N4 = N / 4;
     if ((N4 & (N4 - 1)) == 0)
         hipLaunchKernelGGL(glu_bwd_kernel<0>, dim3((unsigned)g), dim3(TR_THREADS), 0, eab_stream(stream), dy, dump, dz, rows, N,
-                           __builtin_ctz(N4));
+                           __builtin_ctz(N4), dz_bf16);
     else
-        hipLaunchKernelGGL(glu_bwd_kernel<1>, dim3((unsigned)g), dim3(TR_THREADS), 0, eab_stream(stream), dy, dump, dz, rows, N, 0);
+        hipLaunchKernelGGL(glu_bwd_kernel<1>, dim3((unsigned)g), dim3(TR_THREADS), 0, eab_stream(stream), dy, dump, dz, rows, N, 0,
+                           dz_bf16);
     EAB_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int eab_glu_bwd_f32(const float* dy, const float* dump, float* dz, long long rows, int N, eab_stream_t stream) {
+    return eab_glu_bwd_ex_f32(dy, dump, dz, rows, N, 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -287,6 +287,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgBatch bt) {
 typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int wg_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int wg_u32x2 __attribute__((ext_vector_type(2)));
 #define WGB_S 9
 
 __device__ __forceinline__ unsigned wg_bf2(float x0, float x1) {
@@ -338,11 +339,16 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_bf_kernel(const WgBatch bt) 
             tio = d.ioff[k];
         }
     const bool vec_ok = (d.C0 & 3) == 0;
+    // operands STORED as bf16 (eab_wgrad_desc.bf16_mask: the bf16 training programs' convolution-output gradients and
+    // normalised activations): four bf16 of a row per load, and the LDS image of a row pair is a byte permute of the two loads
+    // instead of four conversions -- the same operand bits as rounding the fp32 tensor here, half the bytes
+    const bool a_half = (d.bf16_mask & 1) != 0, b_half = (d.bf16_mask & (second ? 4 : 2)) != 0;
+    const int eszA = a_half ? 2 : 4, eszB = b_half ? 2 : 4;
     // (buffer descriptors and incremental 32-bit offsets as in wgrad_kernel; two row walkers per thread: rows 2 rp, 2 rp + 1)
     const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(m_dz), 0, (unsigned)((size_t)d.B * d.T * d.Fz * d.N * 4), 0x00020000);
+        const_cast<float*>(m_dz), 0, (unsigned)((size_t)d.B * d.T * d.Fz * d.N * eszA), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(b_src), 0, (unsigned)((size_t)d.B * d.T * d.Fin * b_Cs * 4), 0x00020000);
+        const_cast<float*>(b_src), 0, (unsigned)((size_t)d.B * d.T * d.Fin * b_Cs * eszB), 0x00020000);
     constexpr unsigned WG_OOB = 0x80000000u;
     WgRow rw[2];
     unsigned offA[2];
@@ -351,11 +357,11 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_bf_kernel(const WgBatch bt) 
     for (int e = 0; e < 2; ++e) {
         rw[e].init(r_begin + 2 * rp + e, d.T, d.No);
         const long long bt = (long long)rw[e].b * d.T + rw[e].t;
-        offA[e] = (unsigned)((((bt * d.Fz) + (long long)rw[e].o * d.ostride + d.ophase) * d.N + n0 + c4 * 4) * 4);
-        offB[e] = (int)((((bt + tdt) * d.Fin + (long long)rw[e].o * d.istride + tio) * b_Cs + b_cc) * 4);
+        offA[e] = (unsigned)((((bt * d.Fz) + (long long)rw[e].o * d.ostride + d.ophase) * d.N + n0 + c4 * 4) * eszA);
+        offB[e] = (int)((((bt + tdt) * d.Fin + (long long)rw[e].o * d.istride + tio) * b_Cs + b_cc) * eszB);
     }
-    const unsigned dA0 = (unsigned)((adv_a * d.Fz + adv_r * d.ostride) * d.N * 4), dA1 = (unsigned)((d.Fz - d.No * d.ostride) * d.N * 4);
-    const int dB0 = (adv_a * d.Fin + adv_r * d.istride) * b_Cs * 4, dB1 = (d.Fin - d.No * d.istride) * b_Cs * 4;
+    const unsigned dA0 = (unsigned)((adv_a * d.Fz + adv_r * d.ostride) * d.N * eszA), dA1 = (unsigned)((d.Fz - d.No * d.ostride) * d.N * eszA);
+    const int dB0 = (adv_a * d.Fin + adv_r * d.istride) * b_Cs * eszB, dB1 = (d.Fin - d.No * d.istride) * b_Cs * eszB;
 
     f32x4 ra[2], rb[2];
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
@@ -364,11 +370,19 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_bf_kernel(const WgBatch bt) 
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const bool rok = r0 + 2 * rp + e < r_end;
-            ra[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dz, (rok && a_live) ? offA[e] : WG_OOB, 0, 0));
+            if (a_half) {                                         // (workgroup-uniform)
+                const wg_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_dz, (rok && a_live) ? offA[e] : WG_OOB, 0, 0);
+                ra[e] = __builtin_bit_cast(f32x4, wg_u32x4{v[0], v[1], 0u, 0u});
+            } else {
+                ra[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dz, (rok && a_live) ? offA[e] : WG_OOB, 0, 0));
+            }
             const int tt = rw[e].t + tdt, fi = rw[e].o * d.istride + tio;
             const bool ok = rok && b_ok && tt >= 0 && tt < d.T && fi >= 0 && fi < d.Fin;
             const unsigned off = ok ? (unsigned)offB[e] : WG_OOB;
-            if (vec_ok) {
+            if (b_half) {                                         // (uniform per thread's column block; C % 16 == 0: host check)
+                const wg_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_src, off, 0, 0);
+                rb[e] = __builtin_bit_cast(f32x4, wg_u32x4{v[0], v[1], 0u, 0u});
+            } else if (vec_ok) {
                 rb[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0));
             } else {
 #pragma unroll
@@ -382,14 +396,39 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_bf_kernel(const WgBatch bt) 
         }
     };
     auto stash = [&](int buf) {
-        if (a_live) {
+        // row pair -> one dword per column: (row 2rp, row 2rp+1) as (low, high) bf16
+        auto pair4 = [](const f32x4 (&r)[2], bool half, unsigned (&o)[4]) {
+            if (half) {                                           // r[e] = two dwords holding the row's four bf16
+                const wg_u32x4 r0 = __builtin_bit_cast(wg_u32x4, r[0]), r1 = __builtin_bit_cast(wg_u32x4, r[1]);
+                o[0] = __builtin_amdgcn_perm(r1[0], r0[0], 0x05040100u);
+                o[1] = __builtin_amdgcn_perm(r1[0], r0[0], 0x07060302u);
+                o[2] = __builtin_amdgcn_perm(r1[1], r0[1], 0x05040100u);
+                o[3] = __builtin_amdgcn_perm(r1[1], r0[1], 0x07060302u);
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a_t[buf][(c4 * 4 + j) * WGB_S + rp] = wg_bf2(ra[0][j], ra[1][j]);
-            if (do_bias) bsum += ra[0] + ra[1];
+                for (int j = 0; j < 4; ++j) o[j] = wg_bf2(r[0][j], r[1][j]);
+            }
+        };
+        if (a_live) {
+            unsigned o[4];
+            pair4(ra, a_half, o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a_t[buf][(c4 * 4 + j) * WGB_S + rp] = o[j];
+            if (do_bias) {
+                if (a_half) {                                     // bias gradient from the stored (bf16) gradient
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        bsum[j] += __builtin_bit_cast(float, o[j] << 16) + __builtin_bit_cast(float, o[j] & 0xFFFF0000u);
+                } else {
+                    bsum += ra[0] + ra[1];
+                }
+            }
         }
         if (b_live) {
+            unsigned o[4];
+            pair4(rb, b_half, o);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b_t[buf][(c4 * 4 + j) * WGB_S + rp] = wg_bf2(rb[0][j], rb[1][j]);
+            for (int j = 0; j < 4; ++j) b_t[buf][(c4 * 4 + j) * WGB_S + rp] = o[j];
         }
     };
 
@@ -461,7 +500,8 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_bf_kernel(const WgBatch bt) 
 static bool wg_same_geometry(const eab_wgrad_desc* a, const eab_wgrad_desc* b) {
     if (a->N != b->N || a->C0 != b->C0 || a->C1 != b->C1 || a->Kpad != b->Kpad || a->B != b->B || a->T != b->T || a->Fin != b->Fin ||
         a->Fz != b->Fz || a->No != b->No || a->ostride != b->ostride || a->ophase != b->ophase || a->istride != b->istride ||
-        a->ntaps != b->ntaps || a->precision != b->precision || (a->src1 == nullptr) != (b->src1 == nullptr) ||
+        a->ntaps != b->ntaps || a->precision != b->precision || a->bf16_mask != b->bf16_mask ||
+        (a->src1 == nullptr) != (b->src1 == nullptr) ||
         (a->dbias == nullptr) != (b->dbias == nullptr))
         return false;
     for (int k = 0; k < a->ntaps; ++k)
@@ -489,6 +529,11 @@ extern "C" int eab_wgrad_batch_f32(const eab_wgrad_desc* descs, int n, int strid
     }
     EAB_CHECK_ARG(d->B > 0 && d->T > 0 && d->Fin > 0 && d->Fz > 0 && d->No > 0 && d->N > 0 && (d->N % 64) == 0);
     EAB_CHECK_ARG(d->precision == EAB_PREC_F32 || d->precision == EAB_PREC_BF16);
+    if (d->bf16_mask) {        // operands stored as bf16: bf16 products, whole 16-channel units, flagged sources must exist
+        EAB_CHECK_ARG((d->bf16_mask & ~7) == 0 && d->precision == EAB_PREC_BF16 && (d->N % 4) == 0);
+        EAB_CHECK_ARG(!(d->bf16_mask & 2) || (d->C0 % 16) == 0);
+        EAB_CHECK_ARG(!(d->bf16_mask & 4) || (d->src1 && (d->C1 % 16) == 0 && (d->C0 % 16) == 0));
+    }
     // 32-bit byte offsets inside the kernels
     EAB_CHECK_ARG((unsigned long long)d->B * d->T * d->Fz * d->N * 4 < (1ull << 31));
     EAB_CHECK_ARG((unsigned long long)d->B * d->T * d->Fin * (d->C0 > d->C1 ? d->C0 : d->C1) * 4 < (1ull << 31));

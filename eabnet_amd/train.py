@@ -46,6 +46,7 @@ XF_NORM_PRELU, XF_PRELU_NORM = prg.XF_NORM_PRELU, prg.XF_PRELU_NORM
  OP_FILTER_SUM, OP_FS_BWD, OP_LN_FWD, OP_LN_BWD, OP_LSTM_TRAIN, OP_LSTM_BWD, OP_WGRAD) = range(16, 33)
 OP_CLN_STATS, OP_CLN_APPLY, OP_CLN_BWD = prg.OP_CLN_STATS, prg.OP_CLN_APPLY, 37      # include/eabnet_hip.h EAB_OP_CLN_*
 NB_SUMS_ZEROED = 0x100   # include/eabnet_hip.h EAB_NB_SUMS_ZEROED
+STORE_BF16 = 0x200       # include/eabnet_hip.h EAB_STORE_BF16: the op's output tensor is stored as bf16
 MLP_LD = 64          # the second Linear of w_dnn is run with its 2M rows padded to one 64-column tile
 TRAIN_BOUND_CACHE = 3   # bound training programs kept per module (LRU over (B, T, F, device, precision))
 
@@ -105,6 +106,7 @@ class WgradOp:
     kind: int = OP_WGRAD
     dbias: Optional[Ref] = None          # bias gradient (column sums of dz over this launch's rows) rides along
     precision: int = 0                   # EAB_PREC_F32, or EAB_PREC_BF16 (operands rounded to bf16, fp32 accumulation)
+    bf16_mask: int = 0                   # bit 0 / 1 / 2: dz / src0 / src1 is stored as bf16 (eab_wgrad_desc.bf16_mask)
 
 
 class Slot:
@@ -195,6 +197,10 @@ class TrainLowering:
             n += int(np.prod(s.shape)) if s.shape else 1
         self.n_params = n
         self.a_size = 0
+        self.allocs: List[Tuple[int, int]] = []                               # (offset, floats) of every activation-arena region
+        # bf16 STORAGE of the tensors only bf16 contractions read (assign_bf16_storage); EAB_BF16_STORE=0: everything fp32
+        self.bf16_store = os.environ.get("EAB_BF16_STORE", "1") != "0"
+        self.bf16_tensors = 0
         self.w_imgs: List[Tuple[np.ndarray, Optional[np.ndarray]]] = []      # packed-parameter images (flat indices, -1 = 0)
         self.w_size = 0
         self.w_index: Dict[str, Ref] = {}
@@ -220,6 +226,7 @@ class TrainLowering:
     # ---- arenas ------------------------------------------------------------------------------------
     def alloc(self, nfloats: int) -> Ref:
         ref = Ref("a", self.a_size)
+        self.allocs.append((self.a_size, nfloats))
         self.a_size += nfloats + ((-nfloats) % ALIGN)
         return ref
 
@@ -870,6 +877,75 @@ class TrainLowering:
             fn()
         return self.finish()
 
+    def assign_bf16_storage(self) -> None:
+        """bf16 programs: STORE as bf16 every tensor that nothing but bf16 contractions read (BASELINE configs[3]: "bf16").
+        Those kernels round their operands to bf16 on the way into LDS, so a tensor whose only readers are the gather of a bf16
+        convolution (forward or dgrad) and the bf16 weight-gradient kernel can be written in bf16 by its producer: the
+        contractions see the same bits, the producer writes and the consumers read half the bytes, and the consumers convert
+        nothing.  What qualifies in practice: the normalised activations between the 2-D units (producer tr_norm_act) and the
+        gradients of the 2-D convolution outputs (producers: the apply pass of the norm backward, the GLU backward).  Everything
+        else -- raw convolution outputs and their statistics, residual operands, gradients that accumulate, the S-TCN (small-
+        tile kernel), LSTM, head -- stays fp32.  Decided on the finished op lists: a region of the activation arena becomes bf16
+        iff it has exactly one writer, that writer can store bf16, and every reader is such a contraction; regions keep their
+        size and offset (a bf16 tensor occupies the first half), so nothing else of the program changes."""
+        import bisect
+        starts = [a for a, _ in self.allocs]
+
+        def region(ref: Optional[Ref]) -> Optional[int]:
+            if ref is None or ref.arena != "a":
+                return None
+            k = bisect.bisect_right(starts, ref.off) - 1
+            return k if k >= 0 and ref.off < starts[k] + max(self.allocs[k][1], 1) else None
+        uses: Dict[int, list] = {}
+
+        def note(ref, what, op, arg=None):
+            k = region(ref)
+            if k is not None:
+                # a use that does not start at the region's first element is a partial view: never converted
+                uses.setdefault(k, []).append((what if ref.off == starts[k] else "other", op, arg))
+
+        def conv_reads_bf16(op) -> bool:
+            return (op.precision == prg.PREC_BF16 and op.korder == prg.KORDER_TAP and op.xf_mode == prg.XF_NONE and op.Fin > 1
+                    and op.C0 % 16 == 0 and op.C1 % 16 == 0 and op.epi != prg.EPI_DUALGATE and not getattr(op, "win", False)
+                    and op.fin_stats is None)
+        for op in list(self.fwd) + list(self.bwd) + list(self.deferred):
+            if isinstance(op, prg.ConvOp):
+                ok = conv_reads_bf16(op)
+                note(op.src0, "read" if ok else "other", op, ("conv", 1))
+                note(op.src1, "read" if ok else "other", op, ("conv", 2))
+                for f in ("aux", "dst", "dst_acc", "stats", "glu_dump", "xf0", "xf1", "fin_stats", "f2_dst", "f2_stats"):
+                    note(getattr(op, f, None), "other", op)
+            elif isinstance(op, WgradOp):
+                ok = op.precision == prg.PREC_BF16
+                note(op.dz, "read" if ok and op.N % 4 == 0 else "other", op, ("wgrad", 1))
+                note(op.src0, "read" if ok and op.C0 % 16 == 0 else "other", op, ("wgrad", 2))
+                note(op.src1, "read" if ok and op.C0 % 16 == 0 and op.C1 % 16 == 0 else "other", op, ("wgrad", 4))
+            elif isinstance(op, GenOp):
+                writer = {OP_TR_NORM_ACT: 4, OP_GLU_BWD: 2}.get(op.kind)
+                if op.kind == OP_NORM_BWD and len(op.i) == 4 and op.p[7] is None:
+                    writer = 8                                   # dx of the single-tensor norm backward, not accumulating
+                for j, r in enumerate(op.p):
+                    note(r, "write" if j == writer else "other", op, j)
+            else:                                                # MemsetOp, FinalizeOp, ...: whatever they touch stays fp32
+                for v in vars(op).values():
+                    if isinstance(v, Ref):
+                        note(v, "other", op)
+        for k, lst in uses.items():
+            kinds = [w for w, _, _ in lst]
+            if "other" in kinds or kinds.count("write") != 1 or "read" not in kinds:
+                continue
+            self.bf16_tensors += 1
+            for what, op, arg in lst:
+                if what == "write":
+                    if op.kind == OP_GLU_BWD:
+                        op.i = list(op.i[:3]) + [STORE_BF16]
+                    else:
+                        op.i[3] |= STORE_BF16                    # (mode word of eab_train_norm_act_f32 / eab_train_norm_bwd_f32)
+                elif arg[0] == "conv":
+                    op.src_bf16 = getattr(op, "src_bf16", 0) | arg[1]
+                else:
+                    op.bf16_mask |= arg[1]
+
     def finish(self) -> "TrainProgram":
         ia = np.concatenate([a for a, _ in self.w_imgs]).astype(np.int32)
         has_b = any(b is not None for _, b in self.w_imgs)
@@ -882,9 +958,12 @@ class TrainLowering:
                 tgt = fl[m]
                 assert (inv[tgt] == -1).all(), "a parameter element received two gradient entries"
                 inv[tgt] = off + np.nonzero(m)[0]
+        if self.prec == prg.PREC_BF16 and self.bf16_store:
+            self.assign_bf16_storage()
+
         def geometry(o: WgradOp):
             return (o.N, o.C0, o.C1, o.Kpad, o.Fin, o.Fz, o.No, o.ostride, o.ophase, o.istride, tuple(o.dt), tuple(o.ioff),
-                    o.src1 is None, o.dbias is None, o.precision)
+                    o.src1 is None, o.dbias is None, o.precision, o.bf16_mask)
         order: Dict[tuple, int] = {}
         for o in self.deferred:
             order.setdefault(geometry(o), len(order))
@@ -1010,6 +1089,7 @@ class TrainBound:
                               "stat_slope0", "stat_slope1", "fin_stats", "fin_gamma0", "fin_beta0", "fin_gamma1", "fin_beta1"):
                         setattr(d, f, A(getattr(op, f)))
                     d.glu_dump = A(getattr(op, "glu_dump", None))
+                    d.src_bf16 = int(getattr(op, "src_bf16", 0))
                     for f in ("C0", "C1", "xf_mode", "N", "Kpad", "B", "T", "Fin", "Fout", "No", "ostride", "ophase", "istride",
                               "epi", "Cout", "nsets", "stat_tiles", "stat_tile0", "bm", "fin_tiles", "fin_nsets", "fin_count",
                               "precision", "korder"):
@@ -1037,6 +1117,7 @@ class TrainBound:
                         setattr(d, f, int(getattr(op, f)))
                     d.ntaps = len(op.dt)
                     d.precision = int(op.precision)
+                    d.bf16_mask = int(op.bf16_mask)
                     for j in range(_lib.MAX_TAPS):
                         d.dt[j] = op.dt[j] if j < len(op.dt) else 0
                         d.ioff[j] = op.ioff[j] if j < len(op.ioff) else 0

@@ -294,6 +294,12 @@ typedef struct eab_conv_desc {
     int32_t f2_N, f2_nsets, f2_stat_tiles;
     /* EAB_EPI_PHASE2 only: which taps also feed the phase-1 columns (bit j = tap j); 0 otherwise */
     int32_t p2_mask1;
+    /* EAB_PREC_BF16, EAB_KORDER_TAP, xf_mode NONE, Fin > 1, C0 % 16 == C1 % 16 == 0: bit 0 / bit 1 = src0 / src1 is STORED as
+     * bf16 ([B][T][Fin][C] of 2-byte elements) -- the bf16 training programs' normalised activations and convolution-output
+     * gradients (eab_train_norm_act_f32 / eab_train_norm_bwd_f32 / eab_glu_bwd_ex_f32 with EAB_STORE_BF16).  The precision
+     * rounds fp32 operands to bf16 on their way into LDS anyway, so results are identical to the fp32-stored tensor; the
+     * gather moves half the bytes and converts nothing.  0 = fp32 sources. */
+    int32_t src_bf16;
 } eab_conv_desc;
 
 #define EAB_PREC_F32   0
@@ -410,6 +416,9 @@ typedef struct eab_wgrad_desc {
     int32_t ioff[EAB_MAX_TAPS];
     int32_t rows_per_wg;    /* set by the library */
     int32_t precision;      /* EAB_PREC_F32 (exact fp32 products) or EAB_PREC_BF16 (operands rounded to bf16, fp32 accumulation) */
+    int32_t bf16_mask;      /* EAB_PREC_BF16 only: bit 0 / 1 / 2 = dz / src0 / src1 is STORED as bf16 (2-byte elements, same
+                             * shape; needs N % 4 == 0 and C % 16 == 0 for the flagged tensors).  The products are those of
+                             * the fp32-stored tensor (it would be rounded to bf16 here); dbias then sums the stored values. */
 } eab_wgrad_desc;
 
 typedef struct eab_op {
@@ -510,6 +519,11 @@ int eab_train_norm_act_f32(const float* x, const float* xf, const float* slope, 
  * dx = dy * prelu'(x), only dslope is accumulated (the plain U-Net's middle encoder layers, EaBNet.py:219-226).
  * Two launches (reduce, apply; the parameter gradients ride in the apply pass).  Reference: autograd of EaBNet.py:684-686 + nn.PReLU. */
 #define EAB_NB_SUMS_ZEROED 0x100
+/* OR-ed into the `mode` of eab_train_norm_act_f32 (y) / eab_train_norm_bwd_f32 (dx; acc_in must be NULL) and passed as `flags`
+ * to eab_glu_bwd_ex_f32 (dz): the OUTPUT tensor is stored as bf16 (2-byte elements, same shape, round to nearest even).  The
+ * bf16 training programs set it for tensors that only bf16 contractions read (eab_conv_desc.src_bf16, eab_wgrad_desc.bf16_mask):
+ * those round their operands to bf16 anyway, so the numbers do not change -- the bytes halve. */
+#define EAB_STORE_BF16 0x200
 int eab_train_norm_bwd_f32(const float* dy, const float* x, const float* mr, const float* gamma, const float* beta,
                            const float* slope, float* sums, const float* acc_in, float* dx, float* dgamma, float* dbeta,
                            float* dslope, int B, int P, int C, int mode, eab_stream_t stream);
@@ -522,6 +536,8 @@ int eab_train_norm_bwd_multi_f32(const float* dy0, const float* dy1, const float
 /* GLU backward (EaBNet.py:459-460, 489-490): dy [rows][N/2], dump [rows][N] (eab_conv_desc.glu_dump) -> dz [rows][N]
  * in the packed column order of the forward convolution */
 int eab_glu_bwd_f32(const float* dy, const float* dump, float* dz, long long rows, int N, eab_stream_t stream);
+/* the same with flags: EAB_STORE_BF16 = dz is stored as bf16 (read by bf16 weight / data gradients only) */
+int eab_glu_bwd_ex_f32(const float* dy, const float* dump, float* dz, long long rows, int N, int flags, eab_stream_t stream);
 /* S-TCM gate z = a*sigmoid(r) (EaBNet.py:575) and its backward; n floats, n % 4 == 0 */
 int eab_gate_fwd_f32(const float* a, const float* r, float* z, long long n, eab_stream_t stream);
 int eab_gate_bwd_f32(const float* dz, const float* a, const float* r, float* da, float* dr, long long n, eab_stream_t stream);

@@ -1860,6 +1860,36 @@ def test_bf16_training_gradients_vs_fp64_oracle_and_the_references_own_bf16_mode
     assert min(cos.values()) >= 0.99, sorted((c, k) for k, c in cos.items())[:5]
 
 
+def test_bf16_storage_changes_the_bytes_not_the_numbers(dev, monkeypatch):
+    """bf16 training programs store the tensors that only bf16 contractions read as bf16 (train.assign_bf16_storage).  Those
+    kernels round their operands to bf16 anyway, so against the same program with everything stored in fp32 (EAB_BF16_STORE=0)
+    the forward output must be bit-identical and the gradients equal up to the order of the fp32 atomics (and the bias
+    gradients, which sum the stored -- rounded -- convolution-output gradients)."""
+    import eabnet_amd
+    x = torch.from_numpy(paramgen.make_spec_input(2, 40, 161, 4, 1101)).to(dev)
+    label = torch.from_numpy(paramgen.make_spec_input(2, 40, 161, 1, 1102)[..., 0, :]).permute(0, 3, 1, 2).contiguous().to(dev)
+    res = {}
+    for store in ("0", "1"):
+        monkeypatch.setenv("EAB_BF16_STORE", store)
+        net = _model(4, 1100, dev, p=2, q=1).train()
+        net.precision = "bf16"
+        y = net(x)
+        eabnet_amd.com_mag_mse_loss(y, label, [40, 40]).backward()
+        bound = next(iter(net._train_bound.values()))
+        n_bf = sum(1 for op in bound.prog.fwd + bound.prog.bwd if getattr(op, "src_bf16", 0) or getattr(op, "bf16_mask", 0))
+        assert (n_bf > 50) == (store == "1"), n_bf
+        res[store] = (y.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+    assert torch.equal(res["0"][0], res["1"][0]), "forward output must not change"
+    g0 = torch.cat([g.reshape(-1) for g in res["0"][1].values()]).double()
+    g1 = torch.cat([g.reshape(-1) for g in res["1"][1].values()]).double()
+    rel = float((g1 - g0).norm() / g0.norm())
+    assert rel <= 2e-3, rel
+    for k in res["0"][1]:
+        if not k.endswith("bias"):
+            a, b = res["0"][1][k].double(), res["1"][1][k].double()
+            assert float((a - b).norm()) <= 1e-4 * float(a.norm()) + 1e-9, k      # weights: same products, atomics order only
+
+
 def test_config4_ddp_training_on_the_hip_programs(dev):
     """BASELINE configs[3] on one rank: train_distributed.py's step (:218-230) for the beam-former stage with forward and
     backward on the HIP training programs, (a) under torch DistributedDataParallel over the RCCL backend (one 64 MB

@@ -139,3 +139,61 @@ def test_every_post_filter_variant_lowers_to_training_programs(name):
     assert (np.asarray(prog.inv) >= 0).all()
     specs = eabnet_amd.gag_param_specs(cfg)
     assert len(prog.bn_layers) == sum(1 for s in specs.values() if s.kind == "bn_mean")
+
+
+def test_bf16_storage_is_assigned_only_where_nothing_but_bf16_contractions_read(monkeypatch):
+    """bf16 training programs store as bf16 exactly the tensors whose every reader is a bf16 contraction (the gather of a bf16
+    convolution, the bf16 weight gradient): each such tensor has ONE writer, flagged EAB_STORE_BF16; every reader of it is
+    flagged for that operand; no other op touches it; and nothing is flagged in an fp32 program or with EAB_BF16_STORE=0."""
+    from dataclasses import replace
+    from eabnet_amd import program as prg
+    cfg = replace(spec.NetConfig(), M=4, p=2, q=1)
+
+    def flagged(prog):
+        writes, reads = {}, {}
+        for op in prog.fwd + prog.bwd:
+            if isinstance(op, prg.ConvOp):
+                for bit, ref in ((1, op.src0), (2, op.src1)):
+                    if getattr(op, "src_bf16", 0) & bit:
+                        reads.setdefault(ref.off, []).append(op)
+            elif isinstance(op, train.WgradOp):
+                for bit, ref in ((1, op.dz), (2, op.src0), (4, op.src1)):
+                    if op.bf16_mask & bit:
+                        reads.setdefault(ref.off, []).append(op)
+            elif isinstance(op, train.GenOp) and len(op.i) > 3 and (op.i[3] & train.STORE_BF16):
+                out = {train.OP_TR_NORM_ACT: 4, train.OP_NORM_BWD: 8, train.OP_GLU_BWD: 2}[op.kind]
+                assert op.p[out].off not in writes, "one writer per bf16 tensor"
+                writes[op.p[out].off] = op
+        return writes, reads
+
+    prog = train.lower_train(cfg, 2, 20, 161, "bf16")
+    writes, reads = flagged(prog)
+    assert len(writes) >= 20 and set(writes) == set(reads), "every bf16 tensor has its flagged writer and flagged readers"
+    # nobody else reads or writes those regions
+    offs = set(writes)
+    for op in prog.fwd + prog.bwd:
+        refs = []
+        if isinstance(op, prg.ConvOp):
+            refs = [(r, getattr(op, "src_bf16", 0) & b) for b, r in ((1, op.src0), (2, op.src1))] + \
+                   [(getattr(op, f, None), 0) for f in ("aux", "dst", "dst_acc", "stats", "glu_dump")]
+            assert not getattr(op, "src_bf16", 0) or (op.precision == prg.PREC_BF16 and op.korder == prg.KORDER_TAP and op.Fin > 1
+                                                      and op.xf_mode == prg.XF_NONE and op.C0 % 16 == 0 and op.C1 % 16 == 0)
+        elif isinstance(op, train.WgradOp):
+            refs = [(r, op.bf16_mask & b) for b, r in ((1, op.dz), (2, op.src0), (4, op.src1))]
+            assert not op.bf16_mask or op.precision == prg.PREC_BF16
+        elif isinstance(op, train.GenOp):
+            out = {train.OP_TR_NORM_ACT: 4, train.OP_NORM_BWD: 8, train.OP_GLU_BWD: 2}.get(op.kind)
+            st = len(op.i) > 3 and (op.i[3] & train.STORE_BF16) and out is not None
+            refs = [(r, 1 if (st and j == out) else 0) for j, r in enumerate(op.p)]
+            if op.kind == train.OP_NORM_BWD and st:
+                assert op.p[7] is None, "a bf16 gradient is never an accumulation target"
+        for r, fl in refs:
+            if r is not None and r.arena == "a" and r.off in offs:
+                assert fl, f"{getattr(op, 'name', op)} touches a bf16 tensor without knowing it"
+    # the S-TCN (1-D, small-tile kernel), the LSTM and the head stay fp32
+    assert not any(getattr(op, "src_bf16", 0) for op in prog.fwd + prog.bwd if isinstance(op, prg.ConvOp) and op.Fin == 1)
+    w32, r32 = flagged(train.lower_train(cfg, 2, 20, 161, "f32"))
+    assert not w32 and not r32
+    monkeypatch.setenv("EAB_BF16_STORE", "0")
+    w0, r0 = flagged(train.lower_train(cfg, 2, 20, 161, "bf16"))
+    assert not w0 and not r0
