@@ -136,6 +136,7 @@ _SIGS = {
     "eab_wgrad_batch_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "eab_cln_stats_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_float] + [C.c_void_p] * 3 + [TimeWindow, C.c_void_p]),
     "eab_cln_apply_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 5 + [TimeWindow, C.c_void_p]),
+    "eab_cln_step_f32": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 5 + [C.c_float, TimeWindow, C.c_void_p]),
     "eab_gate_rows_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [TimeWindow, C.c_void_p]),
 }
 EXPORTS = tuple(_SIGS)

@@ -135,6 +135,86 @@ extern "C" int eab_cln_apply_f32(const float* x, const float* mr, const float* g
     EAB_RETURN_LAUNCH_STATUS();
 }
 
+// One frame of a streaming step (win.count == 1): statistics, running sums and apply of a unit in ONE launch, one workgroup
+// per utterance.  Each part is the code of the stand-alone kernel it replaces -- the same thread-to-element map and block
+// reduction as cln_frame_sums_kernel, the scan step of cln_scan_kernel, the expression of cln_apply_kernel -- so the frame's
+// bits are those of the three-launch form (and of the offline pass).
+__global__ __launch_bounds__(CL_THREADS) void cln_step_kernel(const float* __restrict__ x, const float* __restrict__ st_slope,
+                                                              double* __restrict__ sums, double* __restrict__ state,
+                                                              float* __restrict__ mr, const float* __restrict__ gain,
+                                                              const float* __restrict__ bias, const float* __restrict__ slope,
+                                                              const float* __restrict__ add, float* __restrict__ y, int T, int P,
+                                                              int C, int mode, float eps, const int* __restrict__ t_pos) {
+    __shared__ double red[4];
+    __shared__ float2 m_sh;
+    const int b = blockIdx.x, t = *t_pos;
+    if (t >= T) return;                                            // (uniform)
+    const float* row = x + ((size_t)b * T + t) * P;
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x * 4; i < P; i += CL_THREADS * 4) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(row + i);
+        if (st_slope) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(st_slope + (i % C));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = eab_prelu(v[j], a[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s += (double)v[j];
+            q += (double)v[j] * (double)v[j];
+        }
+    }
+    s = cl_block_sum(s, red);
+    q = cl_block_sum(q, red);
+    if (threadIdx.x == 0) {
+        sums[((size_t)b * T + t) * 2] = s;
+        sums[((size_t)b * T + t) * 2 + 1] = q;
+        double cs = 0.0, cq = 0.0;
+        if (t > 0) {
+            cs = state[b * 2];
+            cq = state[b * 2 + 1];
+        }
+        cs += s;
+        cq += q;
+        const double cnt = (double)P * (double)(t + 1);
+        const double mean = cs / cnt;
+        double var = (cq - 2.0 * mean * cs) / cnt + mean * mean;        // the reference's expression (EaBNet.py:731, 764)
+        const float2 m = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+        *reinterpret_cast<float2*>(&mr[((size_t)b * T + t) * 2]) = m;
+        state[b * 2] = cs;
+        state[b * 2 + 1] = cq;
+        m_sh = m;
+    }
+    __syncthreads();
+    const float2 m = m_sh;
+    const size_t base4 = ((size_t)b * T + t) * ((unsigned)P >> 2);
+    for (unsigned r = threadIdx.x; r < ((unsigned)P >> 2); r += CL_THREADS) {
+        const size_t i = base4 + r;
+        const int c = (int)(r * 4 % C);
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gain + c), be = *reinterpret_cast<const f32x4*>(bias + c),
+                    a = *reinterpret_cast<const f32x4*>(slope + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = mode == EAB_XF_NORM_PRELU ? eab_prelu(fmaf((v[j] - m.x) * m.y, g[j], be[j]), a[j])
+                                             : fmaf((eab_prelu(v[j], a[j]) - m.x) * m.y, g[j], be[j]);
+        if (add) o += reinterpret_cast<const f32x4*>(add)[i];
+        reinterpret_cast<f32x4*>(y)[i] = o;
+    }
+}
+
+extern "C" int eab_cln_step_f32(const float* x, const float* stat_slope, double* sums, double* state, float* mr, const float* gain,
+                                const float* bias, const float* slope, const float* add, float* y, int B, int T, int P, int C,
+                                int mode, float eps, eab_time_window win, eab_stream_t stream) {
+    EAB_CHECK_ARG(x && sums && state && mr && gain && bias && slope && y && B > 0 && T > 0 && P > 0 && C > 0);
+    EAB_CHECK_ARG((P % C) == 0 && (C % 4) == 0 && win.pos != nullptr && win.count == 1);
+    EAB_CHECK_ARG(mode == EAB_XF_NORM_PRELU || mode == EAB_XF_PRELU_NORM);
+    hipLaunchKernelGGL(cln_step_kernel, dim3((unsigned)B), dim3(CL_THREADS), 0, eab_stream(stream), x, stat_slope, sums, state, mr,
+                       gain, bias, slope, add, y, T, P, C, mode, eps, win.pos);
+    EAB_RETURN_LAUNCH_STATUS();
+}
+
 __global__ __launch_bounds__(CL_THREADS) void gate_rows_kernel(const float* __restrict__ a, const float* __restrict__ r,
                                                                float* __restrict__ z, int T, int row4, const int* __restrict__ t_pos,
                                                                int t_count) {

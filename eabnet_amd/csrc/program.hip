@@ -206,6 +206,11 @@ extern "C" int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream
                 rc = eab_cln_apply_f32(EAB_P(0), EAB_P(1), EAB_P(2), EAB_P(3), EAB_P(4), EAB_P(5), EAB_W(6), o.i[0], o.i[1], o.i[2],
                                        o.i[3], o.i[4], o.win, stream);
                 break;
+            case EAB_OP_CLN_STEP:
+                rc = eab_cln_step_f32(EAB_P(0), EAB_P(1), (double*)const_cast<void*>(o.p[2]), (double*)const_cast<void*>(o.p[3]),
+                                      EAB_W(4), EAB_P(5), EAB_P(6), EAB_P(7), EAB_P(8), EAB_W(9), o.i[0], o.i[1], o.i[2], o.i[3],
+                                      o.i[4], o.f[0], o.win, stream);
+                break;
             case EAB_OP_CLN_BWD:
                 rc = eab_train_cln_bwd_f32(EAB_P(0), EAB_P(1), EAB_P(2), EAB_P(3), EAB_P(4), EAB_P(5), (double*)const_cast<void*>(o.p[6]),
                                            EAB_W(7), EAB_W(8), EAB_P(9), EAB_W(10), o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], stream);

@@ -677,8 +677,10 @@ __global__ __launch_bounds__(TR_THREADS) void copy_kernel(const float* __restric
 extern "C" int eab_copy_f32(const float* src, float* dst, long long n, eab_stream_t stream) {
     EAB_CHECK_ARG(src && dst && n >= 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0);
     if (n == 0) return EAB_OK;
+    // 128 workgroups keep ~0.5 MB of reads in flight -- several times what a PCIe link needs at its latency -- and leave the
+    // rest of the chip to the batches that compute while this one uploads (2048 workgroups queued behind their kernels)
     long long g = (n / 4 + TR_THREADS - 1) / TR_THREADS;
-    if (g > 2048) g = 2048;
+    if (g > 128) g = 128;
     if (g < 1) g = 1;
     hipLaunchKernelGGL(copy_kernel, dim3((unsigned)g), dim3(TR_THREADS), 0, eab_stream(stream), src, dst, n / 4, n);
     EAB_RETURN_LAUNCH_STATUS();

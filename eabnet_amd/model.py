@@ -250,11 +250,16 @@ class _Bound:
         single-op debug launches).  EAB_ST_CHAIN=0 keeps separate launches."""
         import os
         self.exec_ops, self.n_exec, self.chains = None, 0, []
-        if not self.prog.chunk or os.environ.get("EAB_ST_CHAIN", "1") == "0":
+        if not self.prog.chunk:
             return
         lib = _lib.load()
         ops = self.prog.ops
         n = len(ops)
+        use_chain = os.environ.get("EAB_ST_CHAIN", "1") != "0"
+        # cLN, one frame per step: the statistics / scan / apply launches of a unit (eab_cln_stats_f32 = two launches, then
+        # eab_cln_apply_f32) become ONE launch (eab_cln_step_f32: one workgroup per utterance sums the new frame, advances the
+        # running sums and normalises the frame -- the same code paths, so the same bits).  EAB_CLN_STEP=0 keeps three launches.
+        fuse_cln = self.prog.chunk == 1 and os.environ.get("EAB_CLN_STEP", "1") != "0"
         def plan(first, cnt):
             descs = (_lib.ConvDesc * cnt)(*[self.ops[first + t].conv for t in range(cnt)])
             codes = (C.c_int * cnt)()
@@ -264,7 +269,8 @@ class _Bound:
             return first, cnt, descs, codes, lds.value, bf.value
         # every op on its own first (is it a single-tile launch of a form the chain kernel carries, and in which precision),
         # then maximal runs of such ops, planned as a whole
-        single = [plan(k, 1) if (ops[k].kind == prg.OP_CONV and ops[k].korder == prg.KORDER_FRAG) else None for k in range(n)]
+        single = [plan(k, 1) if (use_chain and ops[k].kind == prg.OP_CONV and ops[k].korder == prg.KORDER_FRAG) else None
+                  for k in range(n)]
         runs = []                                       # (first, count, descs, codes, lds, bf)
         k = 0
         while k < n:
@@ -278,12 +284,30 @@ class _Bound:
             if got:
                 runs.append(got)
             k = j
-        if not runs:
+        def cln_pair(k):
+            a, b = ops[k], ops[k + 1] if k + 1 < n else None
+            return (fuse_cln and b is not None and a.kind == prg.OP_CLN_STATS and b.kind == prg.OP_CLN_APPLY and a.x == b.x
+                    and a.mr == b.mr and (a.B, a.T, a.P, a.C) == (b.B, b.T, b.P, b.C) and a.win and b.win and a.state is not None)
+        if not runs and not any(cln_pair(k) for k in range(n - 1)):
             return
         exec_list = []
         k = 0
         ri = 0
         while k < n:
+            if cln_pair(k):
+                a, b = self.ops[k], self.ops[k + 1]
+                o = _lib.Op()
+                o.kind = prg.OP_CLN_STEP
+                for j in range(5):
+                    o.p[j] = a.p[j]                           # x, slope of the statistics, sums, state, mr
+                for j, src in enumerate((2, 3, 4, 5, 6)):
+                    o.p[5 + j] = b.p[src]                     # gain, bias, slope, add, y
+                o.i[0:5] = [b.i[0], b.i[1], b.i[2], b.i[3], b.i[4]]
+                o.f[0] = a.f[0]
+                o.win.pos, o.win.count = a.win.pos, a.win.count
+                exec_list.append(o)
+                k += 2
+                continue
             if ri < len(runs) and runs[ri][0] == k:
                 first, cnt, descs, codes, lds, bf = runs[ri]
                 raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.device)
@@ -1048,7 +1072,9 @@ class _HostStager:
         # (one slot more than the deepest Pipeline keeps in flight: a slot is refilled only when its batch has been consumed)
         self.device, self.depth, self.k = device, depth, 0
         self.slots: Dict[tuple, list] = {}
-        self.stream = torch.cuda.Stream(device=device)
+        # high priority: the copy kernel is a few dozen workgroups that must get their CU slots while other batches compute --
+        # on a normal-priority stream its workgroups queue behind the convolutions' and every pipeline slot waits for its upload
+        self.stream = torch.cuda.Stream(device=device, priority=-1)
 
     def upload(self, t: torch.Tensor) -> Tuple[torch.Tensor, "torch.cuda.Event"]:
         """CPU tensor -> contiguous fp32 device tensor, ordered on the CURRENT stream.  Returns (tensor, consumed):

@@ -33,6 +33,7 @@ XF_NONE, XF_NORM_PRELU, XF_PRELU_NORM = 0, 1, 2
 EPI_LINEAR, EPI_GLU, EPI_RELU, EPI_MULSIG, EPI_ADD, EPI_DUALGATE, EPI_PHASE2 = 0, 1, 2, 3, 4, 5, 6
 OP_CONV, OP_IN_FINALIZE, OP_NORM_ACT, OP_LSTM64, OP_BFW_FS, OP_MEMSET0, OP_GAG_PACK, OP_GAG_CRM = 1, 2, 3, 4, 5, 6, 7, 8
 OP_CLN_STATS, OP_CLN_APPLY, OP_GATE_ROWS = 33, 34, 35
+OP_CLN_STEP = 38         # run-time only (model._Bound): statistics + apply of a cLN unit for a one-frame streaming step in one launch
 OP_CONV_CHAIN = 9        # run-time only (model._Bound): a run of small-tile launches executed by one launch (csrc/conv_st.hip)
 ACT_SIGMOID, ACT_TANH, ACT_RELU = 0, 1, 2
 GAG_PRE_LD = 324   # floats per (b, t) row of the interleaved previous estimate: 2*161 rounded up to a float4

@@ -641,6 +641,12 @@ int eab_cln_apply_f32(const float* x, const float* mr, const float* gain, const 
                       eab_stream_t stream);
 int eab_gate_rows_f32(const float* a, const float* r, float* z, int B, int T, int row_floats, eab_time_window win,
                       eab_stream_t stream);
+/* One frame of a streaming step (win.count == 1): eab_cln_stats_f32 followed by eab_cln_apply_f32 on the same x in ONE launch
+ * (one workgroup per utterance: frame sums -> running sums and mr[b][t] -> normalised frame).  Bit-identical to the two calls
+ * (same reduction tree, same expressions); stat_slope = the statistics' PReLU slope (EAB_XF_PRELU_NORM) or NULL. */
+int eab_cln_step_f32(const float* x, const float* stat_slope, double* sums, double* state, float* mr, const float* gain,
+                     const float* bias, const float* slope, const float* add, float* y, int B, int T, int P, int C, int mode,
+                     float eps, eab_time_window win, eab_stream_t stream);
 /* program ops:  CLN_STATS  p = {x, slope, sums, state, mr}              i = {B, T, P, C}        f = {eps}
  *               CLN_APPLY  p = {x, mr, gain, bias, slope, add, y}       i = {B, T, P, C, mode}
  *               GATE_ROWS  p = {a, r, z}                                i = {B, T, row_floats}       (all three windowed) */
@@ -648,6 +654,7 @@ int eab_gate_rows_f32(const float* a, const float* r, float* z, int B, int T, in
 #define EAB_OP_CLN_APPLY 34
 #define EAB_OP_GATE_ROWS 35
 #define EAB_OP_GAG_CRM_BWD 36
+#define EAB_OP_CLN_STEP 38  /* eab_cln_step_f32: p = {x, stat_slope, sums, state, mr, gain, bias, slope, add, y}, i = {B, T, P, C, mode}, f = {eps} */
 #define EAB_OP_CLN_BWD 37   /* eab_train_cln_bwd_f32: p = {dy, x, mr, gain, bias, slope, rowsums, ab, part, acc_in, dx}, i = {B, T, P, C, mode} */
 
 /* struct-layout handshake for foreign-function mirrors of the structs above */
