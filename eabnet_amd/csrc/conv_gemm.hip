@@ -212,7 +212,13 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
     const int Ctot = d.C0 + d.C1;
     const int UPT = (Ctot + 15) >> 4;
     const int NU = d.ntaps * UPT;
-    const int NS = (NU + KU - 1) / KU;              // pipeline stages
+    // bf16-STORED sources (src_bf16, LEAN gather of the bf16 precision) are walked in units of 32 channels: a thread's 16-byte
+    // load is eight channels, the four threads of a row cover 64 bytes -- a whole sector, where four-channel loads of a bf16
+    // tensor leave half of every 64-byte segment unused -- and a stage carries two MFMA k-steps instead of one: half the
+    // stages, half the barriers.  The k order (and so every bit of the result) is that of the 16-channel walk.
+    const bool w0 = BF && (d.src_bf16 & 1), w1 = BF && (d.src_bf16 & 2);
+    const int NS = (w0 || w1) ? d.ntaps * ((w0 ? d.C0 >> 5 : (d.C0 + 15) >> 4) + (d.C1 > 0 ? (w1 ? d.C1 >> 5 : (d.C1 + 15) >> 4) : 0))
+                              : (NU + KU - 1) / KU;              // pipeline stages
 
     // one buffer descriptor per source, spanning this workgroup's batch element
     // (src_bf16, bf16 products only: a source stored as bf16 [B][T][Fin][C] -- the training programs' normalised activations and
@@ -473,6 +479,7 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
     // staged rows are real.
     struct Stage {                  // one pipeline stage in flight in registers
         f32x4 ra[KU][MI], rb[KU][NI];
+        f32x4 rb2[BF ? NI : 1];     // wide stages (bf16-stored source): the second four weights of the thread's eight
         int r_tc[KU];               // (table << 8 | first channel) of the staged float4
         bool st_ok[KU][MI];
     };
@@ -488,7 +495,7 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
         tap_ok[p] = false;
         tap_b0[p] = tap_b1[p] = 0u;
     }
-    int g_tap = -1, g_c0 = 0;                              // tap and first channel of the next unit to fetch (u = g_tap*UPT + g_c0/16)
+    int g_tap = -1, g_c0 = 0, g_w = 16;                    // tap, first channel and width of the unit fetched last
     // LEAN (one unit per stage, float4 gathers, one transform): the per-stage address work is moved to where it changes.
     // Everything that depends on the unit alone -- which source, the channel offset inside it, the weight column -- is
     // workgroup-uniform and goes into the scalar offset operand of the buffer loads (soffset is not part of the range check,
@@ -502,12 +509,12 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
     for (int p = 0; p < NI; ++p) w_off[p] = (unsigned)((n_blk + srow + 64 * p) * d.Kpad + skq * 4) * 4u;
     auto fetch = [&](int stage, Stage& rg) {
         if constexpr (LEAN) {
-            const int u = stage;                                // (callers never ask for a stage past the last unit)
-            if (u == 0) {
+            // (callers never ask for a stage past the last one; g_w = channels of the previous unit: 16, or 32 for a bf16 source)
+            if (stage == 0) {
                 g_tap = 0;
                 g_c0 = 0;
             } else {
-                g_c0 += 16;
+                g_c0 += g_w;
                 if (g_c0 >= (UPT << 4)) {
                     g_c0 = 0;
                     ++g_tap;
@@ -520,34 +527,38 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
                     const int tt = a_t[p] + dt, fi = a_f0[p] + io;
                     tap_ok[p] = a_ok[p] && tt >= 0 && tt < d.T && fi >= 0 && fi < d.Fin;
                     const unsigned pos = (unsigned)(a_tf[p] + dt * d.Fin + io);
-                    tap_b0[p] = (pos * (unsigned)d.C0 + (unsigned)(skq * 4)) * esz0;
-                    tap_b1[p] = (pos * (unsigned)d.C1 + (unsigned)(skq * 4)) * esz1;
+                    tap_b0[p] = (pos * (unsigned)d.C0 + (unsigned)(skq * (w0 ? 8 : 4))) * esz0;
+                    tap_b1[p] = (pos * (unsigned)d.C1 + (unsigned)(skq * (w1 ? 8 : 4))) * esz1;
                 }
             }
             const bool second = (d.C1 > 0) && (g_c0 >= d.C0);  // workgroup-uniform
             const int Cs = second ? d.C1 : d.C0;
             const int cu = second ? g_c0 - d.C0 : g_c0;         // first channel of the unit inside its source (uniform)
-            const bool cok = cu + skq * 4 < Cs;                 // (false only in the padded tail of a source with C % 16 != 0)
-            const bool half = BF && (second ? esz1 : esz0) == 2u;   // (uniform) this unit's source is stored as bf16
+            const bool half = second ? w1 : w0;                 // (uniform) this unit's source is stored as bf16: 32 channels
+            g_w = half ? 32 : 16;
+            const bool cok = cu + skq * (half ? 8 : 4) < Cs;    // (false only in the padded tail of a source with C % 16 != 0)
+            const int k0 = g_tap * (UPT << 4) + g_c0;           // first weight column of the unit
 #pragma unroll
             for (int p = 0; p < MI; ++p) {
                 const bool ok = tap_ok[p] && cok;
                 rg.st_ok[0][p] = ok;
                 const unsigned off = ok ? (second ? tap_b1[p] : tap_b0[p]) : CG_OOB;
-                if (half) {                                     // four bf16 of the row: already the LDS image of the unit's quarter
-                    const u32x2 v = second ? __builtin_amdgcn_raw_buffer_load_b64(rs1, off, cu * 2, 0)
-                                           : __builtin_amdgcn_raw_buffer_load_b64(rs0, off, cu * 2, 0);
-                    rg.ra[0][p] = __builtin_bit_cast(f32x4, u32x4{v[0], v[1], 0u, 0u});
-                } else {
-                    const u32x4 v = second ? __builtin_amdgcn_raw_buffer_load_b128(rs1, off, cu * 4, 0)
-                                           : __builtin_amdgcn_raw_buffer_load_b128(rs0, off, cu * 4, 0);
-                    rg.ra[0][p] = __builtin_bit_cast(f32x4, v);
-                }
+                // (bf16 source: eight bf16 of the row = the LDS image of this thread's part of the unit; soffset in bytes)
+                const u32x4 v = second ? __builtin_amdgcn_raw_buffer_load_b128(rs1, off, cu * (half ? 2 : 4), 0)
+                                       : __builtin_amdgcn_raw_buffer_load_b128(rs0, off, cu * (half ? 2 : 4), 0);
+                rg.ra[0][p] = __builtin_bit_cast(f32x4, v);
             }
             rg.r_tc[0] = ((half ? 1 : 0) << 9) | ((second ? 1 : 0) << 8) | cu;   // uniform: (stored as bf16, table, first channel)
 #pragma unroll
-            for (int p = 0; p < NI; ++p)
-                rg.rb[0][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, w_off[p], u * 64, 0));
+            for (int p = 0; p < NI; ++p) {
+                if (half) {                                     // eight weights per thread: columns k0 + 8 skq .. + 7
+                    rg.rb[0][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, w_off[p] + skq * 16, k0 * 4, 0));
+                    if constexpr (BF)
+                        rg.rb2[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, w_off[p] + skq * 16, k0 * 4 + 16, 0));
+                } else {
+                    rg.rb[0][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, w_off[p], k0 * 4, 0));
+                }
+            }
             return;
         }
 #pragma unroll
@@ -611,7 +622,9 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
         }
     };
 
+    bool wide_buf[2] = {false, false};                       // (uniform) the stage staged in LDS buffer 0 / 1 is a 32-channel one
     auto stash = [&](int buf, const Stage& rg) {
+        if (BF && LEAN) wide_buf[buf] = ((rg.r_tc[0] >> 9) & 1) != 0;
 #pragma unroll
         for (int ku = 0; ku < KU; ++ku) {
             f32x4 sh01[2], sh23[2], sl[2];
@@ -657,10 +670,11 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
                     }
                     float* arow = &sm.a[(k * 2 + buf) * Smem::ATILE + (srow + 64 * p) * LDK + ku * 16];
                     if (BF) {
-                        const u32x4 raw = __builtin_bit_cast(u32x4, v);
                         const bool half = LEAN && ((rg.r_tc[ku] >> 9) & 1);      // (uniform) bf16 in memory: stored as fetched
-                        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(arow) + skq * 8) =
-                            half ? make_uint2(raw[0], raw[1]) : make_uint2(cg_bf2(v[0], v[1]), cg_bf2(v[2], v[3]));
+                        if (half)                                                // eight channels of a 32-channel unit
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(arow) + skq * 16) = __builtin_bit_cast(u32x4, v);
+                        else
+                            *reinterpret_cast<uint2*>(reinterpret_cast<char*>(arow) + skq * 8) = make_uint2(cg_bf2(v[0], v[1]), cg_bf2(v[2], v[3]));
                     } else if (H3) {
                         // unit layout in LDS (64 B): 16 fp16 hi | 16 fp16 lo; this thread owns channels 4*skq..+3
                         unsigned h01, l01, h23, l23;
@@ -677,8 +691,14 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
             for (int p = 0; p < NI; ++p) {
                 float* brow = &sm.b[buf][(srow + 64 * p) * LDK + ku * 16];
                 if (BF) {
-                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(brow) + skq * 8) =
-                        make_uint2(cg_bf2(rg.rb[ku][p][0], rg.rb[ku][p][1]), cg_bf2(rg.rb[ku][p][2], rg.rb[ku][p][3]));
+                    if (LEAN && ((rg.r_tc[ku] >> 9) & 1)) {      // wide stage: eight weights of the thread -> 16 bytes
+                        const f32x4 r0 = rg.rb[ku][p], r1 = rg.rb2[BF ? p : 0];
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(brow) + skq * 16) =
+                            u32x4{cg_bf2(r0[0], r0[1]), cg_bf2(r0[2], r0[3]), cg_bf2(r1[0], r1[1]), cg_bf2(r1[2], r1[3])};
+                    } else {
+                        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(brow) + skq * 8) =
+                            make_uint2(cg_bf2(rg.rb[ku][p][0], rg.rb[ku][p][1]), cg_bf2(rg.rb[ku][p][2], rg.rb[ku][p][3]));
+                    }
                 } else if (H3) {   // global: [4 hi | 4 lo] per 4-channel group  ->  LDS: [16 hi | 16 lo] per unit
                     const u32x4 w = __builtin_bit_cast(u32x4, rg.rb[ku][p]);
                     *reinterpret_cast<uint2*>(reinterpret_cast<char*>(brow) + skq * 8) = make_uint2(w[0], w[1]);
@@ -714,6 +734,18 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[DUAL ? ni : 0][mi], bb[ni], acc[mi][ni], 0, 0, 0);
+            }
+            if (LEAN && wide_buf[cur]) {                        // (uniform) channels 16..31 of a 32-channel unit: bytes 32..63 of a row
+                bf16x8 ab[MI], bb[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) ab[mi] = *reinterpret_cast<const bf16x8*>(&sm.a[cur * Smem::ATILE + a_base + mi * 32 * LDK + 8]);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) bb[ni] = *reinterpret_cast<const bf16x8*>(&sm.b[cur][b_base + ni * 32 * LDK + 8]);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[mi], bb[ni], acc[mi][ni], 0, 0, 0);
             }
         } else if (H3) {
             // one v_mfma_f32_32x32x16_f16 spans a whole 16-channel unit: lane (i, h) holds k = 8h..8h+7
@@ -1326,6 +1358,7 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
         EAB_CHECK_ARG((d->src_bf16 & ~3) == 0 && d->precision == EAB_PREC_BF16 && d->korder == EAB_KORDER_TAP);
         EAB_CHECK_ARG(d->xf_mode == EAB_XF_NONE && d->fin_stats == nullptr && d->Fin > 1 && d->epi != EAB_EPI_DUALGATE);
         EAB_CHECK_ARG(d->C0 % 16 == 0 && d->C1 % 16 == 0 && (!(d->src_bf16 & 2) || d->src1));
+        EAB_CHECK_ARG((!(d->src_bf16 & 1) || d->C0 % 32 == 0) && (!(d->src_bf16 & 2) || d->C1 % 32 == 0));   // 32-channel units
     }
     const bool fin = d->fin_stats != nullptr;
     if (fin) {

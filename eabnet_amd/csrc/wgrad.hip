@@ -342,7 +342,8 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_bf_kernel(const WgBatch bt) 
     // operands STORED as bf16 (eab_wgrad_desc.bf16_mask: the bf16 training programs' convolution-output gradients and
     // normalised activations): four bf16 of a row per load, and the LDS image of a row pair is a byte permute of the two loads
     // instead of four conversions -- the same operand bits as rounding the fp32 tensor here, half the bytes
-    const bool a_half = (d.bf16_mask & 1) != 0, b_half = (d.bf16_mask & (second ? 4 : 2)) != 0;
+    // (the two sources of a concatenation are either both stored as bf16 or both fp32 -- host check -- so the flag is uniform)
+    const bool a_half = (d.bf16_mask & 1) != 0, b_half = (d.bf16_mask & 2) != 0;
     const int eszA = a_half ? 2 : 4, eszB = b_half ? 2 : 4;
     // (buffer descriptors and incremental 32-bit offsets as in wgrad_kernel; two row walkers per thread: rows 2 rp, 2 rp + 1)
     const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc(
@@ -533,6 +534,7 @@ extern "C" int eab_wgrad_batch_f32(const eab_wgrad_desc* descs, int n, int strid
         EAB_CHECK_ARG((d->bf16_mask & ~7) == 0 && d->precision == EAB_PREC_BF16 && (d->N % 4) == 0);
         EAB_CHECK_ARG(!(d->bf16_mask & 2) || (d->C0 % 16) == 0);
         EAB_CHECK_ARG(!(d->bf16_mask & 4) || (d->src1 && (d->C1 % 16) == 0 && (d->C0 % 16) == 0));
+        EAB_CHECK_ARG(d->src1 == nullptr || ((d->bf16_mask >> 1) & 1) == ((d->bf16_mask >> 2) & 1));   // both sources alike
     }
     // 32-bit byte offsets inside the kernels
     EAB_CHECK_ARG((unsigned long long)d->B * d->T * d->Fz * d->N * 4 < (1ull << 31));

@@ -911,8 +911,8 @@ class TrainLowering:
         for op in list(self.fwd) + list(self.bwd) + list(self.deferred):
             if isinstance(op, prg.ConvOp):
                 ok = conv_reads_bf16(op)
-                note(op.src0, "read" if ok else "other", op, ("conv", 1))
-                note(op.src1, "read" if ok else "other", op, ("conv", 2))
+                note(op.src0, "read" if ok and op.C0 % 32 == 0 else "other", op, ("conv", 1))      # (walked in 32-channel units)
+                note(op.src1, "read" if ok and op.C1 % 32 == 0 else "other", op, ("conv", 2))
                 for f in ("aux", "dst", "dst_acc", "stats", "glu_dump", "xf0", "xf1", "fin_stats", "f2_dst", "f2_stats"):
                     note(getattr(op, f, None), "other", op)
             elif isinstance(op, WgradOp):
@@ -930,10 +930,23 @@ class TrainLowering:
                 for v in vars(op).values():
                     if isinstance(v, Ref):
                         note(v, "other", op)
-        for k, lst in uses.items():
-            kinds = [w for w, _, _ in lst]
-            if "other" in kinds or kinds.count("write") != 1 or "read" not in kinds:
-                continue
+        chosen = {k for k, lst in uses.items()
+                  if "other" not in [w for w, _, _ in lst] and [w for w, _, _ in lst].count("write") == 1
+                  and "read" in [w for w, _, _ in lst]}
+        # the two sources of a concatenation are read by ONE launch: keep the weight-gradient kernel's operand loads uniform
+        # (both sources bf16, or both fp32) -- drop a tensor whose partner in some two-source launch does not qualify
+        while True:
+            drop = set()
+            for op in list(self.fwd) + list(self.bwd) + list(self.deferred):
+                if isinstance(op, (prg.ConvOp, WgradOp)) and op.src1 is not None:
+                    a, b = region(op.src0), region(op.src1)
+                    if (a in chosen) != (b in chosen):
+                        drop |= {a, b} & chosen
+            if not drop:
+                break
+            chosen -= drop
+        for k in sorted(chosen):
+            lst = uses[k]
             self.bf16_tensors += 1
             for what, op, arg in lst:
                 if what == "write":

@@ -1883,6 +1883,9 @@ def test_bf16_storage_changes_the_bytes_not_the_numbers(dev, monkeypatch):
     g0 = torch.cat([g.reshape(-1) for g in res["0"][1].values()]).double()
     g1 = torch.cat([g.reshape(-1) for g in res["1"][1].values()]).double()
     rel = float((g1 - g0).norm() / g0.norm())
+    per = sorted(((float((res["0"][1][k].double() - res["1"][1][k].double()).norm() / (res["0"][1][k].double().norm() + 1e-30)), k)
+                  for k in res["0"][1]), reverse=True)
+    print("bf16 storage on/off: global gradient l2-rel", rel, "worst tensors", per[:12])
     assert rel <= 1e-2, rel                                          # (the bias gradients: sums of rounded values, ~2^-9 each)
     for k in res["0"][1]:
         if not k.endswith("bias"):
