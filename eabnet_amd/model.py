@@ -1070,7 +1070,7 @@ class _HostStager:
 
     def __init__(self, device: torch.device, depth: int = 4):
         # (one slot more than the deepest Pipeline keeps in flight: a slot is refilled only when its batch has been consumed)
-        self.device, self.depth, self.k = device, depth, 0
+        self.device, self.depth, self.k = device, depth, {}
         self.slots: Dict[tuple, list] = {}
         # high priority: the copy kernel is a few dozen workgroups that must get their CU slots while other batches compute --
         # on a normal-priority stream its workgroups queue behind the convolutions' and every pipeline slot waits for its upload
@@ -1085,12 +1085,15 @@ class _HostStager:
             if len(self.slots) > 8:
                 torch.cuda.synchronize(self.device)
                 self.slots.clear()
+                self.k.clear()
             ring = self.slots[key] = [dict(pin=torch.empty(key, dtype=torch.float32).pin_memory(),
                                            dev=torch.empty(key, dtype=torch.float32, device=self.device),
                                            copied=torch.cuda.Event(), consumed=torch.cuda.Event(), used=False)
                                       for _ in range(self.depth)]
-        self.k += 1
-        slot = ring[self.k % self.depth]
+        # (one counter per ring: x and target of a step use different rings -- a shared counter walked each of them with a
+        # stride of two, i.e. gave a pipeline of three batches TWO slots per ring and made submit() wait for the GPU)
+        self.k[key] = self.k.get(key, 0) + 1
+        slot = ring[self.k[key] % self.depth]
         if slot["used"]:
             slot["copied"].synchronize()                 # the pinned buffer is free again (depth steps ago)
             self.stream.wait_event(slot["consumed"])     # the device buffer's readers were enqueued before this

@@ -1883,14 +1883,17 @@ def test_bf16_storage_changes_the_bytes_not_the_numbers(dev, monkeypatch):
     g0 = torch.cat([g.reshape(-1) for g in res["0"][1].values()]).double()
     g1 = torch.cat([g.reshape(-1) for g in res["1"][1].values()]).double()
     rel = float((g1 - g0).norm() / g0.norm())
-    per = sorted(((float((res["0"][1][k].double() - res["1"][1][k].double()).norm() / (res["0"][1][k].double().norm() + 1e-30)), k)
-                  for k in res["0"][1]), reverse=True)
-    print("bf16 storage on/off: global gradient l2-rel", rel, "worst tensors", per[:12])
-    assert rel <= 1e-2, rel                                          # (the bias gradients: sums of rounded values, ~2^-9 each)
-    for k in res["0"][1]:
-        if not k.endswith("bias"):
-            a, b = res["0"][1][k].double(), res["1"][1][k].double()
-            assert float((a - b).norm()) <= 1e-4 * float(a.norm()) + 1e-9, k      # weights: same products, atomics order only
+    # (a bias in front of an InstanceNorm has a zero gradient -- the norm removes the mean -- so its two evaluations are
+    # unrelated rounding noise: tensors below 1e-4 of the largest one are left out of the per-tensor comparison)
+    gmax = max(float(g.double().norm()) for g in res["0"][1].values())
+    per = sorted(((float((res["0"][1][k].double() - res["1"][1][k].double()).norm() / float(res["0"][1][k].double().norm())), k)
+                  for k in res["0"][1] if float(res["0"][1][k].double().norm()) > 1e-4 * gmax), reverse=True)
+    print("bf16 storage on/off: global gradient l2-rel", rel, "worst tensors", per[:8])
+    assert rel <= 1e-2, rel
+    for r, k in per:
+        # weights: the same products, only the order of the fp32 atomics differs; biases of gated / head convolutions: column
+        # sums of the stored (rounded) gradient instead of the unrounded one
+        assert r <= (2e-2 if k.endswith("bias") else 1e-4), (k, r)
 
 
 def test_config4_ddp_training_on_the_hip_programs(dev):

@@ -274,3 +274,103 @@ def test_lstm_training_forward_and_reverse_time_kernel(lib, B, T, Fq):
     for name, src, dt, want in (("ih", xd, 0, lstm.weight_ih_l0.grad), ("hh", hd, -1, lstm.weight_hh_l0.grad)):
         got = _wgrad(lib, dg, src, None, 256, 64, B, T, Fq, Fq, Fq, 1, 0, 1, [dt], [0])
         assert_close(got.numpy(), want.numpy(), TOL, f"wgrad {name}")
+
+
+# ---------------------------------------------------------------------------------------------------
+# bf16-STORED operands (round 4): the bf16 training programs store the tensors only bf16 contractions read as bf16
+# (eab_conv_desc.src_bf16, eab_wgrad_desc.bf16_mask, EAB_STORE_BF16).  The contraction kernels round fp32 operands to bf16
+# on their way into LDS, so feeding them the already-rounded tensor must give the same numbers.
+# ---------------------------------------------------------------------------------------------------
+def _wgrad_masked(lib, dz, src0, src1, N, Kpad, B, T, Fin, Fz, No, ostride, ophase, istride, dt, ioff, mask, C0, C1, dbias=None):
+    from eabnet_amd import _lib
+    d = _lib.WgradDesc()
+    dw = torch.zeros(N, Kpad, device="cuda:0")
+    d.dz, d.src0, d.src1, d.dw = dz.data_ptr(), src0.data_ptr(), (src1.data_ptr() if src1 is not None else None), dw.data_ptr()
+    d.dbias = dbias.data_ptr() if dbias is not None else None
+    d.N, d.C0, d.C1, d.Kpad = N, C0, C1, Kpad
+    d.B, d.T, d.Fin, d.Fz, d.No, d.ostride, d.ophase, d.istride = B, T, Fin, Fz, No, ostride, ophase, istride
+    d.ntaps = len(dt)
+    d.precision = 2
+    d.bf16_mask = mask
+    for j in range(len(dt)):
+        d.dt[j], d.ioff[j] = dt[j], ioff[j]
+    _ck(lib.eab_wgrad_f32(C.byref(d), _st()), "eab_wgrad_f32")
+    torch.cuda.synchronize()
+    return dw.cpu()
+
+
+@pytest.mark.parametrize("N,C0,C1,taps,B,T,Fin,No,ostride,istride", [
+    (64, 64, 0, [(0, 0), (0, 1), (0, 2)], 2, 9, 39, 19, 1, 2),            # Conv2dunit (1,3) / stride 2
+    (128, 64, 0, [(-1, 0), (-1, 1), (-1, 2), (0, 0), (0, 1), (0, 2)], 2, 7, 19, 9, 1, 2),   # GateConv2d (2,3)
+    (64, 64, 64, [(0, 0), (0, -1)], 2, 6, 19, 20, 2, 1),                  # Deconv2dunit phase 0 on a concatenation
+    (128, 16, 0, [(0, 0), (0, 1), (0, 2), (0, 3), (0, 4)], 1, 5, 161, 79, 1, 2),   # first convolution: fp32 input, bf16 dz only
+])
+def test_wgrad_with_bf16_stored_operands(lib, N, C0, C1, taps, B, T, Fin, No, ostride, istride):
+    g = torch.Generator().manual_seed(7)
+    Fz = (No - 1) * ostride + 1 + (1 if ostride == 2 else 0)
+    dz = torch.randn(B, T, Fz, N, generator=g)
+    x0 = torch.randn(B, T, Fin, C0, generator=g)
+    x1 = torch.randn(B, T, Fin, C1, generator=g) if C1 else None
+    upt = (C0 + C1 + 15) // 16
+    Kpad = len(taps) * upt * 16
+    dt, io = [a for a, _ in taps], [c for _, c in taps]
+    full = (C0 % 16 == 0)
+    db32, db16 = torch.zeros(N, device="cuda:0"), torch.zeros(N, device="cuda:0")
+    ref = _wgrad_masked(lib, _dev(dz), _dev(x0), _dev(x1) if C1 else None, N, Kpad, B, T, Fin, Fz, No, ostride, 0, istride, dt, io, 0,
+                        C0, C1, dbias=db32)
+    h = lambda t: t.to("cuda:0").bfloat16().contiguous()        # noqa: E731 (round to nearest even, 2-byte elements)
+    mask = 1 | ((2 | (4 if C1 else 0)) if full else 0)
+    got = _wgrad_masked(lib, h(dz), h(x0) if full else _dev(x0), (h(x1) if full else _dev(x1)) if C1 else None, N, Kpad, B, T, Fin, Fz, No,
+                        ostride, 0, istride, dt, io, mask, C0, C1, dbias=db16)
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-5 * scale, "same operand bits: only the order of the fp32 atomics may differ"
+    want_db = dz.bfloat16().float().sum((0, 1, 2))
+    rows = torch.zeros(B, T, Fz, dtype=torch.bool)
+    rows[:, :, 0:(No - 1) * ostride + 1:ostride] = True
+    want_db = (dz.bfloat16().float() * rows[..., None]).sum((0, 1, 2))
+    assert_close(db16.cpu().numpy(), want_db.numpy(), 1e-4, "dbias from the stored (bf16) gradient")
+
+
+def _conv_plain(lib, src0, src1, w, N, C0, C1, B, T, Fin, Fout, No, ostride, ophase, istride, dt, ioff, src_bf16, bm=128):
+    from eabnet_amd import _lib
+    d = _lib.ConvDesc()
+    out = torch.full((B, T, Fout, N), float("nan"), device="cuda:0")
+    d.src0, d.src1, d.w, d.dst = src0.data_ptr(), (src1.data_ptr() if src1 is not None else None), w.data_ptr(), out.data_ptr()
+    d.C0, d.C1, d.N, d.Kpad, d.Cout = C0, C1, N, w.shape[1], N
+    d.B, d.T, d.Fin, d.Fout, d.No, d.ostride, d.ophase, d.istride = B, T, Fin, Fout, No, ostride, ophase, istride
+    d.ntaps = len(dt)
+    for j in range(len(dt)):
+        d.dt[j], d.ioff[j] = dt[j], ioff[j]
+    d.epi, d.bm, d.precision, d.korder, d.src_bf16 = 0, bm, 2, 0, src_bf16
+    _ck(lib.eab_conv_f32(C.byref(d), _st()), "eab_conv_f32")
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+@pytest.mark.parametrize("N,C0,C1,taps,B,T,Fin,No,ostride,istride,bm", [
+    (64, 64, 0, [(0, 0), (0, 1), (0, 2)], 2, 40, 39, 19, 1, 2, 128),      # unit convolution, 128-row tiles (two register sets)
+    (64, 64, 64, [(0, 0), (0, -1)], 2, 17, 19, 20, 2, 1, 64),             # transposed unit, phase 0, two sources, 64-row tiles
+    (128, 128, 0, [(1, 0), (1, -1), (0, 0), (0, -1)], 1, 21, 9, 10, 2, 1, 64),   # a dgrad-like launch with look-ahead taps
+    (64, 128, 0, [(0, 0)], 2, 12, 79, 79, 1, 1, 128),                     # 1x1
+])
+def test_conv_with_bf16_stored_sources_is_bit_identical(lib, N, C0, C1, taps, B, T, Fin, No, ostride, istride, bm):
+    """EAB_PREC_BF16 gather on sources STORED as bf16 (walked in 32-channel units) == the same launch on the fp32 tensors holding
+    the same (already rounded) values: same operand bits, same k order -> identical fp32 results."""
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(B, T, Fin, C0, generator=g).bfloat16()
+    x1 = torch.randn(B, T, Fin, C1, generator=g).bfloat16() if C1 else None
+    upt = (C0 + C1 + 15) // 16
+    w = torch.randn(N, len(taps) * upt * 16, generator=g).to("cuda:0")
+    Fout = (No - 1) * ostride + 1
+    dt, io = [a for a, _ in taps], [c for _, c in taps]
+    a32 = _conv_plain(lib, x0.float().to("cuda:0").contiguous(), x1.float().to("cuda:0").contiguous() if C1 else None, w, N, C0, C1, B, T,
+                      Fin, Fout, No, ostride, 0, istride, dt, io, 0, bm)
+    a16 = _conv_plain(lib, x0.to("cuda:0").contiguous(), x1.to("cuda:0").contiguous() if C1 else None, w, N, C0, C1, B, T, Fin, Fout, No,
+                      ostride, 0, istride, dt, io, 1 | (2 if C1 else 0), bm)
+    written = torch.isfinite(a32)
+    assert written.any() and torch.equal(torch.isfinite(a16), written)
+    assert torch.equal(a16[written], a32[written])
+    if C1:   # mixed: only the first source stored as bf16
+        mix = _conv_plain(lib, x0.to("cuda:0").contiguous(), x1.float().to("cuda:0").contiguous(), w, N, C0, C1, B, T, Fin, Fout, No,
+                          ostride, 0, istride, dt, io, 1, bm)
+        assert torch.equal(mix[written], a32[written])
