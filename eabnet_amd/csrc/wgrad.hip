@@ -16,19 +16,6 @@
 #include <math.h>
 
 #define WG_THREADS 256
-
-typedef unsigned int wg_u32x4_t __attribute__((ext_vector_type(4)));
-typedef unsigned int wg_u32x2_t __attribute__((ext_vector_type(2)));
-
-// Buffer descriptor from workgroup-uniform inputs, made PROVABLY uniform for the compiler: the member's pointers come out of
-// arrays in the kernel arguments indexed by blockIdx (a vector-unit quotient), and without this every buffer load of the main
-// loop sat in a waterfall loop (4 v_readfirstlane + compare + saveexec + branch per load: 86 readfirstlanes in the bf16 kernel).
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const void* p, unsigned long long bytes) {
-    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    const unsigned nb = __builtin_amdgcn_readfirstlane((unsigned)bytes);
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo), 0, nb, 0x00020000);
-}
 #define WG_ROWS 16           // rows per pipeline stage
 
 template <int TN, int TC>
@@ -150,9 +137,12 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgBatch bt) {
     // incrementally: a stage moves every row walker by WG_ROWS rows = (adv_a, adv_r) in (t, o) plus one conditional wrap, and
     // a row's offset is affine in (b*T + t, o) -- no multiplies, no 64-bit address arithmetic, no branches around the loads
     // (an invalid row or tap gets an out-of-range offset and reads 0).
-    const __amdgpu_buffer_rsrc_t rs_dz = wg_rsrc(m_dz, (size_t)d.B * d.T * d.Fz * d.N * 4);
-    const __amdgpu_buffer_rsrc_t rs_s0 = wg_rsrc(m_src0, (size_t)d.B * d.T * d.Fin * d.C0 * 4);
-    const __amdgpu_buffer_rsrc_t rs_s1 = wg_rsrc(m_src1 ? m_src1 : m_src0, m_src1 ? (size_t)d.B * d.T * d.Fin * d.C1 * 4 : 0);
+    const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(m_dz), 0, (unsigned)((size_t)d.B * d.T * d.Fz * d.N * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_s0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(m_src0), 0, (unsigned)((size_t)d.B * d.T * d.Fin * d.C0 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_s1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(m_src1 ? m_src1 : m_src0), 0, m_src1 ? (unsigned)((size_t)d.B * d.T * d.Fin * d.C1 * 4) : 0u, 0x00020000);
     constexpr unsigned WG_OOB = 0x80000000u;
     WgRow ra_[AP], rb_;
     unsigned offA[AP];
@@ -195,14 +185,8 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgBatch bt) {
             const bool ok = rok && b_ok[j] && tt >= 0 && tt < d.T && fi >= 0 && fi < d.Fin;
             const unsigned off = ok ? (unsigned)offB[j] : WG_OOB;
             if (vec_ok) {
-                // (a thread's column block belongs to one source, a wave's to both: one load per source through its uniform
-                // descriptor, the other source's lanes parked out of range -- no waterfall over per-lane descriptors)
-                wg_u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_s0, b_second[j] ? WG_OOB : off, 0, 0);
-                if (d.C1 > 0) {
-                    const wg_u32x4_t v1 = __builtin_amdgcn_raw_buffer_load_b128(rs_s1, b_second[j] ? off : WG_OOB, 0, 0);
-                    v = b_second[j] ? v1 : v;
-                }
-                rb[j] = __builtin_bit_cast(f32x4, v);
+                rb[j] = __builtin_bit_cast(f32x4, b_second[j] ? __builtin_amdgcn_raw_buffer_load_b128(rs_s1, off, 0, 0)
+                                                              : __builtin_amdgcn_raw_buffer_load_b128(rs_s0, off, 0, 0));
             } else {                // channel count not a multiple of 4 (2M = 18 network inputs): dword loads, row tail guarded
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -362,10 +346,10 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_bf_kernel(const WgBatch bt) 
     const bool a_half = (d.bf16_mask & 1) != 0, b_half = (d.bf16_mask & 2) != 0;
     const int eszA = a_half ? 2 : 4, eszB = b_half ? 2 : 4;
     // (buffer descriptors and incremental 32-bit offsets as in wgrad_kernel; two row walkers per thread: rows 2 rp, 2 rp + 1)
-    const __amdgpu_buffer_rsrc_t rs_dz = wg_rsrc(m_dz, (size_t)d.B * d.T * d.Fz * d.N * eszA);
-    const __amdgpu_buffer_rsrc_t rs_s0 = wg_rsrc(m_src0, (size_t)d.B * d.T * d.Fin * d.C0 * eszB);
-    const __amdgpu_buffer_rsrc_t rs_s1 = wg_rsrc(m_src1 ? m_src1 : m_src0, m_src1 ? (size_t)d.B * d.T * d.Fin * d.C1 * eszB : 0);
-    const bool two = d.C1 > 0;                                    // (uniform) a concatenation: one load per source, see wgrad_kernel
+    const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(m_dz), 0, (unsigned)((size_t)d.B * d.T * d.Fz * d.N * eszA), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(b_src), 0, (unsigned)((size_t)d.B * d.T * d.Fin * b_Cs * eszB), 0x00020000);
     constexpr unsigned WG_OOB = 0x80000000u;
     WgRow rw[2];
     unsigned offA[2];
@@ -396,25 +380,16 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_bf_kernel(const WgBatch bt) 
             const int tt = rw[e].t + tdt, fi = rw[e].o * d.istride + tio;
             const bool ok = rok && b_ok && tt >= 0 && tt < d.T && fi >= 0 && fi < d.Fin;
             const unsigned off = ok ? (unsigned)offB[e] : WG_OOB;
-            if (b_half) {                                         // (uniform; C % 16 == 0: host check)
-                wg_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_s0, second ? WG_OOB : off, 0, 0);
-                if (two) {
-                    const wg_u32x2 v1 = __builtin_amdgcn_raw_buffer_load_b64(rs_s1, second ? off : WG_OOB, 0, 0);
-                    v = second ? v1 : v;
-                }
+            if (b_half) {                                         // (uniform per thread's column block; C % 16 == 0: host check)
+                const wg_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_src, off, 0, 0);
                 rb[e] = __builtin_bit_cast(f32x4, wg_u32x4{v[0], v[1], 0u, 0u});
             } else if (vec_ok) {
-                wg_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_s0, second ? WG_OOB : off, 0, 0);
-                if (two) {
-                    const wg_u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs_s1, second ? off : WG_OOB, 0, 0);
-                    v = second ? v1 : v;
-                }
-                rb[e] = __builtin_bit_cast(f32x4, v);
+                rb[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0));
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     rb[e][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                             rs_s0, (ok && b_cc + q < b_Cs) ? off + 4u * q : WG_OOB, 0, 0));
+                                                             rs_src, (ok && b_cc + q < b_Cs) ? off + 4u * q : WG_OOB, 0, 0));
             }
             const bool wrap = rw[e].step(adv_a, adv_r, d.T, d.No);
             offA[e] += dA0 + (wrap ? dA1 : 0u);

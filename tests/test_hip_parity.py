@@ -1869,7 +1869,7 @@ def test_bf16_storage_changes_the_bytes_not_the_numbers(dev, monkeypatch):
     x = torch.from_numpy(paramgen.make_spec_input(2, 40, 161, 4, 1101)).to(dev)
     label = torch.from_numpy(paramgen.make_spec_input(2, 40, 161, 1, 1102)[..., 0, :]).permute(0, 3, 1, 2).contiguous().to(dev)
     res = {}
-    for store in ("0", "1"):
+    for run, store in (("0", "0"), ("0b", "0"), ("1", "1")):          # "0b": the fp32-stored program again = the run-to-run floor
         monkeypatch.setenv("EAB_BF16_STORE", store)
         net = _model(4, 1100, dev, p=2, q=1).train()
         net.precision = "bf16"
@@ -1878,22 +1878,26 @@ def test_bf16_storage_changes_the_bytes_not_the_numbers(dev, monkeypatch):
         bound = next(iter(net._train_bound.values()))
         n_bf = sum(1 for op in bound.prog.fwd + bound.prog.bwd if getattr(op, "src_bf16", 0) or getattr(op, "bf16_mask", 0))
         assert (n_bf > 50) == (store == "1"), n_bf
-        res[store] = (y.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+        res[run] = (y.detach().clone(), {k: p.grad.detach().double().clone() for k, p in net.named_parameters()})
     assert torch.equal(res["0"][0], res["1"][0]), "forward output must not change"
-    g0 = torch.cat([g.reshape(-1) for g in res["0"][1].values()]).double()
-    g1 = torch.cat([g.reshape(-1) for g in res["1"][1].values()]).double()
-    rel = float((g1 - g0).norm() / g0.norm())
-    # (a bias in front of an InstanceNorm has a zero gradient -- the norm removes the mean -- so its two evaluations are
-    # unrelated rounding noise: tensors below 1e-4 of the largest one are left out of the per-tensor comparison)
-    gmax = max(float(g.double().norm()) for g in res["0"][1].values())
-    per = sorted(((float((res["0"][1][k].double() - res["1"][1][k].double()).norm() / float(res["0"][1][k].double().norm())), k)
-                  for k in res["0"][1] if float(res["0"][1][k].double().norm()) > 1e-4 * gmax), reverse=True)
-    print("bf16 storage on/off: global gradient l2-rel", rel, "worst tensors", per[:8])
-    assert rel <= 1e-2, rel
-    for r, k in per:
-        # weights: the same products, only the order of the fp32 atomics differs; biases of gated / head convolutions: column
-        # sums of the stored (rounded) gradient instead of the unrounded one
-        assert r <= (2e-2 if k.endswith("bias") else 1e-4), (k, r)
+
+    def diffs(a, b):
+        gmax = max(float(g.norm()) for g in a.values())
+        glob = float(torch.cat([(a[k] - b[k]).reshape(-1) for k in a]).norm() / torch.cat([g.reshape(-1) for g in a.values()]).norm())
+        per = {k: float((a[k] - b[k]).norm() / a[k].norm()) for k in a if float(a[k].norm()) > 1e-4 * gmax}
+        return glob, per
+    floor_g, floor = diffs(res["0"][1], res["0b"][1])
+    got_g, got = diffs(res["0"][1], res["1"][1])
+    worst = sorted(((got[k], floor[k], k) for k in got), reverse=True)[:8]
+    print(f"bf16 storage on/off: global gradient l2-rel {got_g:.2e} (run-to-run floor of the fp32-stored program {floor_g:.2e}); "
+          f"worst tensors (diff, floor, name): {worst}")
+    # (a bias in front of an InstanceNorm has a zero gradient -- the norm removes the mean -- so its evaluations are unrelated
+    # rounding noise: tensors below 1e-4 of the largest one are left out.)  Weights: the same products, only the order of the
+    # fp32 atomics differs -> within a few times the program's own run-to-run floor; biases of gated / head convolutions are
+    # column sums of the stored (rounded) gradient instead of the unrounded one
+    assert got_g <= max(5.0 * floor_g, 5e-3), (got_g, floor_g)
+    for k, r in got.items():
+        assert r <= (2e-2 if k.endswith("bias") else max(5.0 * floor[k], 1e-4)), (k, r, floor[k])
 
 
 def test_config4_ddp_training_on_the_hip_programs(dev):
