@@ -295,7 +295,8 @@ __device__ __forceinline__ unsigned wg_bf2(float x0, float x1) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-template <int TN, int TC>
+// HALF (compile time, so that the operand loads of a stage stay one straight-line burst): bit 0 = dz, bit 1 = x stored as bf16
+template <int TN, int TC, int HALF>
 __global__ __launch_bounds__(WG_THREADS) void wgrad_bf_kernel(const WgBatch bt) {
     constexpr int MI = TN / 64, NJ = TC / 64;
     __shared__ unsigned a_t[2][TN * WGB_S];
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_bf_kernel(const WgBatch bt) 
     // normalised activations): four bf16 of a row per load, and the LDS image of a row pair is a byte permute of the two loads
     // instead of four conversions -- the same operand bits as rounding the fp32 tensor here, half the bytes
     // (the two sources of a concatenation are either both stored as bf16 or both fp32 -- host check -- so the flag is uniform)
-    const bool a_half = (d.bf16_mask & 1) != 0, b_half = (d.bf16_mask & 2) != 0;
+    constexpr bool a_half = (HALF & 1) != 0, b_half = (HALF & 2) != 0;
     const int eszA = a_half ? 2 : 4, eszB = b_half ? 2 : 4;
     // (buffer descriptors and incremental 32-bit offsets as in wgrad_kernel; two row walkers per thread: rows 2 rp, 2 rp + 1)
     const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc(
@@ -584,10 +585,19 @@ extern "C" int eab_wgrad_batch_f32(const eab_wgrad_desc* descs, int n, int strid
     dim3 grid((unsigned)(bt.groups * n), (unsigned)cb, (unsigned)nb);
     hipStream_t s = eab_stream(stream);
     if (d->precision == EAB_PREC_BF16) {
-        if (tn == 128 && tc == 128) hipLaunchKernelGGL((wgrad_bf_kernel<128, 128>), grid, dim3(WG_THREADS), 0, s, bt);
-        else if (tn == 128) hipLaunchKernelGGL((wgrad_bf_kernel<128, 64>), grid, dim3(WG_THREADS), 0, s, bt);
-        else if (tc == 128) hipLaunchKernelGGL((wgrad_bf_kernel<64, 128>), grid, dim3(WG_THREADS), 0, s, bt);
-        else hipLaunchKernelGGL((wgrad_bf_kernel<64, 64>), grid, dim3(WG_THREADS), 0, s, bt);
+        const int half = d->bf16_mask & 3;       // (both sources of a concatenation alike: checked above)
+#define WG_BF_LAUNCH(TN_, TC_)                                                                                              \
+    do {                                                                                                                    \
+        if (half == 0) hipLaunchKernelGGL((wgrad_bf_kernel<TN_, TC_, 0>), grid, dim3(WG_THREADS), 0, s, bt);               \
+        else if (half == 1) hipLaunchKernelGGL((wgrad_bf_kernel<TN_, TC_, 1>), grid, dim3(WG_THREADS), 0, s, bt);          \
+        else if (half == 2) hipLaunchKernelGGL((wgrad_bf_kernel<TN_, TC_, 2>), grid, dim3(WG_THREADS), 0, s, bt);          \
+        else hipLaunchKernelGGL((wgrad_bf_kernel<TN_, TC_, 3>), grid, dim3(WG_THREADS), 0, s, bt);                         \
+    } while (0)
+        if (tn == 128 && tc == 128) WG_BF_LAUNCH(128, 128);
+        else if (tn == 128) WG_BF_LAUNCH(128, 64);
+        else if (tc == 128) WG_BF_LAUNCH(64, 128);
+        else WG_BF_LAUNCH(64, 64);
+#undef WG_BF_LAUNCH
         EAB_RETURN_LAUNCH_STATUS();
     }
     if (tn == 128 && tc == 128) hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(WG_THREADS), 0, s, bt);
