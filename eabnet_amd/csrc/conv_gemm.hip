@@ -119,7 +119,10 @@ __device__ __forceinline__ void cg_split2(float x0, float x1, unsigned& hi, unsi
     lo = __builtin_bit_cast(unsigned, l);
 }
 
-template <int MI, int NI, int KU, int MODE, int XF, bool VEC, int PREC, bool PATCH>
+// WIDE (bf16 products, gather pipeline, one unit per stage, no fused transform): every source is STORED as bf16 and walked in
+// 32-channel units -- a compile-time property of the launch, so that the loads of a stage stay one straight-line burst (a
+// run-time flag around them measured slower: the weight-gradient kernel lost 30 % to exactly that)
+template <int MI, int NI, int KU, int MODE, int XF, bool VEC, int PREC, bool PATCH, bool WIDE = false>
 __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE == CG_GLU) ? 3 : (MODE == CG_PH2 ? 2 : 1)) void conv_gemm_kernel(const eab_conv_desc d) {
     // (workgroups per CU the register budget is cut for: three for the gated 128x128 tiles -- 168 registers, no spills --, two
     // for the phase-pair form, whose fused transform and second store stream do not fit 168)
@@ -216,7 +219,8 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
     // load is eight channels, the four threads of a row cover 64 bytes -- a whole sector, where four-channel loads of a bf16
     // tensor leave half of every 64-byte segment unused -- and a stage carries two MFMA k-steps instead of one: half the
     // stages, half the barriers.  The k order (and so every bit of the result) is that of the 16-channel walk.
-    const bool w0 = BF && (d.src_bf16 & 1), w1 = BF && (d.src_bf16 & 2);
+    static_assert(!WIDE || (PREC == EAB_PREC_BF16 && KU == 1 && VEC && !PATCH && XF == EAB_XF_NONE && MODE != CG_DUAL), "WIDE: see above");
+    constexpr bool w0 = WIDE, w1 = WIDE;
     const int NS = (w0 || w1) ? d.ntaps * ((w0 ? d.C0 >> 5 : (d.C0 + 15) >> 4) + (d.C1 > 0 ? (w1 ? d.C1 >> 5 : (d.C1 + 15) >> 4) : 0))
                               : (NU + KU - 1) / KU;              // pipeline stages
 
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
     // (src_bf16, bf16 products only: a source stored as bf16 [B][T][Fin][C] -- the training programs' normalised activations and
     // convolution-output gradients, which this precision rounds to bf16 on their way into LDS anyway: same operands, half the
     // bytes, no conversion.  esz = bytes per element of the source.)
-    const unsigned esz0 = (BF && (d.src_bf16 & 1)) ? 2u : 4u, esz1 = (BF && (d.src_bf16 & 2)) ? 2u : 4u;
+    constexpr unsigned esz0 = WIDE ? 2u : 4u, esz1 = WIDE ? 2u : 4u;
     const unsigned bytes0 = (unsigned)d.T * d.Fin * d.C0 * esz0;
     const unsigned bytes1 = (unsigned)d.T * d.Fin * d.C1 * esz1;
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
@@ -534,7 +538,7 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
             const bool second = (d.C1 > 0) && (g_c0 >= d.C0);  // workgroup-uniform
             const int Cs = second ? d.C1 : d.C0;
             const int cu = second ? g_c0 - d.C0 : g_c0;         // first channel of the unit inside its source (uniform)
-            const bool half = second ? w1 : w0;                 // (uniform) this unit's source is stored as bf16: 32 channels
+            constexpr bool half = WIDE;                         // the sources are stored as bf16: 32-channel units
             g_w = half ? 32 : 16;
             const bool cok = cu + skq * (half ? 8 : 4) < Cs;    // (false only in the padded tail of a source with C % 16 != 0)
             const int k0 = g_tap * (UPT << 4) + g_c0;           // first weight column of the unit
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
             rg.r_tc[0] = ((half ? 1 : 0) << 9) | ((second ? 1 : 0) << 8) | cu;   // uniform: (stored as bf16, table, first channel)
 #pragma unroll
             for (int p = 0; p < NI; ++p) {
-                if (half) {                                     // eight weights per thread: columns k0 + 8 skq .. + 7
+                if constexpr (WIDE) {                           // eight weights per thread: columns k0 + 8 skq .. + 7
                     rg.rb[0][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, w_off[p] + skq * 16, k0 * 4, 0));
                     if constexpr (BF)
                         rg.rb2[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, w_off[p] + skq * 16, k0 * 4 + 16, 0));
@@ -622,9 +626,7 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
         }
     };
 
-    bool wide_buf[2] = {false, false};                       // (uniform) the stage staged in LDS buffer 0 / 1 is a 32-channel one
     auto stash = [&](int buf, const Stage& rg) {
-        if (BF && LEAN) wide_buf[buf] = ((rg.r_tc[0] >> 9) & 1) != 0;
 #pragma unroll
         for (int ku = 0; ku < KU; ++ku) {
             f32x4 sh01[2], sh23[2], sl[2];
@@ -670,7 +672,7 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
                     }
                     float* arow = &sm.a[(k * 2 + buf) * Smem::ATILE + (srow + 64 * p) * LDK + ku * 16];
                     if (BF) {
-                        const bool half = LEAN && ((rg.r_tc[ku] >> 9) & 1);      // (uniform) bf16 in memory: stored as fetched
+                        constexpr bool half = WIDE;                              // bf16 in memory: stored as fetched
                         if (half)                                                // eight channels of a 32-channel unit
                             *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(arow) + skq * 16) = __builtin_bit_cast(u32x4, v);
                         else
@@ -691,7 +693,7 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
             for (int p = 0; p < NI; ++p) {
                 float* brow = &sm.b[buf][(srow + 64 * p) * LDK + ku * 16];
                 if (BF) {
-                    if (LEAN && ((rg.r_tc[ku] >> 9) & 1)) {      // wide stage: eight weights of the thread -> 16 bytes
+                    if constexpr (WIDE) {                        // wide stage: eight weights of the thread -> 16 bytes
                         const f32x4 r0 = rg.rb[ku][p], r1 = rg.rb2[BF ? p : 0];
                         *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(brow) + skq * 16) =
                             u32x4{cg_bf2(r0[0], r0[1]), cg_bf2(r0[2], r0[3]), cg_bf2(r1[0], r1[1]), cg_bf2(r1[2], r1[3])};
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(CG_THREADS, (MI == 2 && NI == 2 && KU == 1 && MODE 
                     for (int ni = 0; ni < NI; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[DUAL ? ni : 0][mi], bb[ni], acc[mi][ni], 0, 0, 0);
             }
-            if (LEAN && wide_buf[cur]) {                        // (uniform) channels 16..31 of a 32-channel unit: bytes 32..63 of a row
+            if constexpr (WIDE) {                               // channels 16..31 of a 32-channel unit: bytes 32..63 of a row
                 bf16x8 ab[MI], bb[NI];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) ab[mi] = *reinterpret_cast<const bf16x8*>(&sm.a[cur * Smem::ATILE + a_base + mi * 32 * LDK + 8]);
@@ -1262,11 +1264,20 @@ static int cg_launch(const eab_conv_desc* d, hipStream_t s) {
         else
             return EAB_EUNSUPPORTED;
     } else if (d->precision == EAB_PREC_BF16) {
-        if constexpr (VEC)
-            hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, KU, MODE, XF, VEC, EAB_PREC_BF16, false>), grid,
-                               dim3(CG_THREADS), 0, s, *d);
-        else
+        if constexpr (VEC) {
+            if (d->src_bf16) {                   // every source stored as bf16 (host check): the 32-channel walk
+                if constexpr (KU == 1 && XF == EAB_XF_NONE && MODE != CG_DUAL)
+                    hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, KU, MODE, XF, VEC, EAB_PREC_BF16, false, true>), grid,
+                                       dim3(CG_THREADS), 0, s, *d);
+                else
+                    return EAB_EUNSUPPORTED;
+            } else {
+                hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, KU, MODE, XF, VEC, EAB_PREC_BF16, false>), grid,
+                                   dim3(CG_THREADS), 0, s, *d);
+            }
+        } else {
             return EAB_EUNSUPPORTED;
+        }
     } else {
         hipLaunchKernelGGL((conv_gemm_kernel<MI, NI, KU, MODE, XF, VEC, EAB_PREC_F32, false>), grid, dim3(CG_THREADS), 0,
                            s, *d);
@@ -1359,6 +1370,7 @@ extern "C" int eab_conv_f32(const eab_conv_desc* d, eab_stream_t stream) {
         EAB_CHECK_ARG(d->xf_mode == EAB_XF_NONE && d->fin_stats == nullptr && d->Fin > 1 && d->epi != EAB_EPI_DUALGATE);
         EAB_CHECK_ARG(d->C0 % 16 == 0 && d->C1 % 16 == 0 && (!(d->src_bf16 & 2) || d->src1));
         EAB_CHECK_ARG((!(d->src_bf16 & 1) || d->C0 % 32 == 0) && (!(d->src_bf16 & 2) || d->C1 % 32 == 0));   // 32-channel units
+        EAB_CHECK_ARG(d->src_bf16 == (d->src1 ? 3 : 1));                  // all sources of a launch alike
     }
     const bool fin = d->fin_stats != nullptr;
     if (fin) {
