@@ -589,6 +589,16 @@ def main():
                 """exact MACs*2 of a conv launch: taps that fall on zero padding are not counted"""
                 tot = 0
                 oo = np.arange(o.No)
+                if o.epi == prg.EPI_PHASE2:
+                    # both output-column phases of a transposed convolution in one launch: the phase-0 columns (N / 2) take
+                    # every tap, the phase-1 columns only the taps of p2_mask1 and only where the output column 2o+1 exists
+                    for j, (dt, io) in enumerate(zip(o.dt, o.ioff)):
+                        fi = oo * o.istride + io
+                        ok = (fi >= 0) & (fi < o.Fin)
+                        tot += max(o.T + dt, 0) * int(ok.sum())
+                        if (o.p2_mask1 >> j) & 1:
+                            tot += max(o.T + dt, 0) * int((ok & (2 * oo + 1 < o.Fout)).sum())
+                    return 2.0 * o.B * tot * (o.N // 2) * (o.C0 + o.C1)
                 for dt, io in zip(o.dt, o.ioff):
                     fi = oo * o.istride + io
                     tot += max(o.T + dt, 0) * int(((fi >= 0) & (fi < o.Fin)).sum())
@@ -636,10 +646,10 @@ def main():
             # half of a wide coalesced read stream on gfx950.
             traffic = None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_final", "pmc_summary.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_final", "pmc_summary.json")))
                 if pmc.get("_meta", {}).get("kernel_source_sha16") != kernel_source_sha():
                     raise LookupError("the committed PMC summary was taken on other kernel sources")
-                tag = "conv_gemm_kernel<2, 2, 1, 1, 0, true, %d, true>" % (0 if a.precision == "f32" else 1)
+                tag = "conv_gemm_kernel<2, 2, 1, 1, 0, true, %d, true, false>" % (0 if a.precision == "f32" else 1)
                 ent = next(v for k, v in pmc.items() if tag in k)
                 c = ent["counters"]
                 nd = ent.get("dispatches_of", {})
@@ -651,7 +661,7 @@ def main():
                 "kernel": "conv_gemm_kernel<MI=2,NI=2,KU=1,GLU,XF=0,VEC," + ("f32" if a.precision == "f32" else "f16x3")
                           + "> (128x128-tile gated gather-GEMM convolution)",
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r03_final; null when that profile is of other kernel sources)",
+                "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r04_final; null when that profile is of other kernel sources)",
                 "launches_per_step": len(dom), "avg_launch_ms": dom_ms / max(len(dom), 1),
                 "algorithmic_gflop_per_launch": dom_flop / max(len(dom), 1) / 1e9,
                 "share_of_program_time": dom_ms / float(ms.sum()),

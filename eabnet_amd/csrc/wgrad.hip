@@ -81,7 +81,9 @@ struct WgBatch {
     float* dbias[WG_MAXB];
 };
 
-template <int TN, int TC>
+// VEC (compile time): channel counts are multiples of 4 -> 16-byte gathers; false only for the network input of an odd
+// number of microphones.  A run-time flag around the operand loads breaks their burst (see wgrad_bf_kernel).
+template <int TN, int TC, bool VEC>
 __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgBatch bt) {
     using Smem = WgSmem<TN, TC>;
     const eab_wgrad_desc& d = bt.d;
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgBatch bt) {
 #pragma unroll
     for (int p = 0; p < AP; ++p) bsum[p] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool do_bias = m_dbias != nullptr && blockIdx.y == 0;
-    const bool vec_ok = (d.C0 & 3) == 0;                           // (two sources require C0 % 16 == 0 and C1 % 4 == 0)
+    constexpr bool vec_ok = VEC;                                   // (two sources require C0 % 16 == 0 and C1 % 4 == 0)
     auto fetch = [&](long long r0) {
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
@@ -296,7 +298,7 @@ __device__ __forceinline__ unsigned wg_bf2(float x0, float x1) {
 }
 
 // HALF (compile time, so that the operand loads of a stage stay one straight-line burst): bit 0 = dz, bit 1 = x stored as bf16
-template <int TN, int TC, int HALF>
+template <int TN, int TC, int HALF, bool VEC>
 __global__ __launch_bounds__(WG_THREADS) void wgrad_bf_kernel(const WgBatch bt) {
     constexpr int MI = TN / 64, NJ = TC / 64;
     __shared__ unsigned a_t[2][TN * WGB_S];
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_bf_kernel(const WgBatch bt) 
             tdt = d.dt[k];
             tio = d.ioff[k];
         }
-    const bool vec_ok = (d.C0 & 3) == 0;
+    constexpr bool vec_ok = VEC;
     // operands STORED as bf16 (eab_wgrad_desc.bf16_mask: the bf16 training programs' convolution-output gradients and
     // normalised activations): four bf16 of a row per load, and the LDS image of a row pair is a byte permute of the two loads
     // instead of four conversions -- the same operand bits as rounding the fp32 tensor here, half the bytes
@@ -584,14 +586,19 @@ extern "C" int eab_wgrad_batch_f32(const eab_wgrad_desc* descs, int n, int strid
     EAB_CHECK_ARG((long long)bt.groups * n < (1ll << 31));
     dim3 grid((unsigned)(bt.groups * n), (unsigned)cb, (unsigned)nb);
     hipStream_t s = eab_stream(stream);
+    const bool vec = (d->C0 & 3) == 0;               // 16-byte gathers (compile-time property of the kernel instance)
     if (d->precision == EAB_PREC_BF16) {
         const int half = d->bf16_mask & 3;       // (both sources of a concatenation alike: checked above)
 #define WG_BF_LAUNCH(TN_, TC_)                                                                                              \
     do {                                                                                                                    \
-        if (half == 0) hipLaunchKernelGGL((wgrad_bf_kernel<TN_, TC_, 0>), grid, dim3(WG_THREADS), 0, s, bt);               \
-        else if (half == 1) hipLaunchKernelGGL((wgrad_bf_kernel<TN_, TC_, 1>), grid, dim3(WG_THREADS), 0, s, bt);          \
-        else if (half == 2) hipLaunchKernelGGL((wgrad_bf_kernel<TN_, TC_, 2>), grid, dim3(WG_THREADS), 0, s, bt);          \
-        else hipLaunchKernelGGL((wgrad_bf_kernel<TN_, TC_, 3>), grid, dim3(WG_THREADS), 0, s, bt);                         \
+        if (!vec) {       /* odd channel counts: the network input only, never stored as bf16 (dz may be) */               \
+            if (half & 2) return EAB_EUNSUPPORTED;                                                                          \
+            if (half == 0) hipLaunchKernelGGL((wgrad_bf_kernel<TN_, TC_, 0, false>), grid, dim3(WG_THREADS), 0, s, bt);    \
+            else hipLaunchKernelGGL((wgrad_bf_kernel<TN_, TC_, 1, false>), grid, dim3(WG_THREADS), 0, s, bt);              \
+        } else if (half == 0) hipLaunchKernelGGL((wgrad_bf_kernel<TN_, TC_, 0, true>), grid, dim3(WG_THREADS), 0, s, bt);  \
+        else if (half == 1) hipLaunchKernelGGL((wgrad_bf_kernel<TN_, TC_, 1, true>), grid, dim3(WG_THREADS), 0, s, bt);    \
+        else if (half == 2) hipLaunchKernelGGL((wgrad_bf_kernel<TN_, TC_, 2, true>), grid, dim3(WG_THREADS), 0, s, bt);    \
+        else hipLaunchKernelGGL((wgrad_bf_kernel<TN_, TC_, 3, true>), grid, dim3(WG_THREADS), 0, s, bt);                   \
     } while (0)
         if (tn == 128 && tc == 128) WG_BF_LAUNCH(128, 128);
         else if (tn == 128) WG_BF_LAUNCH(128, 64);
@@ -600,10 +607,16 @@ extern "C" int eab_wgrad_batch_f32(const eab_wgrad_desc* descs, int n, int strid
 #undef WG_BF_LAUNCH
         EAB_RETURN_LAUNCH_STATUS();
     }
-    if (tn == 128 && tc == 128) hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(WG_THREADS), 0, s, bt);
-    else if (tn == 128) hipLaunchKernelGGL((wgrad_kernel<128, 64>), grid, dim3(WG_THREADS), 0, s, bt);
-    else if (tc == 128) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(WG_THREADS), 0, s, bt);
-    else hipLaunchKernelGGL((wgrad_kernel<64, 64>), grid, dim3(WG_THREADS), 0, s, bt);
+#define WG_F32_LAUNCH(TN_, TC_)                                                                                             \
+    do {                                                                                                                    \
+        if (vec) hipLaunchKernelGGL((wgrad_kernel<TN_, TC_, true>), grid, dim3(WG_THREADS), 0, s, bt);                     \
+        else hipLaunchKernelGGL((wgrad_kernel<TN_, TC_, false>), grid, dim3(WG_THREADS), 0, s, bt);                        \
+    } while (0)
+    if (tn == 128 && tc == 128) WG_F32_LAUNCH(128, 128);
+    else if (tn == 128) WG_F32_LAUNCH(128, 64);
+    else if (tc == 128) WG_F32_LAUNCH(64, 128);
+    else WG_F32_LAUNCH(64, 64);
+#undef WG_F32_LAUNCH
     EAB_RETURN_LAUNCH_STATUS();
 }
 

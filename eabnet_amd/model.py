@@ -1168,10 +1168,11 @@ def _check_nola(window: torch.Tensor, fft_num: int, hop: int, T: int) -> None:
     """torch.istft's window-overlap condition, on the host, before the kernel divides by the envelope: the squared-window
     overlap-add over the frames that exist must stay above 1e-11 at every output sample (a short zero-padded window with a
     large hop leaves gaps).  The envelope's two rims and its periodic interior are those of a signal of 2R+2 frames."""
-    key = (window.data_ptr(), window._version, str(window.device), window.numel(), fft_num, hop, min(T, 2 * (fft_num // hop) + 2))
+    w = window.detach().to("cpu", torch.float64).numpy()                     # (already zero-padded to fft_num by the caller)
+    key = (w.tobytes(), fft_num, hop, min(T, 2 * (fft_num // hop) + 2))     # by content: a pointer can be reused by another window
     ok = _NOLA.get(key)
     if ok is None:
-        w2 = window.detach().to("cpu", torch.float64).numpy() ** 2          # (already zero-padded to fft_num by the caller)
+        w2 = w ** 2
         Te = key[-1]
         env = np.zeros(fft_num + hop * (Te - 1))
         for t in range(Te):

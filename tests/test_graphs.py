@@ -104,3 +104,20 @@ def test_branch_switch_no_longer_depends_on_a_process_group(monkeypatch):
     assert model.graph_branches_allowed()
     monkeypatch.setenv("EAB_GRAPH_BRANCHES", "0")
     assert not model.graph_branches_allowed()
+
+
+def test_nola_check_is_keyed_by_window_content():
+    """istft's host-side NOLA check caches its verdict; two windows that happen to live at the same address (the allocator
+    hands a freed window's storage to the next one) must not share it."""
+    import torch
+    import torch.nn.functional as F
+    from eabnet_amd import model
+    bad = F.pad(torch.hann_window(100), (110, 110))
+    with pytest.raises(RuntimeError, match="NOLA"):
+        model._check_nola(bad, 320, 160, 12)
+    bad.copy_(torch.hann_window(320))               # same storage, same object: now a valid window
+    model._check_nola(bad, 320, 160, 12)
+    model._check_nola(torch.ones(256), 256, 256, 11)
+    with pytest.raises(RuntimeError, match="NOLA"):
+        model._check_nola(torch.hann_window(256), 256, 256, 11)
+    model._check_nola(torch.hann_window(256), 256, 256, 1)      # a single frame has no trimmed sample to divide
