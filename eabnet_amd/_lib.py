@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libeabnet_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_TAPS = 16
 _fp = C.POINTER(C.c_float)
 

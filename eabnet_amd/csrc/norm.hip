@@ -89,6 +89,11 @@ extern "C" int eab_in_finalize_mr_f32(const float* stats, int B, int C, int nset
 
 // out = prelu(a*sa + ha) [+ prelu(b*sb + hb)], float4 per thread.  blockIdx.y = batch element, grid-stride over
 // its float4s in 32-bit arithmetic (the flat 64-bit index needed two emulated 64-bit divisions per float4).
+// NA_UNROLL float4s per operand and thread are in flight before the first is used (one per iteration ran at one memory latency
+// per grid sweep, 2.6 TB/s); HOIST: C/4 divides the block size, so a thread's four channels never change over its walk and
+// their (scale, shift, slope) are loaded once.
+#define NA_UNROLL 4
+template <bool HOIST, bool TWO>
 __global__ __launch_bounds__(256) void norm_act_kernel(const float* __restrict__ a, const float* __restrict__ xfa,
                                                        const float* __restrict__ sla, const float* __restrict__ bb,
                                                        const float* __restrict__ xfb, const float* __restrict__ slb,
@@ -102,30 +107,49 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const float* __restrict__
     const unsigned n4 = p_lo < (unsigned)P ? rows * C4 : 0u;
     const unsigned b = blockIdx.y;
     const size_t base = ((size_t)b * P + p_lo) * C4;
-    const bool pow2 = (C4 & (C4 - 1)) == 0;
-    for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < n4; r += gridDim.x * blockDim.x) {
-        const size_t i = base + r;
-        const int c = (int)(pow2 ? (r & (C4 - 1)) : (r % C4)) * 4;
-        const f32x4 va = reinterpret_cast<const f32x4*>(a)[i];
+    const unsigned stride = gridDim.x * blockDim.x, start = blockIdx.x * blockDim.x + threadIdx.x;
+    f32x4 s01, s23, sl, t01, t23, tl;
+    auto tables = [&](unsigned r) {
+        const int c = (int)(r % C4) * 4;
         const float* xp = xfa + ((size_t)b * C + c) * 2;
-        const f32x4 s01 = *reinterpret_cast<const f32x4*>(xp), s23 = *reinterpret_cast<const f32x4*>(xp + 4);
-        const f32x4 sl = *reinterpret_cast<const f32x4*>(sla + c);
-        f32x4 r4;
-        r4[0] = eab_prelu(fmaf(va[0], s01[0], s01[1]), sl[0]);
-        r4[1] = eab_prelu(fmaf(va[1], s01[2], s01[3]), sl[1]);
-        r4[2] = eab_prelu(fmaf(va[2], s23[0], s23[1]), sl[2]);
-        r4[3] = eab_prelu(fmaf(va[3], s23[2], s23[3]), sl[3]);
-        if (bb) {
-            const f32x4 vb = reinterpret_cast<const f32x4*>(bb)[i];
+        s01 = *reinterpret_cast<const f32x4*>(xp);
+        s23 = *reinterpret_cast<const f32x4*>(xp + 4);
+        sl = *reinterpret_cast<const f32x4*>(sla + c);
+        if (TWO) {
             const float* yp = xfb + ((size_t)b * C + c) * 2;
-            const f32x4 t01 = *reinterpret_cast<const f32x4*>(yp), t23 = *reinterpret_cast<const f32x4*>(yp + 4);
-            const f32x4 tl = *reinterpret_cast<const f32x4*>(slb + c);
-            r4[0] += eab_prelu(fmaf(vb[0], t01[0], t01[1]), tl[0]);
-            r4[1] += eab_prelu(fmaf(vb[1], t01[2], t01[3]), tl[1]);
-            r4[2] += eab_prelu(fmaf(vb[2], t23[0], t23[1]), tl[2]);
-            r4[3] += eab_prelu(fmaf(vb[3], t23[2], t23[3]), tl[3]);
+            t01 = *reinterpret_cast<const f32x4*>(yp);
+            t23 = *reinterpret_cast<const f32x4*>(yp + 4);
+            tl = *reinterpret_cast<const f32x4*>(slb + c);
         }
-        reinterpret_cast<f32x4*>(out)[i] = r4;
+    };
+    if (HOIST && start < n4) tables(start);
+    for (unsigned r0 = start; r0 < n4; r0 += NA_UNROLL * stride) {
+        f32x4 va[NA_UNROLL], vb[NA_UNROLL];
+#pragma unroll
+        for (int u = 0; u < NA_UNROLL; ++u) {
+            const unsigned r = r0 + u * stride;
+            const size_t i = base + (r < n4 ? r : r0);
+            va[u] = reinterpret_cast<const f32x4*>(a)[i];
+            if (TWO) vb[u] = reinterpret_cast<const f32x4*>(bb)[i];
+        }
+#pragma unroll
+        for (int u = 0; u < NA_UNROLL; ++u) {
+            const unsigned r = r0 + u * stride;
+            if (r >= n4) continue;
+            if (!HOIST) tables(r);
+            f32x4 r4;
+            r4[0] = eab_prelu(fmaf(va[u][0], s01[0], s01[1]), sl[0]);
+            r4[1] = eab_prelu(fmaf(va[u][1], s01[2], s01[3]), sl[1]);
+            r4[2] = eab_prelu(fmaf(va[u][2], s23[0], s23[1]), sl[2]);
+            r4[3] = eab_prelu(fmaf(va[u][3], s23[2], s23[3]), sl[3]);
+            if (TWO) {
+                r4[0] += eab_prelu(fmaf(vb[u][0], t01[0], t01[1]), tl[0]);
+                r4[1] += eab_prelu(fmaf(vb[u][1], t01[2], t01[3]), tl[1]);
+                r4[2] += eab_prelu(fmaf(vb[u][2], t23[0], t23[1]), tl[2]);
+                r4[3] += eab_prelu(fmaf(vb[u][3], t23[2], t23[3]), tl[3]);
+            }
+            reinterpret_cast<f32x4*>(out)[base + r] = r4;
+        }
     }
 }
 
@@ -137,12 +161,21 @@ extern "C" int eab_norm_act_win_f32(const float* a, const float* xfa, const floa
     EAB_CHECK_ARG(win.pos == nullptr || win.count > 0);
     const long long P = (long long)T * rows_per_t, Pw = (long long)(win.pos ? win.count : T) * rows_per_t;
     EAB_CHECK_ARG(P * (C / 4) < (1ll << 31) && B <= 65535);
-    long long gx = (Pw * (C / 4) + 255) / 256;
-    const long long cap = (256 * 8 + B - 1) / B;       // <= 8 blocks per CU over the whole grid, grid-stride the rest
+    long long gx = (Pw * (C / 4) + 256 * NA_UNROLL - 1) / (256 * NA_UNROLL);
+    const long long cap = (256 * 4 + B - 1) / B;       // <= 4 blocks per CU over the whole grid, grid-stride the rest
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)gx, (unsigned)B), dim3(256), 0, eab_stream(stream), a, xfa, slopea,
-                       b, xfb, slopeb, out, (int)P, C, win.pos, rows_per_t, (int)Pw);
+    const dim3 grid((unsigned)gx, (unsigned)B), block(256);
+    hipStream_t s = eab_stream(stream);
+    const bool hoist = 256 % (C / 4) == 0;
+#define NA_LAUNCH(H_, T_) hipLaunchKernelGGL((norm_act_kernel<H_, T_>), grid, block, 0, s, a, xfa, slopea, b, xfb, slopeb, out, (int)P, C, \
+                                              win.pos, rows_per_t, (int)Pw)
+    if (hoist) {
+        if (b) NA_LAUNCH(true, true); else NA_LAUNCH(true, false);
+    } else {
+        if (b) NA_LAUNCH(false, true); else NA_LAUNCH(false, false);
+    }
+#undef NA_LAUNCH
     EAB_RETURN_LAUNCH_STATUS();
 }
 

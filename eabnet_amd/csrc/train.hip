@@ -211,39 +211,59 @@ extern "C" int eab_train_in1d_multi_f32(const float* x, const float* slope, int 
 // y = f(x) [+ add]   with f = prelu(x*scale + shift)  (EAB_XF_NORM_PRELU, 2-D units)
 //                        or prelu(x)*scale + shift    (EAB_XF_PRELU_NORM, S-TCM)
 // ---------------------------------------------------------------------------------------------------
+// HOIST: C/4 divides the block size, so a thread's channel group never changes over its grid-stride walk and the
+// (scale, shift, slope) of its four channels are loaded once.  TR_UNROLL float4s per thread are in flight before the first is used.
+#define TR_UNROLL 4
+template <int MODE, bool HOIST>
 __global__ __launch_bounds__(TR_THREADS) void tr_norm_act_kernel(const float* __restrict__ x, const float* __restrict__ xf,
                                                                  const float* __restrict__ slope, const float* __restrict__ add,
-                                                                 float* __restrict__ y, int P, int C, int mode_flags) {
-    const int mode = mode_flags & 0xFF;
+                                                                 float* __restrict__ y, int P, int C, int store_bf16) {
     const unsigned C4 = (unsigned)C >> 2, n4 = (unsigned)P * C4, b = blockIdx.y;
     const size_t base = (size_t)b * n4;
-    for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < n4; r += gridDim.x * blockDim.x) {
-        const int c = (int)(((C4 & (C4 - 1)) == 0) ? (r & (C4 - 1)) : (r % C4)) * 4;   // (64 / 128 / 256 channels: a mask)
-        const f32x4 v = reinterpret_cast<const f32x4*>(x)[base + r];
-        // xf == NULL: no norm in front of the PReLU (the plain U-Net's middle encoder layers, EaBNet.py:219-226)
-        const f32x4 one0 = {1.f, 0.f, 1.f, 0.f};
-        const float* xp = xf + ((size_t)b * C + c) * 2;
-        const f32x4 s01 = xf ? *reinterpret_cast<const f32x4*>(xp) : one0, s23 = xf ? *reinterpret_cast<const f32x4*>(xp + 4) : one0;
-        const f32x4 sl = *reinterpret_cast<const f32x4*>(slope + c);
-        const float sc[4] = {s01[0], s01[2], s23[0], s23[2]}, sh[4] = {s01[1], s01[3], s23[1], s23[3]};
-        f32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            o[j] = mode == EAB_XF_NORM_PRELU ? eab_prelu(fmaf(v[j], sc[j], sh[j]), sl[j]) : fmaf(eab_prelu(v[j], sl[j]), sc[j], sh[j]);
-        if (add) {
-            const f32x4 a = reinterpret_cast<const f32x4*>(add)[base + r];
-            o += a;
+    const unsigned stride = gridDim.x * blockDim.x, start = blockIdx.x * blockDim.x + threadIdx.x;
+    // xf == NULL: no norm in front of the PReLU (the plain U-Net's middle encoder layers, EaBNet.py:219-226)
+    const f32x4 one0 = {1.f, 0.f, 1.f, 0.f};
+    f32x4 s01 = one0, s23 = one0, sl = {0.f, 0.f, 0.f, 0.f};
+    auto tables = [&](unsigned r) {
+        const int c = (int)(r % C4) * 4;
+        if (xf) {
+            const float* xp = xf + ((size_t)b * C + c) * 2;
+            s01 = *reinterpret_cast<const f32x4*>(xp);
+            s23 = *reinterpret_cast<const f32x4*>(xp + 4);
         }
-        if (mode_flags & EAB_STORE_BF16)          // the tensor is read by bf16 contractions only: store what they would round to
-            reinterpret_cast<uint2*>(y)[base + r] = make_uint2(tr_bf2(o[0], o[1]), tr_bf2(o[2], o[3]));
-        else
-            reinterpret_cast<f32x4*>(y)[base + r] = o;
+        sl = *reinterpret_cast<const f32x4*>(slope + c);
+    };
+    if (HOIST) tables(start);
+    for (unsigned r0 = start; r0 < n4; r0 += TR_UNROLL * stride) {
+        f32x4 v[TR_UNROLL], ad[TR_UNROLL];
+#pragma unroll
+        for (int u = 0; u < TR_UNROLL; ++u) {
+            const unsigned r = r0 + u * stride, rr = r < n4 ? r : r0;
+            v[u] = reinterpret_cast<const f32x4*>(x)[base + rr];
+            if (add) ad[u] = reinterpret_cast<const f32x4*>(add)[base + rr];
+        }
+#pragma unroll
+        for (int u = 0; u < TR_UNROLL; ++u) {
+            const unsigned r = r0 + u * stride;
+            if (r >= n4) continue;
+            if (!HOIST) tables(r);
+            const float sc[4] = {s01[0], s01[2], s23[0], s23[2]}, sh[4] = {s01[1], s01[3], s23[1], s23[3]};
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                o[j] = MODE == EAB_XF_NORM_PRELU ? eab_prelu(fmaf(v[u][j], sc[j], sh[j]), sl[j]) : fmaf(eab_prelu(v[u][j], sl[j]), sc[j], sh[j]);
+            if (add) o += ad[u];
+            if (store_bf16)                       // the tensor is read by bf16 contractions only: store what they would round to
+                reinterpret_cast<uint2*>(y)[base + r] = make_uint2(tr_bf2(o[0], o[1]), tr_bf2(o[2], o[3]));
+            else
+                reinterpret_cast<f32x4*>(y)[base + r] = o;
+        }
     }
 }
 
 static inline unsigned tr_grid_x(long long n4, int B) {
-    long long gx = (n4 + TR_THREADS - 1) / TR_THREADS;
-    const long long cap = (256 * 8 + B - 1) / B;
+    long long gx = (n4 + (long long)TR_THREADS * TR_UNROLL - 1) / ((long long)TR_THREADS * TR_UNROLL);
+    const long long cap = (256 * 4 + B - 1) / B;
     if (gx > cap) gx = cap;
     return (unsigned)(gx < 1 ? 1 : gx);
 }
@@ -251,13 +271,21 @@ static inline unsigned tr_grid_x(long long n4, int B) {
 extern "C" int eab_train_norm_act_f32(const float* x, const float* xf, const float* slope, const float* add, float* y, int B,
                                       int P, int C, int mode, eab_stream_t stream) {
     EAB_CHECK_ARG(x && slope && y && B > 0 && P > 0 && C > 0 && (C % 4) == 0 && B <= 65535);
-    const int flags = mode & EAB_STORE_BF16;                         // y stored as bf16 (2-byte elements)
+    const int bf = (mode & EAB_STORE_BF16) ? 1 : 0;                  // y stored as bf16 (2-byte elements)
     mode &= ~EAB_STORE_BF16;
     EAB_CHECK_ARG(mode == EAB_XF_NORM_PRELU || mode == EAB_XF_PRELU_NORM);
     EAB_CHECK_ARG(xf || mode == EAB_XF_NORM_PRELU);                  // xf == NULL: y = prelu(x) [+ add]
     EAB_CHECK_ARG((long long)P * (C / 4) < (1ll << 31));
-    hipLaunchKernelGGL(tr_norm_act_kernel, dim3(tr_grid_x((long long)P * (C / 4), B), B), dim3(TR_THREADS), 0, eab_stream(stream),
-                       x, xf, slope, add, y, P, C, mode | flags);
+    const dim3 grid(tr_grid_x((long long)P * (C / 4), B), B), block(TR_THREADS);
+    hipStream_t s = eab_stream(stream);
+    const bool hoist = TR_THREADS % (C / 4) == 0;
+#define TR_NA(MODE_, H_) hipLaunchKernelGGL((tr_norm_act_kernel<MODE_, H_>), grid, block, 0, s, x, xf, slope, add, y, P, C, bf)
+    if (mode == EAB_XF_NORM_PRELU) {
+        if (hoist) TR_NA(EAB_XF_NORM_PRELU, true); else TR_NA(EAB_XF_NORM_PRELU, false);
+    } else {
+        if (hoist) TR_NA(EAB_XF_PRELU_NORM, true); else TR_NA(EAB_XF_PRELU_NORM, false);
+    }
+#undef TR_NA
     EAB_RETURN_LAUNCH_STATUS();
 }
 
@@ -273,17 +301,23 @@ extern "C" int eab_train_norm_act_f32(const float* x, const float* xf, const flo
 // pass 3 (params): dgamma[c] += sum_b Q, dbeta[c] += sum_b A, dslope[c] += sum_b S.
 // ---------------------------------------------------------------------------------------------------
 #define NB_ROWS 16      // position lanes per block: block = 16 float4 channel groups (64 channels) x 16 positions
+#define NB_UNROLL 4     // rows a thread has in flight
+#define NB_SHARDS EAB_NB_SUM_COPIES
 
 __global__ __launch_bounds__(TR_THREADS) void tr_zero_kernel(float* __restrict__ p, long long n4) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n4) reinterpret_cast<f32x4*>(p)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// thread -> 4 channels (float4) x every 16th position of the block's chunk: a wave reads 4 positions x 256 B = 1 KB
+// thread -> 4 channels (float4) x every 16th position of the block's chunk: a wave reads 4 positions x 256 B = 1 KB.
+// NB_UNROLL rows per thread are in flight before the first is used (32 KB of loads per workgroup: a streaming kernel with one
+// load per thread and iteration ran at one memory latency per 16 rows, 2.6 TB/s), and the block's atomics go to copy
+// blockIdx.x % NB_SHARDS of the sums (330 workgroups adding into the 24 words of one cache line cost more than the reads).
+template <int MODE>
 __global__ __launch_bounds__(TR_THREADS) void norm_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                      const float* __restrict__ mr, const float* __restrict__ gamma,
                                                                      const float* __restrict__ beta, const float* __restrict__ slope,
-                                                                     float* __restrict__ sums, int P, int C, int mode, int chunk,
+                                                                     float* __restrict__ sums, int P, int C, int chunk,
                                                                      int xC, const float* __restrict__ dy1) {
     __shared__ f32x4 red[3][NB_ROWS][16];
     const int b = blockIdx.z, cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
@@ -302,21 +336,31 @@ __global__ __launch_bounds__(TR_THREADS) void norm_bwd_reduce_kernel(const float
         const size_t xbase = (size_t)b * P * xC + (c % xC);
         const float* dyp = xC < C ? (c < xC ? dy : dy1) + xbase : dy + (size_t)b * P * C + c;
         const int dC = xC < C ? xC : C;
-        for (int i = p0 + pl; i < p1; i += NB_ROWS) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(&x[xbase + (size_t)i * xC]);
-            const f32x4 d = *reinterpret_cast<const f32x4*>(&dyp[(size_t)i * dC]);
+        for (int i0 = p0 + pl; i0 < p1; i0 += NB_ROWS * NB_UNROLL) {
+            f32x4 xv[NB_UNROLL], dv[NB_UNROLL];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (mode == EAB_XF_NORM_PRELU) {
-                    const float xh = (xv[j] - mean[j]) * rstd[j], u = fmaf(g[j], xh, be[j]);
-                    const float du = u > 0.f ? d[j] : a[j] * d[j];
-                    A[j] += du;
-                    Q[j] = fmaf(du, xh, Q[j]);
-                    S[j] += u > 0.f ? 0.f : d[j] * u;
-                } else {
-                    const float xh = (eab_prelu(xv[j], a[j]) - mean[j]) * rstd[j];
-                    A[j] += d[j];
-                    Q[j] = fmaf(d[j], xh, Q[j]);
+            for (int u = 0; u < NB_UNROLL; ++u) {               // rows past the chunk re-read row i0 with a zero gradient: they add 0
+                const int i = i0 + NB_ROWS * u, ii = i < p1 ? i : i0;
+                xv[u] = *reinterpret_cast<const f32x4*>(&x[xbase + (size_t)ii * xC]);
+                dv[u] = *reinterpret_cast<const f32x4*>(&dyp[(size_t)ii * dC]);
+            }
+#pragma unroll
+            for (int u = 0; u < NB_UNROLL; ++u) {
+                if (i0 + NB_ROWS * u >= p1) continue;
+                const f32x4 d = dv[u];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (MODE == EAB_XF_NORM_PRELU) {
+                        const float xh = (xv[u][j] - mean[j]) * rstd[j], uu = fmaf(g[j], xh, be[j]);
+                        const float du = uu > 0.f ? d[j] : a[j] * d[j];
+                        A[j] += du;
+                        Q[j] = fmaf(du, xh, Q[j]);
+                        S[j] += uu > 0.f ? 0.f : d[j] * uu;
+                    } else {
+                        const float xh = (eab_prelu(xv[u][j], a[j]) - mean[j]) * rstd[j];
+                        A[j] += d[j];
+                        Q[j] = fmaf(d[j], xh, Q[j]);
+                    }
                 }
             }
         }
@@ -326,40 +370,37 @@ __global__ __launch_bounds__(TR_THREADS) void norm_bwd_reduce_kernel(const float
     red[2][pl][cl] = S;
     __syncthreads();
     if (pl < 3 && c < C) {       // pl = which of (A, Q, S); fixed-order sum over the 16 position lanes, then one atomic per value
-        if (pl == 2 && mode != EAB_XF_NORM_PRELU) return;
+        if (pl == 2 && MODE != EAB_XF_NORM_PRELU) return;
         if (pl < 2 && !mr) return;
         f32x4 t = red[pl][0][cl];
 #pragma unroll
         for (int k = 1; k < NB_ROWS; ++k) t += red[pl][k][cl];
+        float* sh = sums + (size_t)(blockIdx.x % NB_SHARDS) * gridDim.z * C * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) atomicAdd(&sums[((size_t)b * C + c + j) * 4 + pl], t[j]);
+        for (int j = 0; j < 4; ++j) atomicAdd(&sh[((size_t)b * C + c + j) * 4 + pl], t[j]);
     }
 }
 
+// (A, Q, S, -) of (b, c): the sum of the NB_SHARDS copies, in copy order
+__device__ __forceinline__ f32x4 nb_sums(const float* __restrict__ sums, int B, int C, int b, int c) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(&sums[((size_t)b * C + c) * 4]);
+#pragma unroll
+    for (int s = 1; s < NB_SHARDS; ++s) t += *reinterpret_cast<const f32x4*>(&sums[(((size_t)s * B + b) * C + c) * 4]);
+    return t;
+}
+
+template <int MODE>
 __global__ __launch_bounds__(TR_THREADS) void norm_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                     const float* __restrict__ mr, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, const float* __restrict__ slope,
                                                                     float* __restrict__ sums, const float* __restrict__ acc_in,
                                                                     float* __restrict__ dx, float* __restrict__ dgamma,
                                                                     float* __restrict__ dbeta, float* __restrict__ dslope, int P, int C,
-                                                                    int mode, int chunk, int dx_bf16) {
+                                                                    int chunk, int dx_bf16) {
     __shared__ f32x4 red[NB_ROWS][16];
-    const int b = blockIdx.z, cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int b = blockIdx.z, B = gridDim.z, cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int c = blockIdx.y * 64 + cl * 4;
     f32x4 S = {0.f, 0.f, 0.f, 0.f};
-    if ((dgamma || !mr) && blockIdx.x == 0 && pl == 0 && c < C) {
-        // the sums A, Q (and S for NORM_PRELU) of (b, c) are final after the reduce pass -> the parameter gradients ride
-        // along here (one workgroup per (b, channel group); B atomics per address)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(&sums[((size_t)b * C + c + j) * 4]);
-            if (mr) {
-                atomicAdd(&dbeta[c + j], v[0]);
-                atomicAdd(&dgamma[c + j], v[1]);
-            }
-            if (mode == EAB_XF_NORM_PRELU) atomicAdd(&dslope[c + j], v[2]);
-        }
-    }
     if (c < C) {
         // mr == NULL: no norm -- dx = dy * prelu'(x), no projection
         const f32x4 zero_one = {0.f, 1.f, 0.f, 1.f}, ones = {1.f, 1.f, 1.f, 1.f}, zeros = {0.f, 0.f, 0.f, 0.f};
@@ -372,37 +413,61 @@ __global__ __launch_bounds__(TR_THREADS) void norm_bwd_apply_kernel(const float*
         float Am[4], Qm[4], k[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            Am[j] = sums[((size_t)b * C + c + j) * 4] * inv_p;
-            Qm[j] = sums[((size_t)b * C + c + j) * 4 + 1] * inv_p;
+            const f32x4 v = nb_sums(sums, B, C, b, c + j);
+            Am[j] = v[0] * inv_p;
+            Qm[j] = v[1] * inv_p;
             k[j] = rstd[j] * g[j];
+            // the sums A, Q (and S for NORM_PRELU) of (b, c) are final after the reduce pass -> the parameter gradients ride
+            // along here (one workgroup per (b, channel group); B atomics per address)
+            if ((dgamma || !mr) && blockIdx.x == 0 && pl == 0) {
+                if (mr) {
+                    atomicAdd(&dbeta[c + j], v[0]);
+                    atomicAdd(&dgamma[c + j], v[1]);
+                }
+                if (MODE == EAB_XF_NORM_PRELU) atomicAdd(&dslope[c + j], v[2]);
+            }
         }
         const int p0 = blockIdx.x * chunk, p1 = p0 + chunk < P ? p0 + chunk : P;
         const size_t base = (size_t)b * P * C + c;
-        for (int i = p0 + pl; i < p1; i += NB_ROWS) {
-            const size_t e = base + (size_t)i * C;
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(&x[e]), d = *reinterpret_cast<const f32x4*>(&dy[e]);
-            f32x4 r;
+        for (int i0 = p0 + pl; i0 < p1; i0 += NB_ROWS * NB_UNROLL) {
+            f32x4 xq[NB_UNROLL], dq[NB_UNROLL], aq[NB_UNROLL];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (mode == EAB_XF_NORM_PRELU) {
-                    const float xh = (xv[j] - mean[j]) * rstd[j], u = fmaf(g[j], xh, be[j]);
-                    const float du = u > 0.f ? d[j] : a[j] * d[j];
-                    r[j] = k[j] * (du - Am[j] - xh * Qm[j]);
-                } else {
-                    const float xh = (eab_prelu(xv[j], a[j]) - mean[j]) * rstd[j];
-                    const float dp = k[j] * (d[j] - Am[j] - xh * Qm[j]);
-                    r[j] = xv[j] > 0.f ? dp : a[j] * dp;
-                    S[j] += xv[j] > 0.f ? 0.f : dp * xv[j];
-                }
+            for (int u = 0; u < NB_UNROLL; ++u) {               // NB_UNROLL rows in flight (rows past the chunk re-read row i0)
+                const int i = i0 + NB_ROWS * u;
+                const size_t e = base + (size_t)(i < p1 ? i : i0) * C;
+                xq[u] = *reinterpret_cast<const f32x4*>(&x[e]);
+                dq[u] = *reinterpret_cast<const f32x4*>(&dy[e]);
+                if (acc_in) aq[u] = *reinterpret_cast<const f32x4*>(&acc_in[e]);
             }
-            if (acc_in) r += *reinterpret_cast<const f32x4*>(&acc_in[e]);
-            if (dx_bf16)                                   // read by bf16 contractions only (wgrad, dgrad): half the bytes
-                *reinterpret_cast<uint2*>(reinterpret_cast<char*>(dx) + e * 2) = make_uint2(tr_bf2(r[0], r[1]), tr_bf2(r[2], r[3]));
-            else
-                *reinterpret_cast<f32x4*>(&dx[e]) = r;
+#pragma unroll
+            for (int u = 0; u < NB_UNROLL; ++u) {
+                const int i = i0 + NB_ROWS * u;
+                if (i >= p1) continue;
+                const size_t e = base + (size_t)i * C;
+                const f32x4 xv = xq[u], d = dq[u];
+                f32x4 r;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (MODE == EAB_XF_NORM_PRELU) {
+                        const float xh = (xv[j] - mean[j]) * rstd[j], uu = fmaf(g[j], xh, be[j]);
+                        const float du = uu > 0.f ? d[j] : a[j] * d[j];
+                        r[j] = k[j] * (du - Am[j] - xh * Qm[j]);
+                    } else {
+                        const float xh = (eab_prelu(xv[j], a[j]) - mean[j]) * rstd[j];
+                        const float dp = k[j] * (d[j] - Am[j] - xh * Qm[j]);
+                        r[j] = xv[j] > 0.f ? dp : a[j] * dp;
+                        S[j] += xv[j] > 0.f ? 0.f : dp * xv[j];
+                    }
+                }
+                if (acc_in) r += aq[u];
+                if (dx_bf16)                               // read by bf16 contractions only (wgrad, dgrad): half the bytes
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(dx) + e * 2) = make_uint2(tr_bf2(r[0], r[1]), tr_bf2(r[2], r[3]));
+                else
+                    *reinterpret_cast<f32x4*>(&dx[e]) = r;
+            }
         }
     }
-    if (mode == EAB_XF_PRELU_NORM) {
+    if (MODE == EAB_XF_PRELU_NORM) {
         red[pl][cl] = S;
         __syncthreads();
         if (pl == 0 && c < C) {
@@ -410,7 +475,7 @@ __global__ __launch_bounds__(TR_THREADS) void norm_bwd_apply_kernel(const float*
 #pragma unroll
             for (int kk = 1; kk < NB_ROWS; ++kk) t += red[kk][cl];
             // PRELU_NORM: the slope sum only exists after this pass.  merged (dgamma != NULL): straight into dslope (the host
-            // picks that when a slope address sees few workgroups), else into sums for the params kernel
+            // picks that when a slope address sees few workgroups), else into copy 0 of the sums for the params kernel
 #pragma unroll
             for (int j = 0; j < 4; ++j) atomicAdd(dgamma ? &dslope[c + j] : &sums[((size_t)b * C + c + j) * 4 + 2], t[j]);
         }
@@ -445,7 +510,7 @@ __global__ __launch_bounds__(TR_THREADS) void norm_bwd_apply_multi_kernel(const 
             const float mn[4] = {m01[0], m01[2], m23[0], m23[2]}, rs[4] = {m01[1], m01[3], m23[1], m23[3]};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const f32x4 sv = *reinterpret_cast<const f32x4*>(&sums[((size_t)b * C + cv + j) * 4]);
+                const f32x4 sv = nb_sums(sums, gridDim.z, C, b, cv + j);
                 mean[v][j] = mn[j];
                 k[v][j] = rs[j] * g[j];
                 Am[v][j] = sv[0] * inv_p;
@@ -493,7 +558,7 @@ __global__ __launch_bounds__(64) void norm_bwd_params_kernel(const float* __rest
     if (c >= C) return;
     float A = 0.f, Q = 0.f, S = 0.f;
     for (int b = 0; b < B; ++b) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(&sums[((size_t)b * C + c) * 4]);
+        const f32x4 v = nb_sums(sums, B, C, b, c);
         A += v[0];
         Q += v[1];
         S += v[2];
@@ -504,13 +569,15 @@ __global__ __launch_bounds__(64) void norm_bwd_params_kernel(const float* __rest
 }
 
 static inline int nb_chunk(int P, int B, int C) {
-    // positions per block: ~2048 blocks over the grid, at least 64 positions each
+    // positions per block: ~1024 blocks over the grid (four per CU, each with NB_UNROLL rows per thread in flight), at least 64
+    // positions each, a whole number of unrolled iterations
     const long long blocks_bc = (long long)B * ((C + 63) / 64);
-    long long want = (2048 + blocks_bc - 1) / blocks_bc;
+    long long want = (1024 + blocks_bc - 1) / blocks_bc;
     if (want < 1) want = 1;
     long long chunk = (P + want - 1) / want;
     if (chunk < 64) chunk = 64;
-    return (int)((chunk + NB_ROWS - 1) / NB_ROWS * NB_ROWS);
+    const int step = NB_ROWS * NB_UNROLL;
+    return (int)((chunk + step - 1) / step * step);
 }
 
 extern "C" int eab_train_norm_bwd_f32(const float* dy, const float* x, const float* mr, const float* gamma, const float* beta,
@@ -531,14 +598,23 @@ extern "C" int eab_train_norm_bwd_f32(const float* dy, const float* x, const flo
     dim3 grid((P + chunk - 1) / chunk, (C + 63) / 64, B);
     // (a kernel, not hipMemsetAsync: memset nodes of a captured graph were not reliably ordered on this stack)
     if (!zeroed)
-        hipLaunchKernelGGL(tr_zero_kernel, dim3((B * C + TR_THREADS - 1) / TR_THREADS), dim3(TR_THREADS), 0, s, sums, (long long)B * C);
-    hipLaunchKernelGGL(norm_bwd_reduce_kernel, grid, dim3(TR_THREADS), 0, s, dy, x, mr, gamma, beta, slope, sums, P, C, mode, chunk, C,
-                       nullptr);
+        hipLaunchKernelGGL(tr_zero_kernel, dim3((NB_SHARDS * B * C + TR_THREADS - 1) / TR_THREADS), dim3(TR_THREADS), 0, s, sums,
+                           (long long)NB_SHARDS * B * C);
+    if (mode == EAB_XF_NORM_PRELU)
+        hipLaunchKernelGGL(norm_bwd_reduce_kernel<EAB_XF_NORM_PRELU>, grid, dim3(TR_THREADS), 0, s, dy, x, mr, gamma, beta, slope, sums, P,
+                           C, chunk, C, nullptr);
+    else
+        hipLaunchKernelGGL(norm_bwd_reduce_kernel<EAB_XF_PRELU_NORM>, grid, dim3(TR_THREADS), 0, s, dy, x, mr, gamma, beta, slope, sums, P,
+                           C, chunk, C, nullptr);
     // parameter gradients inside the apply pass: always for NORM_PRELU (all three sums are final after the reduce pass); for
     // PRELU_NORM when its slope sums can go straight into dslope (<= 256 workgroups per address: the S-TCN's slabs)
     const bool merged = mode == EAB_XF_NORM_PRELU || (long long)grid.x * B <= 256;
-    hipLaunchKernelGGL(norm_bwd_apply_kernel, grid, dim3(TR_THREADS), 0, s, dy, x, mr, gamma, beta, slope, sums, acc_in, dx,
-                       merged ? dgamma : nullptr, dbeta, dslope, P, C, mode, chunk, dx_bf16);
+    if (mode == EAB_XF_NORM_PRELU)
+        hipLaunchKernelGGL(norm_bwd_apply_kernel<EAB_XF_NORM_PRELU>, grid, dim3(TR_THREADS), 0, s, dy, x, mr, gamma, beta, slope, sums,
+                           acc_in, dx, merged ? dgamma : nullptr, dbeta, dslope, P, C, chunk, dx_bf16);
+    else
+        hipLaunchKernelGGL(norm_bwd_apply_kernel<EAB_XF_PRELU_NORM>, grid, dim3(TR_THREADS), 0, s, dy, x, mr, gamma, beta, slope, sums,
+                           acc_in, dx, merged ? dgamma : nullptr, dbeta, dslope, P, C, chunk, dx_bf16);
     if (!merged) hipLaunchKernelGGL(norm_bwd_params_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, B, C, dgamma, dbeta, dslope);
     EAB_RETURN_LAUNCH_STATUS();
 }
@@ -557,8 +633,8 @@ extern "C" int eab_train_norm_bwd_multi_f32(const float* dy0, const float* dy1, 
     const float* const beta = gamma;            // (not read in the PRELU_NORM order)
     const int chunk = nb_chunk(P, B, C);
     hipStream_t s = eab_stream(stream);
-    hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3((P + chunk - 1) / chunk, (C + 63) / 64, B), dim3(TR_THREADS), 0, s, dy, x, mr, gamma,
-                       beta, slope, sums, P, C, EAB_XF_PRELU_NORM, chunk, xC, dy1);
+    hipLaunchKernelGGL(norm_bwd_reduce_kernel<EAB_XF_PRELU_NORM>, dim3((P + chunk - 1) / chunk, (C + 63) / 64, B), dim3(TR_THREADS), 0, s,
+                       dy, x, mr, gamma, beta, slope, sums, P, C, chunk, xC, dy1);
     hipLaunchKernelGGL(norm_bwd_apply_multi_kernel, dim3((P + chunk - 1) / chunk, (xC + 63) / 64, B), dim3(TR_THREADS), 0, s, dy, dy1, x,
                        mr, gamma, slope, sums, acc_in, dx, dgamma, dbeta, dslope, P, C, xC, chunk);
     EAB_RETURN_LAUNCH_STATUS();
@@ -575,22 +651,35 @@ template <int GENERIC>
 __global__ __launch_bounds__(TR_THREADS) void glu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dump,
                                                              float* __restrict__ dz, long long rows, int N, int lg4, int dz_bf16) {
     const int Cout = N >> 1, N4 = N >> 2;
-    const long long n4 = rows * N4;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-        const long long row = GENERIC ? i / N4 : i >> lg4;
-        const int r = (int)(i - row * N4) * 4;                 // first packed column of this float4 (same half, same 32-group)
-        const int half = (r & 63) >> 5, c = (r >> 6) * 32 + (r & 31);
-        const int mate = half ? r - 32 : r + 32;               // packed column of the partner (gate <-> value)
-        const f32x4 d = *reinterpret_cast<const f32x4*>(&dy[row * Cout + c]);
-        const f32x4 me = *reinterpret_cast<const f32x4*>(&dump[row * N + r]);
-        const f32x4 ot = *reinterpret_cast<const f32x4*>(&dump[row * N + mate]);
-        f32x4 o;
+    const long long n4 = rows * N4, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += TR_UNROLL * stride) {
+        f32x4 d[TR_UNROLL], me[TR_UNROLL], ot[TR_UNROLL];
+        long long at[TR_UNROLL];
+        int half[TR_UNROLL];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = half ? d[j] * ot[j] * me[j] * (1.0f - me[j]) : d[j] * ot[j];
-        if (dz_bf16)
-            *reinterpret_cast<uint2*>(reinterpret_cast<char*>(dz) + (row * N + r) * 2) = make_uint2(tr_bf2(o[0], o[1]), tr_bf2(o[2], o[3]));
-        else
-            *reinterpret_cast<f32x4*>(&dz[row * N + r]) = o;
+        for (int u = 0; u < TR_UNROLL; ++u) {                     // TR_UNROLL float4s of each operand in flight
+            const long long i = i0 + u * stride < n4 ? i0 + u * stride : i0;
+            const long long row = GENERIC ? i / N4 : i >> lg4;
+            const int r = (int)(i - row * N4) * 4;                 // first packed column of this float4 (same half, same 32-group)
+            const int c = (r >> 6) * 32 + (r & 31);
+            half[u] = (r & 63) >> 5;
+            const int mate = half[u] ? r - 32 : r + 32;            // packed column of the partner (gate <-> value)
+            at[u] = row * N + r;
+            d[u] = *reinterpret_cast<const f32x4*>(&dy[row * Cout + c]);
+            me[u] = *reinterpret_cast<const f32x4*>(&dump[row * N + r]);
+            ot[u] = *reinterpret_cast<const f32x4*>(&dump[row * N + mate]);
+        }
+#pragma unroll
+        for (int u = 0; u < TR_UNROLL; ++u) {
+            if (i0 + u * stride >= n4) continue;
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = half[u] ? d[u][j] * ot[u][j] * me[u][j] * (1.0f - me[u][j]) : d[u][j] * ot[u][j];
+            if (dz_bf16)
+                *reinterpret_cast<uint2*>(reinterpret_cast<char*>(dz) + at[u] * 2) = make_uint2(tr_bf2(o[0], o[1]), tr_bf2(o[2], o[3]));
+            else
+                *reinterpret_cast<f32x4*>(&dz[at[u]]) = o;
+        }
     }
 }
 
@@ -598,8 +687,8 @@ extern "C" int eab_glu_bwd_ex_f32(const float* dy, const float* dump, float* dz,
                                   eab_stream_t stream) {
     EAB_CHECK_ARG(dy && dump && dz && rows > 0 && N > 0 && (N % 64) == 0 && (flags & ~EAB_STORE_BF16) == 0);
     const int dz_bf16 = (flags & EAB_STORE_BF16) ? 1 : 0;            // dz stored as bf16 (read by bf16 wgrad / dgrad only)
-    long long g = (rows * (N / 4) + TR_THREADS - 1) / TR_THREADS;
-    if (g > 8192) g = 8192;
+    long long g = (rows * (N / 4) + TR_THREADS * TR_UNROLL - 1) / (TR_THREADS * TR_UNROLL);
+    if (g > 2048) g = 2048;
     const int N4 = N / 4;
     if ((N4 & (N4 - 1)) == 0)
         hipLaunchKernelGGL(glu_bwd_kernel<0>, dim3((unsigned)g), dim3(TR_THREADS), 0, eab_stream(stream), dy, dump, dz, rows, N,

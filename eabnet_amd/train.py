@@ -46,6 +46,7 @@ XF_NORM_PRELU, XF_PRELU_NORM = prg.XF_NORM_PRELU, prg.XF_PRELU_NORM
  OP_FILTER_SUM, OP_FS_BWD, OP_LN_FWD, OP_LN_BWD, OP_LSTM_TRAIN, OP_LSTM_BWD, OP_WGRAD) = range(16, 33)
 OP_CLN_STATS, OP_CLN_APPLY, OP_CLN_BWD = prg.OP_CLN_STATS, prg.OP_CLN_APPLY, 37      # include/eabnet_hip.h EAB_OP_CLN_*
 NB_SUMS_ZEROED = 0x100   # include/eabnet_hip.h EAB_NB_SUMS_ZEROED
+NB_SUM_COPIES = 8        # include/eabnet_hip.h EAB_NB_SUM_COPIES: the reduce pass spreads its atomics over that many copies
 STORE_BF16 = 0x200       # include/eabnet_hip.h EAB_STORE_BF16: the op's output tensor is stored as bf16
 MLP_LD = 64          # the second Linear of w_dnn is run with its 2M rows padded to one 64-column tile
 TRAIN_BOUND_CACHE = 3   # bound training programs kept per module (LRU over (B, T, F, device, precision))
@@ -393,7 +394,7 @@ class TrainLowering:
             # reduction scratch in the gradient arena: that arena is zero-filled once before every backward run, so the
             # kernel needs no zero-fill launch of its own (EAB_NB_SUMS_ZEROED)
             sums = Ref("g", self.g_size)
-            self.g_size += self.nB * raw.C * 4 + ((-self.nB * raw.C * 4) % ALIGN)
+            self.g_size += NB_SUM_COPIES * self.nB * raw.C * 4 + ((-NB_SUM_COPIES * self.nB * raw.C * 4) % ALIGN)
             self.bwd.append(GenOp(OP_NORM_BWD, [d, raw.ref, mr, gam, bet, slp, sums, aux, dst,
                                                 self.gvec(f"{norm}.norm.weight") if norm else None,
                                                 self.gvec(f"{norm}.norm.bias") if norm else None, self.gvec(f"{act}.weight")],
@@ -661,7 +662,7 @@ class TrainLowering:
             d0, d1 = self.grad_of(outs[0]), self.grad_of(outs[1])
             dst, aux = self.grad_target(raw)
             sums = Ref("g", self.g_size)                                     # zero-filled with the gradient arena
-            self.g_size += self.nB * C * 4 + ((-self.nB * C * 4) % ALIGN)
+            self.g_size += NB_SUM_COPIES * self.nB * C * 4 + ((-NB_SUM_COPIES * self.nB * C * 4) % ALIGN)
             # (p[4], beta in the one-view form, carries the second view's gradient here: the PRELU_NORM backward never reads beta)
             self.bwd.append(GenOp(OP_NORM_BWD, [d0, raw.ref, mr, gam, d1, slp, sums, aux, dst, self.gadd([img_g]), self.gadd([img_b]),
                                                 self.gadd([img_s])], [self.nB, P, C, XF_PRELU_NORM | NB_SUMS_ZEROED, raw.C],

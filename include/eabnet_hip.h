@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EAB_ABI_VERSION 7
+#define EAB_ABI_VERSION 8
 
 #define EAB_OK          0
 #define EAB_EINVAL      1   /* bad argument (shape, alignment, limit) */
@@ -514,11 +514,14 @@ int eab_train_norm_act_f32(const float* x, const float* xf, const float* slope, 
                            int C, int mode, eab_stream_t stream);
 /* Backward of y = f(x) through the InstanceNorm statistics (per (b, c) over P) and the PReLU:
  *   dx = (acc_in ? acc_in : 0) + d loss / d x;   dgamma[c], dbeta[c], dslope[c] += their gradients.
- * sums: scratch [B][C][4]; OR-ing EAB_NB_SUMS_ZEROED into `mode` promises it is zero on entry (saves the zero-fill launch).
+ * sums: scratch [EAB_NB_SUM_COPIES][B][C][4] (the reduce pass spreads its atomics over the copies: hundreds of workgroups adding
+ * into the 24 words of one cache line cost more than reading the tensors); OR-ing EAB_NB_SUMS_ZEROED into `mode` promises it is
+ * zero on entry (saves the zero-fill launch).
  * mr == NULL (EAB_XF_NORM_PRELU only; eab_train_norm_act_f32: xf == NULL): no norm in front of the PReLU -- y = prelu(x),
  * dx = dy * prelu'(x), only dslope is accumulated (the plain U-Net's middle encoder layers, EaBNet.py:219-226).
  * Two launches (reduce, apply; the parameter gradients ride in the apply pass).  Reference: autograd of EaBNet.py:684-686 + nn.PReLU. */
 #define EAB_NB_SUMS_ZEROED 0x100
+#define EAB_NB_SUM_COPIES 8
 /* OR-ed into the `mode` of eab_train_norm_act_f32 (y) / eab_train_norm_bwd_f32 (dx; acc_in must be NULL) and passed as `flags`
  * to eab_glu_bwd_ex_f32 (dz): the OUTPUT tensor is stored as bf16 (2-byte elements, same shape, round to nearest even).  The
  * bf16 training programs set it for tensors that only bf16 contractions read (eab_conv_desc.src_bf16, eab_wgrad_desc.bf16_mask):
@@ -529,7 +532,8 @@ int eab_train_norm_bwd_f32(const float* dy, const float* x, const float* mr, con
                            float* dslope, int B, int P, int C, int mode, eab_stream_t stream);
 /* The same for the TWO units of the EAB_XF_PRELU_NORM order that read ONE xC-channel tensor x (forward:
  * eab_train_in1d_multi_f32): dy0 / dy1 [B][P][xC] = the views' output gradients; mr, gamma, slope, sums, dgamma, dbeta, dslope
- * [..][2 xC] view-major; dx [B][P][xC] = (acc_in) + both input gradients.  sums must be zero on entry. */
+ * [..][2 xC] view-major (sums: EAB_NB_SUM_COPIES copies, as above); dx [B][P][xC] = (acc_in) + both input gradients.  sums must be
+ * zero on entry. */
 int eab_train_norm_bwd_multi_f32(const float* dy0, const float* dy1, const float* x, const float* mr, const float* gamma,
                                  const float* slope, float* sums, const float* acc_in, float* dx, float* dgamma, float* dbeta,
                                  float* dslope, int B, int P, int xC, eab_stream_t stream);

@@ -144,7 +144,7 @@ def test_instance_norm_prelu_forward_and_backward(lib, mode, B, P, Cc):
         # statistics-only kernel over 16: the fp32 results agree to the last bit or two)
         for got_t, want_t, what in ((xf1, xf, "xf"), (mr1, mr, "mr"), (y1, yd, "y")):
             assert_close(got_t.cpu().numpy(), want_t.cpu().numpy(), 1e-6, f"in1d one launch: {what}")
-    sums = torch.full((B, Cc, 4), 7.0, device="cuda:0")
+    sums = torch.full((8, B, Cc, 4), 7.0, device="cuda:0")           # EAB_NB_SUM_COPIES copies of [B][C][4]
     acc = torch.randn(B, P, Cc, device="cuda:0")
     for acc_in in (None, acc):
         dx = torch.empty_like(xd)
