@@ -131,6 +131,8 @@ _SIGS = {
     "eab_layernorm64_bwd_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_longlong, C.c_void_p]),
     "eab_lstm64_train_fwd_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p]),
     "eab_lstm64_bwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
+    "eab_lstm64_train_fwd_prec_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
+    "eab_lstm64_bwd_prec_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
     "eab_wgrad_f32": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
     "eab_wgrad_batchable": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "eab_wgrad_batch_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

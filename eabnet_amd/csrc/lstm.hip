@@ -495,11 +495,23 @@ extern "C" int eab_lstm64_stream_f32(const float* x, const float* ln_g, const fl
 
 // Training forward: the same layer (no LayerNorm inside: the training program materialises it, its output is an
 // operand of the weight gradient) that also stores the activated gates and cell states, gates [B*F][T][5][64].
+int eab_lstm64_bf_train_launch(const float* x, const float* wcat, const float* bias, float* h_out, float* gates, int T, int F, int S,
+                               hipStream_t stream);     // lstm_h3.hip
+
 extern "C" int eab_lstm64_train_fwd_f32(const float* x, const float* wcat, const float* bias, float* h_out, float* gates, int B,
                                         int T, int F, eab_stream_t stream) {
+    return eab_lstm64_train_fwd_prec_f32(x, wcat, bias, h_out, gates, B, T, F, EAB_PREC_F32, stream);
+}
+
+// precision EAB_PREC_BF16: x_t, h_{t-1} and the weights rounded to bf16, one product on the 16-bit matrix cores, fp32
+// accumulation, activations, cell state and stored gates (the arithmetic of torch.autocast(bfloat16) on nn.LSTM)
+extern "C" int eab_lstm64_train_fwd_prec_f32(const float* x, const float* wcat, const float* bias, float* h_out, float* gates, int B,
+                                             int T, int F, int precision, eab_stream_t stream) {
     EAB_CHECK_ARG(x && wcat && bias && h_out && gates && B > 0 && T > 0 && F > 0);
+    EAB_CHECK_ARG(precision == EAB_PREC_F32 || precision == EAB_PREC_BF16);
     const long long S = (long long)B * F;
     EAB_CHECK_ARG(S * T * LS_H * 4 < (1ll << 31));
+    if (precision == EAB_PREC_BF16) return eab_lstm64_bf_train_launch(x, wcat, bias, h_out, gates, T, F, (int)S, eab_stream(stream));
     if (S <= 2048) {        // same split as the inference dispatcher: 4-sequence workgroups while they fit the chip in two rounds
         hipLaunchKernelGGL((lstm64_q_kernel<false, 1, true>), dim3((unsigned)((S + 3) / 4)), dim3(256), 0, eab_stream(stream), x,
                            nullptr, nullptr, 0.0f, wcat, bias, h_out, T, F, (int)S, nullptr, 0, nullptr, gates);

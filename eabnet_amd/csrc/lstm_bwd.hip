@@ -18,26 +18,44 @@
 #define LB_SEQ 16
 #define LB_LD (4 * LB_H + 4)      // dgates tile row: 256 floats + pad (odd 16-byte-slot stride)
 #define LB_OOB 0x80000000u
+#define LB_PF 3                    // steps of operands in flight in the reverse-time kernels
+
+#define LBB_ROW (4 * LB_H * 2 + 16) // the same tile as bf16: 512 bytes + pad (odd 16-byte-slot stride)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 lb_bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float lb_tanh(float x) { return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)), -1.0f); }
 
+// BF (the bf16 training programs): dgates_t and W_hh rounded to bf16, dh_rec on 8 v_mfma_f32_16x16x32_bf16 per wave instead of
+// 64 fp32 MFMAs of 32 cycles -- the recurrent product torch.autocast(bfloat16) runs for nn.LSTM's backward; the elementwise
+// chain, the carries and the dgates written for the weight / input gradients stay fp32.
+template <bool BF>
 __global__ __launch_bounds__(256) void lstm64_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ dh_out,
                                                          const float* __restrict__ wcat, float* __restrict__ dgates, int T, int F,
                                                          int S) {
     __shared__ __attribute__((aligned(16))) float dg[2][LB_SEQ * LB_LD];
+    __shared__ __attribute__((aligned(16))) char dgb[BF ? 2 : 1][BF ? LB_SEQ * LBB_ROW : 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ln = lane & 15, lk = lane >> 4;
     const int s0 = blockIdx.x * LB_SEQ;
     const int u = wave * 16 + ln;
 
     // stationary operand: whT[4j+s] = W_hh[k = 16j + 4lk + s][u] = wcat[k][64 + u]
-    float whT[64];
+    // (BF: B fragments of the 16x16x32 form: whb[kb][j] = W_hh[k = 32kb + 8lk + j][u])
+    float whT[BF ? 1 : 64];
+    lb_bf16x8 whb[BF ? 8 : 1];
+    if constexpr (BF) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
+        for (int kb = 0; kb < 8; ++kb)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) whT[4 * j + s] = wcat[(size_t)(16 * j + 4 * lk + s) * 128 + 64 + u];
+            for (int j = 0; j < 8; ++j) whb[kb][j] = (__bf16)wcat[(size_t)(32 * kb + 8 * lk + j) * 128 + 64 + u];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) whT[4 * j + s] = wcat[(size_t)(16 * j + 4 * lk + s) * 128 + 64 + u];
+    }
 
     // element role: unit u of sequences sq[r] = s0 + 4*lk + r
     size_t goff[4];       // float offset of gates[sq][0][0][u]
@@ -62,29 +80,39 @@ __global__ __launch_bounds__(256) void lstm64_bwd_kernel(const float* __restrict
     const size_t dg_t = (size_t)F * 4 * LB_H;
 
     float dhr[4] = {0.f, 0.f, 0.f, 0.f}, dcc[4] = {0.f, 0.f, 0.f, 0.f};
-    // values of step t in registers (loaded one step ahead)
-    float gi[4], gf[4], gg[4], go[4], ct[4], cp[4], du[4];
-    auto load = [&](int t, float (&i_)[4], float (&f_)[4], float (&g_)[4], float (&o_)[4], float (&c_)[4], float (&p_)[4],
-                    float (&d_)[4]) {
+    // operands of the next LB_PF steps in registers: every step touches new cache lines of gates / dh_out, and one step of
+    // lead (rounds 2-3) made the step time the memory latency
+    float pf[LB_PF][7][4];
+    auto load = [&](int t, float (&q)[7][4]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool v = ok[r] && t >= 0;
             const float* gp = gates + goff[r] + (size_t)(t >= 0 ? t : 0) * g_t;
-            i_[r] = v ? gp[0] : 0.f;
-            f_[r] = v ? gp[LB_H] : 0.f;
-            g_[r] = v ? gp[2 * LB_H] : 0.f;
-            o_[r] = v ? gp[3 * LB_H] : 0.f;
-            c_[r] = v ? gp[4 * LB_H] : 0.f;
-            p_[r] = (v && t > 0) ? *(gp - LB_H) : 0.f;          // c_{t-1}: slot 4 of step t-1 sits 64 floats below slot 0 of step t
-            d_[r] = v ? dh_out[hoff[r] + (size_t)(t >= 0 ? t : 0) * h_t] : 0.f;
+            q[0][r] = v ? gp[0] : 0.f;
+            q[1][r] = v ? gp[LB_H] : 0.f;
+            q[2][r] = v ? gp[2 * LB_H] : 0.f;
+            q[3][r] = v ? gp[3 * LB_H] : 0.f;
+            q[4][r] = v ? gp[4 * LB_H] : 0.f;
+            q[5][r] = (v && t > 0) ? *(gp - LB_H) : 0.f;        // c_{t-1}: slot 4 of step t-1 sits 64 floats below slot 0 of step t
+            q[6][r] = v ? dh_out[hoff[r] + (size_t)(t >= 0 ? t : 0) * h_t] : 0.f;
         }
     };
-    load(T - 1, gi, gf, gg, go, ct, cp, du);
+#pragma unroll
+    for (int k = 0; k < LB_PF; ++k) load(T - 1 - k, pf[k]);
 
-    for (int t = T - 1; t >= 0; --t) {
+    for (int t0 = T - 1; t0 >= 0; t0 -= LB_PF) {
+#pragma unroll
+      for (int k = 0; k < LB_PF; ++k) {
+        const int t = t0 - k;
+        if (t < 0) break;
         const int buf = t & 1;
-        float ni[4], nf[4], ng[4], no[4], nc[4], np[4], nd[4];
-        load(t - 1, ni, nf, ng, no, nc, np, nd);                      // next step's operands in flight
+        float gi[4], gf[4], gg[4], go[4], ct[4], cp[4], du[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            gi[r] = pf[k][0][r]; gf[r] = pf[k][1][r]; gg[r] = pf[k][2][r]; go[r] = pf[k][3][r];
+            ct[r] = pf[k][4][r]; cp[r] = pf[k][5][r]; du[r] = pf[k][6][r];
+        }
+        load(t - LB_PF, pf[k]);                                   // this slot's next use, LB_PF steps ahead
         // ---- elementwise: gate pre-activation gradients of step t
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -101,18 +129,34 @@ __global__ __launch_bounds__(256) void lstm64_bwd_kernel(const float* __restrict
             row[LB_H] = d_f;
             row[2 * LB_H] = d_g;
             row[3 * LB_H] = d_o;
+            if constexpr (BF) {
+                __bf16* rb = reinterpret_cast<__bf16*>(&dgb[buf][(4 * lk + r) * LBB_ROW]) + u;
+                rb[0] = (__bf16)d_i;
+                rb[LB_H] = (__bf16)d_f;
+                rb[2 * LB_H] = (__bf16)d_g;
+                rb[3 * LB_H] = (__bf16)d_o;
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         // ---- dh_rec = dgates_t . W_hh   (four accumulation chains)
         f32x4 acc[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* arow = &dg[buf][ln * LB_LD + 4 * lk];
+        if constexpr (BF) {
+            // A fragments: lane (m = ln, kq = lk) holds k = 32*kb + 8*kq + j
+            const char* ab = &dgb[buf][ln * LBB_ROW + lk * 16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * j);
+            for (int kb = 0; kb < 8; ++kb)
+                acc[kb & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const lb_bf16x8*>(ab + kb * 64), whb[kb], acc[kb & 3],
+                                                                     0, 0, 0);
+        } else {
+            const float* arow = &dg[buf][ln * LB_LD + 4 * lk];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc[j & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], whT[4 * j + s], acc[j & 3], 0, 0, 0);
+            for (int j = 0; j < 16; ++j) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * j);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[j & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], whT[4 * j + s], acc[j & 3], 0, 0, 0);
+            }
         }
         // ---- coalesced write-back of the dgates tile: 1 KB per sequence row
         if (wok) {
@@ -122,10 +166,8 @@ __global__ __launch_bounds__(256) void lstm64_bwd_kernel(const float* __restrict
             for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dst + 4 * q) = *reinterpret_cast<const f32x4*>(src + 4 * q);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            dhr[r] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
-            gi[r] = ni[r]; gf[r] = nf[r]; gg[r] = ng[r]; go[r] = no[r]; ct[r] = nc[r]; cp[r] = np[r]; du[r] = nd[r];
-        }
+        for (int r = 0; r < 4; ++r) dhr[r] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+      }
     }
 }
 
@@ -162,24 +204,29 @@ __global__ __launch_bounds__(256) void lstm64_bwd_q_kernel(const float* __restri
     for (int kk = 0; kk < 64; ++kk) wh[kk] = wcat[(size_t)(64 * wave + kk) * 128 + 64 + lane];
 
     float dhr = 0.f, dcc = 0.f;
-    float gi, gf, gg, go, ct, cp, du;
-    auto load = [&](int t, float& i_, float& f_, float& g_, float& o_, float& c_, float& p_, float& d_) {
+    float pf[LB_PF][7];                                            // (i, f, g, o, c_t, c_{t-1}, dh_out) of the next LB_PF steps
+    auto load = [&](int t, float (&q)[7]) {
         const bool v = ok && t >= 0;
         const float* gp = gates + goff + (size_t)(t >= 0 ? t : 0) * g_t;
-        i_ = v ? gp[0] : 0.f;
-        f_ = v ? gp[LB_H] : 0.f;
-        g_ = v ? gp[2 * LB_H] : 0.f;
-        o_ = v ? gp[3 * LB_H] : 0.f;
-        c_ = v ? gp[4 * LB_H] : 0.f;
-        p_ = (v && t > 0) ? *(gp - LB_H) : 0.f;                     // c_{t-1}
-        d_ = v ? dh_out[hoff + (size_t)(t >= 0 ? t : 0) * h_t] : 0.f;
+        q[0] = v ? gp[0] : 0.f;
+        q[1] = v ? gp[LB_H] : 0.f;
+        q[2] = v ? gp[2 * LB_H] : 0.f;
+        q[3] = v ? gp[3 * LB_H] : 0.f;
+        q[4] = v ? gp[4 * LB_H] : 0.f;
+        q[5] = (v && t > 0) ? *(gp - LB_H) : 0.f;                   // c_{t-1}
+        q[6] = v ? dh_out[hoff + (size_t)(t >= 0 ? t : 0) * h_t] : 0.f;
     };
-    load(T - 1, gi, gf, gg, go, ct, cp, du);
+#pragma unroll
+    for (int k = 0; k < LB_PF; ++k) load(T - 1 - k, pf[k]);
 
-    for (int t = T - 1; t >= 0; --t) {
+    for (int t0 = T - 1; t0 >= 0; t0 -= LB_PF) {
+#pragma unroll
+      for (int k = 0; k < LB_PF; ++k) {
+        const int t = t0 - k;
+        if (t < 0) break;
         const int buf = t & 1;
-        float ni, nf, ng, no, nc, np, nd;
-        load(t - 1, ni, nf, ng, no, nc, np, nd);
+        const float gi = pf[k][0], gf = pf[k][1], gg = pf[k][2], go = pf[k][3], ct = pf[k][4], cp = pf[k][5], du = pf[k][6];
+        load(t - LB_PF, pf[k]);
         {   // same expressions as the 16-sequence kernel
             const float dh = du + dhr;
             const float tc = lb_tanh(ct);
@@ -214,21 +261,35 @@ __global__ __launch_bounds__(256) void lstm64_bwd_q_kernel(const float* __restri
             *reinterpret_cast<f32x4*>(dgates + dg_base + (size_t)t * dg_t) = *reinterpret_cast<const f32x4*>(&dg[buf][es * LBQ_LD + eu * 4]);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         dhr = (part[0][es][eu] + part[1][es][eu]) + (part[2][es][eu] + part[3][es][eu]);
-        gi = ni; gf = nf; gg = ng; go = no; ct = nc; cp = np; du = nd;
+      }
     }
 }
 
 extern "C" int eab_lstm64_bwd_f32(const float* gates, const float* dh_out, const float* wcat, float* dgates, int B, int T, int F,
                                   eab_stream_t stream) {
+    return eab_lstm64_bwd_prec_f32(gates, dh_out, wcat, dgates, B, T, F, EAB_PREC_F32, stream);
+}
+
+extern "C" int eab_lstm64_bwd_prec_f32(const float* gates, const float* dh_out, const float* wcat, float* dgates, int B, int T, int F,
+                                       int precision, eab_stream_t stream) {
     EAB_CHECK_ARG(gates && dh_out && wcat && dgates && B > 0 && T > 0 && F > 0);
+    EAB_CHECK_ARG(precision == EAB_PREC_F32 || precision == EAB_PREC_BF16);
     const long long S = (long long)B * F;
     EAB_CHECK_ARG(S * T * 5 * LB_H < (1ll << 40));
+    // bf16: a step of the 16-sequence form is 8 short MFMAs instead of 64 long ones (742 vs 1004 us per layer at 2576 sequences);
+    // up to 2048 sequences the 4-sequence fp32 kernel below is faster than either (655 vs 926 us at 966: four times the
+    // workgroups, a quarter of the elementwise chain per lane) and exact, so small batches take it in every mode
+    if (precision == EAB_PREC_BF16 && S > 2048) {
+        hipLaunchKernelGGL(lstm64_bwd_kernel<true>, dim3((unsigned)((S + LB_SEQ - 1) / LB_SEQ)), dim3(256), 0, eab_stream(stream), gates,
+                           dh_out, wcat, dgates, T, F, (int)S);
+        EAB_RETURN_LAUNCH_STATUS();
+    }
     if (S <= 2048) {
         hipLaunchKernelGGL(lstm64_bwd_q_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, eab_stream(stream), gates, dh_out, wcat,
                            dgates, T, F, (int)S);
         EAB_RETURN_LAUNCH_STATUS();
     }
     const int grid = (int)((S + LB_SEQ - 1) / LB_SEQ);
-    hipLaunchKernelGGL(lstm64_bwd_kernel, dim3(grid), dim3(256), 0, eab_stream(stream), gates, dh_out, wcat, dgates, T, F, (int)S);
+    hipLaunchKernelGGL(lstm64_bwd_kernel<false>, dim3(grid), dim3(256), 0, eab_stream(stream), gates, dh_out, wcat, dgates, T, F, (int)S);
     EAB_RETURN_LAUNCH_STATUS();
 }

@@ -63,12 +63,13 @@ __device__ __forceinline__ float lh_join(unsigned short hi, unsigned short lo) {
     return (float)__builtin_bit_cast(_Float16, hi) + (float)__builtin_bit_cast(_Float16, lo);
 }
 
-template <bool LN, bool BF>
+template <bool LN, bool BF, bool DUMP = false>
 __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict__ x, const float* __restrict__ ln_g,
                                                         const float* __restrict__ ln_b, float ln_eps,
                                                         const float* __restrict__ wcat, const float* __restrict__ bias,
                                                         float* __restrict__ h_out, int T, int F, int S,
-                                                        const int* __restrict__ t_pos, int t_count, float* __restrict__ c_state) {
+                                                        const int* __restrict__ t_pos, int t_count, float* __restrict__ c_state,
+                                                        float* __restrict__ gates = nullptr) {
     using v8 = std::conditional_t<BF, bf16x8, h16x8>;
     using e16 = std::conditional_t<BF, __bf16, _Float16>;
     __shared__ __attribute__((aligned(16))) char xs[2][LH_SEQ * LH_ROW];
@@ -213,6 +214,15 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
         const int b = sq < S ? sq / F : 0, f = sq < S ? sq - b * F : 0;
         hdir[r] = sq < S ? (unsigned)((((size_t)b * T * F + f) * 64 + u) * 4) : LH_OOB;
     }
+    // training (DUMP): gates[seq][t][5][64] = activated i, f, g, o and the cell state (the layout csrc/lstm_bwd.hip reads)
+    float* gdump[4];
+    if (DUMP) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int sq = s0 + 4 * lk + r;
+            gdump[r] = sq < S ? gates + ((size_t)sq * T * 5) * 64 + u : nullptr;
+        }
+    }
     for (int t = t_lo; t < t_hi; ++t) {
         const int cur = (t - t_lo) & 1, nxt = cur ^ 1;
         const f32x4 xn = load_x(t + 4);
@@ -237,6 +247,14 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
             const float og = lh_sigmoid(acc[3][r]);
             cst[r] = fmaf(fg, cst[r], ig * gg);
             const float h = og * lh_tanh(cst[r]);
+            if (DUMP && gdump[r]) {
+                float* gp = gdump[r] + (size_t)t * 320;
+                gp[0] = ig;
+                gp[64] = fg;
+                gp[128] = gg;
+                gp[192] = og;
+                gp[256] = cst[r];
+            }
             const e16 hi = (e16)h;
             *reinterpret_cast<e16*>(hrow + (4 * lk + r) * LH_ROW) = hi;
             if (BF) {
@@ -272,6 +290,15 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
         for (int r = 0; r < 4; ++r)
             if (s0 + 4 * lk + r < S) c_state[(size_t)(s0 + 4 * lk + r) * 64 + u] = cst[r];
     }
+}
+
+// training forward in bf16 (eab_lstm64_train_fwd_prec_f32, csrc/lstm.hip): the bf16 kernel that also stores the gates
+int eab_lstm64_bf_train_launch(const float* x, const float* wcat, const float* bias, float* h_out, float* gates, int T, int F, int S,
+                               hipStream_t stream) {
+    const int grid = (S + LH_SEQ - 1) / LH_SEQ;
+    hipLaunchKernelGGL((lstm64_h3_kernel<false, true, true>), dim3(grid), dim3(256), 0, stream, x, nullptr, nullptr, 0.0f, wcat, bias,
+                       h_out, T, F, S, nullptr, 0, nullptr, gates);
+    EAB_RETURN_LAUNCH_STATUS();
 }
 
 // dispatcher shared with csrc/lstm.hip

@@ -180,10 +180,10 @@ extern "C" int eab_run_program(const eab_op* ops, int n_ops, eab_stream_t stream
                                              stream);
                 break;
             case EAB_OP_LSTM_TRAIN:
-                rc = eab_lstm64_train_fwd_f32(EAB_P(0), EAB_P(1), EAB_P(2), EAB_W(3), EAB_W(4), o.i[0], o.i[1], o.i[2], stream);
+                rc = eab_lstm64_train_fwd_prec_f32(EAB_P(0), EAB_P(1), EAB_P(2), EAB_W(3), EAB_W(4), o.i[0], o.i[1], o.i[2], o.i[3], stream);
                 break;
             case EAB_OP_LSTM_BWD:
-                rc = eab_lstm64_bwd_f32(EAB_P(0), EAB_P(1), EAB_P(2), EAB_W(3), o.i[0], o.i[1], o.i[2], stream);
+                rc = eab_lstm64_bwd_prec_f32(EAB_P(0), EAB_P(1), EAB_P(2), EAB_W(3), o.i[0], o.i[1], o.i[2], o.i[3], stream);
                 break;
             case EAB_OP_GAG_CRM_BWD:
                 rc = eab_gag_crm_bwd_f32(EAB_P(0), EAB_P(1), EAB_P(2), EAB_P(3), EAB_P(4), EAB_W(5), EAB_W(6), EAB_W(7), EAB_W(8), o.i[0],

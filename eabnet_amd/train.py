@@ -172,8 +172,12 @@ class TrainLowering:
     def __init__(self, cfg, B: int, T: int, F: int = 161, precision: str = "f32"):
         if precision not in ("f32", "bf16"):
             raise ValueError("training precision is 'f32' or 'bf16' (bf16: forward, dgrad and wgrad contractions on the bf16 "
-                             "matrix cores with fp32 accumulation; LSTM, norms, gradients and the optimiser state stay fp32)")
+                             "matrix cores with fp32 accumulation -- the LSTM's recurrent products included; cell state, norms, "
+                             "gradients and the optimiser state stay fp32)")
         self.prec = prg.PREC_CODE[precision]
+        # bf16 programs: the LSTM's recurrent products on the bf16 matrix cores too (what torch.autocast does for nn.LSTM);
+        # EAB_BF16_LSTM=0 keeps the fp32 recurrence of rounds 2-3
+        self.lstm_prec = prg.PREC_BF16 if (self.prec == prg.PREC_BF16 and os.environ.get("EAB_BF16_LSTM", "1") != "0") else prg.PREC_F32
         # small-tile kernel (csrc/conv_st.hip) for the 1-D convolutions of the S-TCMs and their dgrads
         self.st = os.environ.get("EAB_ST", "1") != "0"
         if not self.supports(cfg):
@@ -812,7 +816,7 @@ class TrainLowering:
             wcat = self.wadd(f"{p}.wcat", wcat_img)
             bias = self.wadd(f"{p}.bias", self.idx(f"{p}.bias_ih_l0"), self.idx(f"{p}.bias_hh_l0"))
             h, gates = self.act(F, 64), self.alloc(rows * 5 * 64)
-            self.fwd.append(GenOp(OP_LSTM_TRAIN, [h_in.ref, wcat, bias, h.ref, gates], [B, T, F], name=p))
+            self.fwd.append(GenOp(OP_LSTM_TRAIN, [h_in.ref, wcat, bias, h.ref, gates], [B, T, F, self.lstm_prec], name=p))
             self.flops_fwd += 2 * rows * 256 * 128
             layers.append((p, h_in, h, gates, wcat))
             self.gtaps[p] = h
@@ -858,7 +862,7 @@ class TrainLowering:
             self.dgrad("w_dnn.0.dgrad", h2, dpre, 64, F, [(self.wadd("w_dnn.0.wd", w1d), F, 1, 0, 1, [0], [0])])
             for p, hin, h, gates, wcat in reversed(layers):
                 dg = self.alloc(rows * 256)
-                self.bwd.append(GenOp(OP_LSTM_BWD, [gates, self.grad_of(h), wcat, dg], [B, T, F], name=p + ".bwd"))
+                self.bwd.append(GenOp(OP_LSTM_BWD, [gates, self.grad_of(h), wcat, dg], [B, T, F, self.lstm_prec], name=p + ".bwd"))
                 self.flops_bwd += 2 * rows * 256 * 64
                 self.wgrad_op(p + ".wgrad_ih", dg, 256, F, [hin], F, 1, 0, 1, [0], [0], self.idx(f"{p}.weight_ih_l0"),
                               dbias=self.gadd([self.idx(f"{p}.bias_ih_l0"), self.idx(f"{p}.bias_hh_l0")]))

@@ -569,6 +569,14 @@ int eab_lstm64_train_fwd_f32(const float* x, const float* wcat, const float* bia
                              int F, eab_stream_t stream);
 int eab_lstm64_bwd_f32(const float* gates, const float* dh_out, const float* wcat, float* dgates, int B, int T, int F,
                        eab_stream_t stream);
+/* the same with `precision` EAB_PREC_F32 or EAB_PREC_BF16 (the bf16 training programs, BASELINE configs[3]): the recurrent
+ * products -- [x_t | h_{t-1}] W in the forward, dgates_t W_hh in the backward -- take their operands rounded to bf16 on the
+ * 16-bit matrix cores with fp32 accumulation, as torch.autocast(bfloat16) runs nn.LSTM; activations, cell state, carries and
+ * every stored tensor stay fp32. */
+int eab_lstm64_train_fwd_prec_f32(const float* x, const float* wcat, const float* bias, float* h_out, float* gates, int B, int T,
+                                  int F, int precision, eab_stream_t stream);
+int eab_lstm64_bwd_prec_f32(const float* gates, const float* dh_out, const float* wcat, float* dgates, int B, int T, int F,
+                            int precision, eab_stream_t stream);
 
 /* Weight gradient on fp32 MFMA:
  *   dw[n][tap*UPT*16 + c] += sum_{b,t,o} dz[b][t][o*ostride+ophase][n] * src[b][t+dt_tap][o*istride+ioff_tap][c]

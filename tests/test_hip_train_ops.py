@@ -276,11 +276,83 @@ def test_lstm_training_forward_and_reverse_time_kernel(lib, B, T, Fq):
         assert_close(got.numpy(), want.numpy(), TOL, f"wgrad {name}")
 
 
-# ---------------------------------------------------------------------------------------------------
-# bf16-STORED operands (round 4): the bf16 training programs store the tensors only bf16 contractions read as bf16
-# (eab_conv_desc.src_bf16, eab_wgrad_desc.bf16_mask, EAB_STORE_BF16).  The contraction kernels round fp32 operands to bf16
-# on their way into LDS, so feeding them the already-rounded tensor must give the same numbers.
-# ---------------------------------------------------------------------------------------------------
+def _bf(t):
+    """round to bf16 (nearest even) and back, in the tensor's own dtype"""
+    return t.float().bfloat16().to(t.dtype)
+
+
+@pytest.mark.parametrize("B,T,Fq", [(1, 9, 21), (2, 40, 161), (13, 7, 161)])      # the last: > 2048 sequences
+def test_lstm_training_kernels_in_bf16(lib, B, T, Fq):
+    """The bf16 training programs run the LSTM's recurrent products on the bf16 matrix cores (precision EAB_PREC_BF16 of
+    eab_lstm64_train_fwd_prec_f32 / eab_lstm64_bwd_prec_f32): operands rounded to bf16, everything else fp32.  Reference: the same
+    recurrences in fp64 with exactly those roundings -- forward [x_t | h_{t-1}] and W, backward dgates_t and W_hh --, the backward
+    fed with the kernel's own stored gates (above 2048 sequences; below, the reverse pass is the fp32 kernel in every mode); and the
+    result stays within bf16 distance of the exact layer."""
+    g = torch.Generator().manual_seed(11)
+    lstm = torch.nn.LSTM(64, 64, batch_first=True).double()
+    S = B * Fq
+    x = torch.randn(S, T, 64, generator=g, dtype=torch.float64)
+    dh = torch.randn(S, T, 64, generator=g, dtype=torch.float64)
+    w_ih, w_hh = lstm.weight_ih_l0.detach(), lstm.weight_hh_l0.detach()
+    bias = (lstm.bias_ih_l0 + lstm.bias_hh_l0).detach()
+    wcat = torch.cat((w_ih, w_hh), 1)
+    to_btf = lambda t: t.detach().view(B, Fq, T, -1).permute(0, 2, 1, 3)      # noqa: E731
+    xd, dhd, wd, bd = _dev(to_btf(x)), _dev(to_btf(dh)), _dev(wcat), _dev(bias)
+    hd = torch.empty(B, T, Fq, 64, device="cuda:0")
+    gates = torch.empty(S, T, 5, 64, device="cuda:0")
+    _ck(lib.eab_lstm64_train_fwd_prec_f32(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), hd.data_ptr(), gates.data_ptr(), B, T, Fq, 2, _st()))
+    # forward reference with the kernel's roundings (the device holds fp32 x and weights: round THOSE)
+    xr, wir, whr = _bf(xd.cpu().permute(0, 2, 1, 3).reshape(S, T, 64)).double(), _bf(wd.cpu()[:, :64]).double(), _bf(wd.cpu()[:, 64:]).double()
+    bf = bd.cpu().double()
+    h, c = torch.zeros(S, 64, dtype=torch.float64), torch.zeros(S, 64, dtype=torch.float64)
+    hs, gs = [], []
+    for t in range(T):
+        pre = xr[:, t] @ wir.T + _bf(h.float()).double() @ whr.T + bf
+        i, f, gg, o = torch.sigmoid(pre[:, :64]), torch.sigmoid(pre[:, 64:128]), torch.tanh(pre[:, 128:192]), torch.sigmoid(pre[:, 192:])
+        c = f * c + i * gg
+        h = o * torch.tanh(c)
+        hs.append(h)
+        gs.append(torch.stack((i, f, gg, o, c), 1))
+    h_ref, g_ref = torch.stack(hs, 1), torch.stack(gs, 1)                     # (S, T, 64), (S, T, 5, 64)
+    h_got = hd.cpu().double().permute(0, 2, 1, 3).reshape(S, T, 64)
+    # (a value that lands on the other side of a bf16 rounding boundary of h_{t-1} moves the next step by 2^-9 of one operand)
+    assert_close(h_got.numpy(), h_ref.numpy(), 2e-3, "h (bf16 recurrence)", tol_max=1e-2)
+    assert_close(gates.cpu().double().numpy(), g_ref.numpy(), 2e-3, "stored gates", tol_max=1e-2)
+    h_exact, _ = lstm(x)
+    err = float((h_got - h_exact.detach()).norm() / h_exact.detach().norm())
+    assert 1e-4 < err < 2e-2, err                                             # really bf16 products, and no worse than bf16
+    # backward: the reverse recurrence on the kernel's own gates, dgates and W_hh rounded for the recurrent product
+    dg = torch.empty(B, T, Fq, 256, device="cuda:0")
+    _ck(lib.eab_lstm64_bwd_prec_f32(gates.data_ptr(), dhd.data_ptr(), wd.data_ptr(), dg.data_ptr(), B, T, Fq, 2, _st()))
+    torch.cuda.synchronize()
+    gk = gates.cpu().double()
+    dhq = dhd.cpu().double().permute(0, 2, 1, 3).reshape(S, T, 64)
+    dhr, dcc = torch.zeros(S, 64, dtype=torch.float64), torch.zeros(S, 64, dtype=torch.float64)
+    want = torch.zeros(S, T, 256, dtype=torch.float64)
+    for t in range(T - 1, -1, -1):
+        i, f, gg, o, c = (gk[:, t, k] for k in range(5))
+        cp = gk[:, t - 1, 4] if t > 0 else torch.zeros_like(c)
+        d = dhq[:, t] + dhr
+        tc = torch.tanh(c)
+        d_o = d * tc * o * (1 - o)
+        dc = dcc + d * o * (1 - tc * tc)
+        d_i, d_g, d_f = dc * gg * i * (1 - i), dc * i * (1 - gg * gg), dc * cp * f * (1 - f)
+        dcc = dc * f
+        want[:, t] = torch.cat((d_i, d_f, d_g, d_o), 1)
+        dhr = _bf(want[:, t].float()).double() @ whr
+    dgc = dg.cpu().double().permute(0, 2, 1, 3).reshape(S, T, 256)
+    dg32 = torch.empty_like(dg)
+    _ck(lib.eab_lstm64_bwd_f32(gates.data_ptr(), dhd.data_ptr(), wd.data_ptr(), dg32.data_ptr(), B, T, Fq, _st()))
+    torch.cuda.synchronize()
+    if S > 2048:
+        assert_close(dgc.numpy(), want.numpy(), 2e-3, "dgates (bf16 recurrence)", tol_max=1e-2)
+        err = float((dg - dg32).norm() / dg32.norm())
+        assert 1e-5 < err < 2e-2, err                     # bf16 distance from the fp32 kernel on the same gates, not more
+    else:
+        # up to 2048 sequences the reverse pass takes the 4-sequence fp32 kernel in every mode (faster there, and exact)
+        assert torch.equal(dg, dg32)
+
+
 def _wgrad_masked(lib, dz, src0, src1, N, Kpad, B, T, Fin, Fz, No, ostride, ophase, istride, dt, ioff, mask, C0, C1, dbias=None):
     from eabnet_amd import _lib
     d = _lib.WgradDesc()

@@ -197,3 +197,19 @@ def test_bf16_storage_is_assigned_only_where_nothing_but_bf16_contractions_read(
     monkeypatch.setenv("EAB_BF16_STORE", "0")
     w0, r0 = flagged(train.lower_train(cfg, 2, 20, 161, "bf16"))
     assert not w0 and not r0
+
+
+def test_bf16_programs_run_the_lstm_products_in_bf16(monkeypatch):
+    """precision word of the two LSTM ops (eab_lstm64_train_fwd_prec_f32 / eab_lstm64_bwd_prec_f32): bf16 in a bf16 program,
+    fp32 in an fp32 program and with EAB_BF16_LSTM=0 (the rounds 2-3 arithmetic, kept as the A/B switch)."""
+    cfg = replace(spec.NetConfig(), M=4, p=2, q=1)
+
+    def precs(prog):
+        ops = [op for op in prog.fwd + prog.bwd if isinstance(op, train.GenOp) and op.kind in (train.OP_LSTM_TRAIN, train.OP_LSTM_BWD)]
+        assert len(ops) == 4 and all(len(op.i) == 4 for op in ops)
+        return {op.i[3] for op in ops}
+    monkeypatch.delenv("EAB_BF16_LSTM", raising=False)
+    assert precs(train.lower_train(cfg, 2, 20, 161, "bf16")) == {prg.PREC_BF16}
+    assert precs(train.lower_train(cfg, 2, 20, 161, "f32")) == {prg.PREC_F32}
+    monkeypatch.setenv("EAB_BF16_LSTM", "0")
+    assert precs(train.lower_train(cfg, 2, 20, 161, "bf16")) == {prg.PREC_F32}
