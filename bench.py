@@ -369,7 +369,13 @@ def train_measure(rank, world, dev, is_dist, *, precision="f32", two_stage=False
                     res[which]["ms_total"] += wg_ms - float(ms[wg].sum())
                     res[which]["ms_by_kernel"]["wgrad"] = round(wg_ms, 3)
                     res[which]["ms_by_kernel"]["wgrad (one launch per descriptor)"] = round(float(ms[wg].sum()), 3)
-                    wg_by = sum(4.0 * o.B * o.T * o.No * (o.N + len(o.dt) * (o.C0 + o.C1)) for o in ops if o.kind == tr.OP_WGRAD)
+                    # operand bytes as they are STORED (bf16-stored operands, eab_wgrad_desc.bf16_mask, are two bytes each)
+                    def wbytes(o):
+                        m = getattr(o, "bf16_mask", 0)
+                        return float(o.B * o.T * o.No) * (o.N * (2 if m & 1 else 4)
+                                                          + len(o.dt) * (o.C0 * (2 if m & 2 else 4) + o.C1 * (2 if m & 4 else 4)))
+                    wg_by = sum(wbytes(o) for o in ops if o.kind == tr.OP_WGRAD)
+                    wg_by32 = sum(4.0 * o.B * o.T * o.No * (o.N + len(o.dt) * (o.C0 + o.C1)) for o in ops if o.kind == tr.OP_WGRAD)
                     if net.precision == "bf16":
                         # bf16 products: the matrix work is 1/16 of the fp32 form's, the kernel is bound by its operand traffic
                         # (rows x (N + taps x C) x 4 B per descriptor: dz once, the gathered activations once per tap) and by the
@@ -379,8 +385,12 @@ def train_measure(rank, world, dev, is_dist, *, precision="f32", two_stage=False
                                            "frac": wg_by / (wg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
                                            "achieved_tflops": wg_fl / (wg_ms * 1e-3) / 1e12,
                                            "weight_gradients_per_step": len(wg), "launches_per_step": launches, "ms_per_step": wg_ms,
-                                           "note": "all weight gradients of the step: algorithmic operand bytes / HIP-event time of the "
-                                                   "block as it runs in production (descriptors of identical geometry share a launch)"}
+                                           "bf16_stored_operand_descriptors": sum(1 for k in wg if getattr(ops[k], "bf16_mask", 0)),
+                                           "achieved_if_all_operands_were_fp32": wg_by32 / (wg_ms * 1e-3) / 1e9,
+                                           "note": "all weight gradients of the step: operand bytes as stored (bf16-stored operands two "
+                                                   "bytes; dz once, the gathered activations once per tap) / HIP-event time of the block as "
+                                                   "it runs in production (descriptors of identical geometry share a launch).  The kernel "
+                                                   "is not byte-bound: halving operands did not shorten it (DESIGN.md, round 4 item 3)"}
                     else:
                         out["roofline"] = {"kernel": "wgrad_kernel (fp32 MFMA 32x32x2, split-K, atomics)", "bound": "mfma",
                                            "achieved": wg_fl / (wg_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -63,7 +63,10 @@ __device__ __forceinline__ float lh_join(unsigned short hi, unsigned short lo) {
     return (float)__builtin_bit_cast(_Float16, hi) + (float)__builtin_bit_cast(_Float16, lo);
 }
 
-template <bool LN, bool BF, bool DUMP = false>
+// NS = 8 (bf16 training at small batches): 8 sequences per workgroup in tile rows 4q + {0, 1}, so that every lane still owns
+// sequences (two instead of four: half the exp / rcp chain of the cell update per step, twice the workgroups); rows 4q + {2, 3}
+// are padding the MFMAs carry along.
+template <bool LN, bool BF, bool DUMP = false, int NS = LH_SEQ>
 __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict__ x, const float* __restrict__ ln_g,
                                                         const float* __restrict__ ln_b, float ln_eps,
                                                         const float* __restrict__ wcat, const float* __restrict__ bias,
@@ -76,7 +79,11 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
     __shared__ __attribute__((aligned(16))) char hs[2][LH_SEQ * LH_ROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ln = lane & 15, lk = lane >> 4;
-    const int s0 = blockIdx.x * LH_SEQ;
+    static_assert(NS == LH_SEQ || (NS == 8 && BF), "the 8-sequence form exists for the bf16 kernel only");
+    constexpr int NR = NS == LH_SEQ ? 4 : 2;                  // sequences per lane
+    // tile row -> sequence of this workgroup (or -1: padding)
+    auto row_seq = [](int row) { return NS == LH_SEQ ? row : ((row & 3) < 2 ? (row >> 2) * 2 + (row & 1) : -1); };
+    const int s0 = blockIdx.x * NS;
     // streaming (eab_time_window): steps [t_lo, t_hi) only
     const int t_lo = t_pos ? *t_pos : 0;
     const int t_hi = t_pos ? (t_lo + t_count < T ? t_lo + t_count : T) : T;
@@ -108,8 +115,8 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
 
     // ---- loader role: thread -> (sequence ls, channels lc..lc+3)
     const int ls = tid >> 4, lc = (tid & 15) * 4;
-    const int sg = s0 + ls;
-    const bool sv = sg < S;
+    const int sg = s0 + row_seq(ls);
+    const bool sv = row_seq(ls) >= 0 && sg < S;
     const int sb = sv ? sg / F : 0, sf = sv ? sg - sb * F : 0;
     const unsigned total_bytes = (unsigned)S * (unsigned)T * 256u;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, total_bytes, 0x00020000);
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
 
     // prologue: h_{t_lo-1} (0 at the start of the utterance; hi and lo), c_{t_lo-1}, x_{t_lo} / x_{t_lo+1} in LDS,
     // accx = b + W_x x_{t_lo}
-    for (int e = tid; e < LH_SEQ * LH_ROW / 4; e += 256) reinterpret_cast<unsigned*>(hs[0])[e] = 0u;
+    for (int e = tid; e < 2 * LH_SEQ * LH_ROW / 4; e += 256) reinterpret_cast<unsigned*>(hs[0])[e] = 0u;     // (both buffers)
     __syncthreads();
     if (t_lo > 0) {
         const f32x4 hp = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
@@ -186,8 +193,8 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
     float cst[4] = {0.f, 0.f, 0.f, 0.f};
     if (c_state && t_lo > 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (s0 + 4 * lk + r < S) cst[r] = c_state[(size_t)(s0 + 4 * lk + r) * 64 + uq];
+        for (int r = 0; r < NR; ++r)
+            if (s0 + row_seq(4 * lk + r) < S) cst[r] = c_state[(size_t)(s0 + row_seq(4 * lk + r)) * 64 + uq];
     }
     __syncthreads();
     f32x4 accx[4];
@@ -209,8 +216,8 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
     // very value the offline run rounded): byte offsets of (sequence 4*lk + r, unit u)
     unsigned hdir[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int sq = s0 + 4 * lk + r;
+    for (int r = 0; r < NR; ++r) {
+        const int sq = s0 + row_seq(4 * lk + r);
         const int b = sq < S ? sq / F : 0, f = sq < S ? sq - b * F : 0;
         hdir[r] = sq < S ? (unsigned)((((size_t)b * T * F + f) * 64 + u) * 4) : LH_OOB;
     }
@@ -218,8 +225,8 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
     float* gdump[4];
     if (DUMP) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int sq = s0 + 4 * lk + r;
+        for (int r = 0; r < NR; ++r) {
+            const int sq = s0 + row_seq(4 * lk + r);
             gdump[r] = sq < S ? gates + ((size_t)sq * T * 5) * 64 + u : nullptr;
         }
     }
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
         __builtin_amdgcn_sched_barrier(0);
         char* hrow = &hs[nxt][hcol];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {                   // lane holds unit u for sequences 4*lk + r
+        for (int r = 0; r < NR; ++r) {                  // lane holds unit u for the sequences of tile rows 4*lk + r
             const float ig = lh_sigmoid(acc[0][r]);
             const float fg = lh_sigmoid(acc[1][r]);
             const float gg = lh_tanh(acc[2][r]);
@@ -287,17 +294,22 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
     }
     if (c_state) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (s0 + 4 * lk + r < S) c_state[(size_t)(s0 + 4 * lk + r) * 64 + u] = cst[r];
+        for (int r = 0; r < NR; ++r)
+            if (s0 + row_seq(4 * lk + r) < S) c_state[(size_t)(s0 + row_seq(4 * lk + r)) * 64 + u] = cst[r];
     }
 }
 
 // training forward in bf16 (eab_lstm64_train_fwd_prec_f32, csrc/lstm.hip): the bf16 kernel that also stores the gates
 int eab_lstm64_bf_train_launch(const float* x, const float* wcat, const float* bias, float* h_out, float* gates, int T, int F, int S,
                                hipStream_t stream) {
-    const int grid = (S + LH_SEQ - 1) / LH_SEQ;
-    hipLaunchKernelGGL((lstm64_h3_kernel<false, true, true>), dim3(grid), dim3(256), 0, stream, x, nullptr, nullptr, 0.0f, wcat, bias,
-                       h_out, T, F, S, nullptr, 0, nullptr, gates);
+    // up to 2048 sequences (the training batch of configs[3] is 966): 8 sequences per workgroup -- the step is the cell update's
+    // exp / rcp chain per lane, not the 16 MFMAs, and twice the workgroups halve it
+    if (S <= 2048)
+        hipLaunchKernelGGL((lstm64_h3_kernel<false, true, true, 8>), dim3((S + 7) / 8), dim3(256), 0, stream, x, nullptr, nullptr, 0.0f,
+                           wcat, bias, h_out, T, F, S, nullptr, 0, nullptr, gates);
+    else
+        hipLaunchKernelGGL((lstm64_h3_kernel<false, true, true>), dim3((S + LH_SEQ - 1) / LH_SEQ), dim3(256), 0, stream, x, nullptr,
+                           nullptr, 0.0f, wcat, bias, h_out, T, F, S, nullptr, 0, nullptr, gates);
     EAB_RETURN_LAUNCH_STATUS();
 }
 

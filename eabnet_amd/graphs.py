@@ -74,6 +74,60 @@ def single_lane(n_ops: int) -> List[tuple]:
     return [(RUN, 0, 0, n_ops)] if n_ops else []
 
 
+# Side streams that really run beside the launch stream.  HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
+# default) in creation order, and two streams on one queue execute back to back: a freshly created side stream overlaps with the
+# launch stream -- or not -- depending on every stream the process created before (measured: the post-filter's three chains per
+# streamed hop, 2.11 ms with distinct queues, 2.64 ms = the single-lane time without).  The runtime's own branch replay picked
+# distinct queues itself (that is what the loop quoted above is for); with the streams in our hands we do: candidates are timed
+# pairwise with a spin kernel, once per (device, launch stream), and the first that overlap with the launch stream AND with
+# each other are kept for every program of the process.
+_SIDE_POOL: Dict[Tuple[str, int], List[torch.cuda.Stream]] = {}
+_PROBE_CYCLES = 400_000        # torch.cuda._sleep: ~0.2 ms
+
+
+def _overlap(a: torch.cuda.Stream, b: torch.cuda.Stream, device: torch.device) -> float:
+    """seconds for one spin kernel on each of two streams, started together"""
+    import time
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for st in (a, b):
+        with torch.cuda.stream(st):
+            torch.cuda._sleep(_PROBE_CYCLES)
+    a.synchronize()
+    b.synchronize()
+    return time.perf_counter() - t0
+
+
+def side_streams(device: torch.device, n: int) -> List[torch.cuda.Stream]:
+    """n streams that overlap with the current stream of `device` and with each other (best effort: when fewer than n such
+    streams are found among the candidates the rest are ordinary new streams -- correctness never depends on overlap)."""
+    if n <= 0:
+        return []
+    main = torch.cuda.current_stream(device)
+    key = (str(device), main.cuda_stream)
+    if key not in _SIDE_POOL and sum(1 for k in _SIDE_POOL if k[0] == key[0]) >= 4:
+        key = next(k for k in _SIDE_POOL if k[0] == key[0])                 # many launch streams: stop creating streams, reuse
+    pool = _SIDE_POOL.setdefault(key, [])
+    if len(pool) >= n:
+        return pool[:n]
+    if not hasattr(torch.cuda, "_sleep") or torch.cuda.is_current_stream_capturing():
+        pool += [torch.cuda.Stream(device=device) for _ in range(n - len(pool))]
+        return pool[:n]
+    with torch.cuda.device(device):
+        probe = torch.cuda.Stream(device=device)
+        _overlap(main, probe, device)                                       # (first launch: module load)
+        alone = min(_overlap(main, main, device) for _ in range(2)) / 2.0    # one spin kernel
+        cands = [torch.cuda.Stream(device=device) for _ in range(8)]
+        for c in cands:
+            if len(pool) >= n:
+                break
+            if all(_overlap(o, c, device) < 1.5 * alone for o in [main] + pool):
+                pool.append(c)
+        spare = [c for c in cands if c not in pool]
+        pool += spare[:max(0, n - len(pool))]
+    return pool[:n]
+
+
 class LaneGraphs:
     """The captured form of one program: one single-stream hipGraph per ("run", ...) entry of the plan.
 
@@ -84,10 +138,12 @@ class LaneGraphs:
         self.device, self.plan, self.launch = device, plan, launch
         self.side: Dict[int, torch.cuda.Stream] = {}
         self.graphs: Dict[Tuple[int, int], torch.cuda.CUDAGraph] = {}
+        lanes = []
         for e in plan:                          # every lane a run or a mark names (a forked lane may carry no op)
             for l in ([e[1]] if e[0] == RUN else e[1]):
-                if l != 0 and l not in self.side:
-                    self.side[l] = torch.cuda.Stream(device=device)
+                if l != 0 and l not in lanes:
+                    lanes.append(l)
+        self.side = dict(zip(lanes, side_streams(device, len(lanes))))
 
     @property
     def n_graphs(self) -> int:

@@ -131,7 +131,7 @@ class _Bound:
                 self.static_in.zero_()
                 if self.static_in2 is not None:
                     self.static_in2.zero_()
-                self.run(side.cuda_stream)
+                self._launch(side.cuda_stream, 0, len(self.prog.ops))      # (program order on one stream: no lanes to set up)
             torch.cuda.current_stream().wait_stream(side)
             # one single-stream hipGraph per lane segment (graphs.py: a hipGraph with internal branches can crash the HIP
             # runtime at replay, depending on streams created elsewhere in the process); programs without parallel

@@ -1072,8 +1072,8 @@ class TrainBound:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                 # warm-up outside the capture (weights are packed already)
                 self.g.zero_()
-                self.run("fwd", side.cuda_stream)
-                self.run("bwd", side.cuda_stream)
+                self._launch("fwd", side.cuda_stream, 0, len(self.prog.fwd))       # (program order on one stream)
+                self._launch("bwd", side.cuda_stream, 0, len(self.prog.bwd))
             torch.cuda.current_stream().wait_stream(side)
             # one single-stream hipGraph per lane segment (graphs.py: a hipGraph with internal branches can crash the HIP
             # runtime at replay); programs without parallel branches are one graph each
