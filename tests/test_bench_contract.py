@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r03_bench_final.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r04_bench_final.json")) as f:
         return json.loads(f.read().strip().splitlines()[-1])
 
 
