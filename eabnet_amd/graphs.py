@@ -98,9 +98,28 @@ def _overlap(a: torch.cuda.Stream, b: torch.cuda.Stream, device: torch.device) -
     return time.perf_counter() - t0
 
 
+def _pick(device: torch.device, n: int, fixed: List[torch.cuda.Stream], pool: List[torch.cuda.Stream]) -> None:
+    """extend `pool` to n streams that overlap with every stream of `fixed` and with each other (best effort: when fewer
+    such streams are found among the candidates the rest are ordinary new streams -- correctness never depends on overlap)"""
+    if not hasattr(torch.cuda, "_sleep") or torch.cuda.is_current_stream_capturing():
+        pool += [torch.cuda.Stream(device=device) for _ in range(n - len(pool))]
+        return
+    with torch.cuda.device(device):
+        ref = fixed[0] if fixed else torch.cuda.current_stream(device)
+        _overlap(ref, torch.cuda.Stream(device=device), device)             # (first launch: module load)
+        alone = min(_overlap(ref, ref, device) for _ in range(2)) / 2.0      # one spin kernel
+        cands = [torch.cuda.Stream(device=device) for _ in range(8)]
+        for c in cands:
+            if len(pool) >= n:
+                break
+            if all(_overlap(o, c, device) < 1.5 * alone for o in fixed + pool):
+                pool.append(c)
+        spare = [c for c in cands if c not in pool]
+        pool += spare[:max(0, n - len(pool))]
+
+
 def side_streams(device: torch.device, n: int) -> List[torch.cuda.Stream]:
-    """n streams that overlap with the current stream of `device` and with each other (best effort: when fewer than n such
-    streams are found among the candidates the rest are ordinary new streams -- correctness never depends on overlap)."""
+    """n streams that overlap with the current stream of `device` and with each other."""
     if n <= 0:
         return []
     main = torch.cuda.current_stream(device)
@@ -108,23 +127,15 @@ def side_streams(device: torch.device, n: int) -> List[torch.cuda.Stream]:
     if key not in _SIDE_POOL and sum(1 for k in _SIDE_POOL if k[0] == key[0]) >= 4:
         key = next(k for k in _SIDE_POOL if k[0] == key[0])                 # many launch streams: stop creating streams, reuse
     pool = _SIDE_POOL.setdefault(key, [])
-    if len(pool) >= n:
-        return pool[:n]
-    if not hasattr(torch.cuda, "_sleep") or torch.cuda.is_current_stream_capturing():
-        pool += [torch.cuda.Stream(device=device) for _ in range(n - len(pool))]
-        return pool[:n]
-    with torch.cuda.device(device):
-        probe = torch.cuda.Stream(device=device)
-        _overlap(main, probe, device)                                       # (first launch: module load)
-        alone = min(_overlap(main, main, device) for _ in range(2)) / 2.0    # one spin kernel
-        cands = [torch.cuda.Stream(device=device) for _ in range(8)]
-        for c in cands:
-            if len(pool) >= n:
-                break
-            if all(_overlap(o, c, device) < 1.5 * alone for o in [main] + pool):
-                pool.append(c)
-        spare = [c for c in cands if c not in pool]
-        pool += spare[:max(0, n - len(pool))]
+    if len(pool) < n:
+        _pick(device, n, [main], pool)
+    return pool[:n]
+
+
+def overlapping_streams(device: torch.device, n: int) -> List[torch.cuda.Stream]:
+    """n new streams that overlap with each other (the executor's batches in flight, model.Pipeline)."""
+    pool: List[torch.cuda.Stream] = []
+    _pick(device, n, [], pool)
     return pool[:n]
 
 

@@ -722,7 +722,8 @@ class Pipeline:
                 # (observed: a later Pipeline with freshly created streams gained nothing)
                 key = (str(device), self.depth)
                 if key not in _PIPE_STREAMS:
-                    _PIPE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(self.depth)]
+                    from .graphs import overlapping_streams
+                    _PIPE_STREAMS[key] = overlapping_streams(device, self.depth)   # (probed: on distinct hardware queues)
                 self._streams = _PIPE_STREAMS[key]
             slot = self._n % self.depth
             self._n += 1
