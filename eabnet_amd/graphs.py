@@ -25,6 +25,7 @@ events for the forks and joins.  Same kernels, same order per lane, same concurr
 instead of 1 for the default post-filter."""
 from __future__ import annotations
 
+import threading
 from typing import Callable, Dict, List, Sequence, Tuple
 
 import torch
@@ -82,6 +83,7 @@ def single_lane(n_ops: int) -> List[tuple]:
 # pairwise with a spin kernel, once per (device, launch stream), and the first that overlap with the launch stream AND with
 # each other are kept for every program of the process.
 _SIDE_POOL: Dict[Tuple[str, int], List[torch.cuda.Stream]] = {}
+_POOL_LOCK = threading.Lock()      # (two threads binding programs at once would otherwise probe -- and create streams -- twice)
 _PROBE_CYCLES = 400_000        # torch.cuda._sleep: ~0.2 ms
 
 
@@ -124,12 +126,13 @@ def side_streams(device: torch.device, n: int) -> List[torch.cuda.Stream]:
         return []
     main = torch.cuda.current_stream(device)
     key = (str(device), main.cuda_stream)
-    if key not in _SIDE_POOL and sum(1 for k in _SIDE_POOL if k[0] == key[0]) >= 4:
-        key = next(k for k in _SIDE_POOL if k[0] == key[0])                 # many launch streams: stop creating streams, reuse
-    pool = _SIDE_POOL.setdefault(key, [])
-    if len(pool) < n:
-        _pick(device, n, [main], pool)
-    return pool[:n]
+    with _POOL_LOCK:
+        if key not in _SIDE_POOL and sum(1 for k in _SIDE_POOL if k[0] == key[0]) >= 4:
+            key = next(k for k in _SIDE_POOL if k[0] == key[0])             # many launch streams: stop creating streams, reuse
+        pool = _SIDE_POOL.setdefault(key, [])
+        if len(pool) < n:
+            _pick(device, n, [main], pool)
+        return pool[:n]
 
 
 def overlapping_streams(device: torch.device, n: int) -> List[torch.cuda.Stream]:

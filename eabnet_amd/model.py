@@ -1077,18 +1077,19 @@ class _HostStager:
         # on a normal-priority stream its workgroups queue behind the convolutions' and every pipeline slot waits for its upload
         self.stream = torch.cuda.Stream(device=device, priority=-1)
 
-    def upload(self, t: torch.Tensor) -> Tuple[torch.Tensor, "torch.cuda.Event"]:
+    def upload(self, t: torch.Tensor, role: int = 0) -> Tuple[torch.Tensor, "torch.cuda.Event"]:
         """CPU tensor -> contiguous fp32 device tensor, ordered on the CURRENT stream.  Returns (tensor, consumed):
-        record `consumed` on the current stream after the last kernel that reads the tensor has been enqueued."""
-        key = tuple(t.shape)
+        record `consumed` on the current stream after the last kernel that reads the tensor has been enqueued.
+        role: which input of the step this is (x = 0, target = 1) -- inputs of equal shape (one microphone) keep their own rings."""
+        key = (role,) + tuple(t.shape)
         ring = self.slots.get(key)
         if ring is None:
             if len(self.slots) > 8:
                 torch.cuda.synchronize(self.device)
                 self.slots.clear()
                 self.k.clear()
-            ring = self.slots[key] = [dict(pin=torch.empty(key, dtype=torch.float32).pin_memory(),
-                                           dev=torch.empty(key, dtype=torch.float32, device=self.device),
+            ring = self.slots[key] = [dict(pin=torch.empty(key[1:], dtype=torch.float32).pin_memory(),
+                                           dev=torch.empty(key[1:], dtype=torch.float32, device=self.device),
                                            copied=torch.cuda.Event(), consumed=torch.cuda.Event(), used=False)
                                       for _ in range(self.depth)]
         # (one counter per ring: x and target of a step use different rings -- a shared counter walked each of them with a
@@ -1121,14 +1122,14 @@ class _HostStager:
 _STAGERS: Dict[str, _HostStager] = {}
 
 
-def _upload(t: torch.Tensor, device: torch.device):
+def _upload(t: torch.Tensor, device: torch.device, role: int = 0):
     """(device tensor, event to record after its consumers) for any input of prepare_data"""
     if t.is_cuda:
         return t.to(device), None
     st = _STAGERS.get(str(device))
     if st is None:
         st = _STAGERS[str(device)] = _HostStager(device)
-    return st.upload(t)
+    return st.upload(t, role)
 
 
 def prepare_data(x: torch.Tensor, target: torch.Tensor, device, args):
@@ -1147,7 +1148,7 @@ def prepare_data(x: torch.Tensor, target: torch.Tensor, device, args):
         device = torch.device("cuda", torch.cuda.current_device())
     with torch.cuda.device(device):
         xd, ev_x = _upload(x, device)
-        td, ev_t = _upload(target, device)
+        td, ev_t = _upload(target, device, 1)
         noisy_wav = xd.contiguous().view(batch_size, args.mics, -1)
         target_wav = td.reshape(batch_size, 1, -1)
         window = torch.hann_window(win_size)
