@@ -18,7 +18,11 @@
 #define LB_SEQ 16
 #define LB_LD (4 * LB_H + 4)      // dgates tile row: 256 floats + pad (odd 16-byte-slot stride)
 #define LB_OOB 0x80000000u
-#define LB_PF 3                    // steps of operands in flight in the reverse-time kernels
+#define LB_PF 3                    // steps of operands in flight in the 16-sequence reverse-time kernel (28 registers per step)
+// ... and in the 4-sequence kernel (7 registers per step).  Measured at 966 sequences, us per layer: 1 step of lead 870, 2: 997,
+// 3: 644, 4: 633, 5: 552, 8: 533, 12: 1843 (84 loads exceed the 6-bit vmcnt).  The latency to cover is ~3.5 us, far above an HBM
+// read: on gfx9 loads and the dgates stores of earlier steps retire in issue order, so a load waits for the stores' acknowledgements.
+#define LBQ_PF 5
 
 #define LBB_ROW (4 * LB_H * 2 + 16) // the same tile as bf16: 512 bytes + pad (odd 16-byte-slot stride)
 
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(256) void lstm64_bwd_q_kernel(const float* __restri
     for (int kk = 0; kk < 64; ++kk) wh[kk] = wcat[(size_t)(64 * wave + kk) * 128 + 64 + lane];
 
     float dhr = 0.f, dcc = 0.f;
-    float pf[LB_PF][7];                                            // (i, f, g, o, c_t, c_{t-1}, dh_out) of the next LB_PF steps
+    float pf[LBQ_PF][7];                                            // (i, f, g, o, c_t, c_{t-1}, dh_out) of the next LBQ_PF steps
     auto load = [&](int t, float (&q)[7]) {
         const bool v = ok && t >= 0;
         const float* gp = gates + goff + (size_t)(t >= 0 ? t : 0) * g_t;
@@ -217,16 +221,16 @@ __global__ __launch_bounds__(256) void lstm64_bwd_q_kernel(const float* __restri
         q[6] = v ? dh_out[hoff + (size_t)(t >= 0 ? t : 0) * h_t] : 0.f;
     };
 #pragma unroll
-    for (int k = 0; k < LB_PF; ++k) load(T - 1 - k, pf[k]);
+    for (int k = 0; k < LBQ_PF; ++k) load(T - 1 - k, pf[k]);
 
-    for (int t0 = T - 1; t0 >= 0; t0 -= LB_PF) {
+    for (int t0 = T - 1; t0 >= 0; t0 -= LBQ_PF) {
 #pragma unroll
-      for (int k = 0; k < LB_PF; ++k) {
+      for (int k = 0; k < LBQ_PF; ++k) {
         const int t = t0 - k;
         if (t < 0) break;
         const int buf = t & 1;
         const float gi = pf[k][0], gf = pf[k][1], gg = pf[k][2], go = pf[k][3], ct = pf[k][4], cp = pf[k][5], du = pf[k][6];
-        load(t - LB_PF, pf[k]);
+        load(t - LBQ_PF, pf[k]);
         {   // same expressions as the 16-sequence kernel
             const float dh = du + dhr;
             const float tc = lb_tanh(ct);

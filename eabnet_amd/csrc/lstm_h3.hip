@@ -63,9 +63,10 @@ __device__ __forceinline__ float lh_join(unsigned short hi, unsigned short lo) {
     return (float)__builtin_bit_cast(_Float16, hi) + (float)__builtin_bit_cast(_Float16, lo);
 }
 
-// NS = 8 (bf16 training at small batches): 8 sequences per workgroup in tile rows 4q + {0, 1}, so that every lane still owns
-// sequences (two instead of four: half the exp / rcp chain of the cell update per step, twice the workgroups); rows 4q + {2, 3}
-// are padding the MFMAs carry along.
+// NS = 8 / 4 (bf16 training): 8 or 4 sequences per workgroup in tile rows 4q + {0, 1} / 4q, so that every lane still owns
+// sequences (two / one instead of four: half / a quarter of the exp / rcp chain of the cell update per step, two / four times the
+// workgroups); the other rows are padding the MFMAs carry along.  Per layer at 966 sequences: NS 16 / 8 / 4 = 638 / 534 / 454 us,
+// at 2,576: 594 / 570 / 542.
 template <bool LN, bool BF, bool DUMP = false, int NS = LH_SEQ>
 __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict__ x, const float* __restrict__ ln_g,
                                                         const float* __restrict__ ln_b, float ln_eps,
@@ -79,10 +80,10 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
     __shared__ __attribute__((aligned(16))) char hs[2][LH_SEQ * LH_ROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ln = lane & 15, lk = lane >> 4;
-    static_assert(NS == LH_SEQ || (NS == 8 && BF), "the 8-sequence form exists for the bf16 kernel only");
-    constexpr int NR = NS == LH_SEQ ? 4 : 2;                  // sequences per lane
+    static_assert(NS == LH_SEQ || ((NS == 8 || NS == 4) && BF), "the 8- and 4-sequence forms exist for the bf16 kernel only");
+    constexpr int NR = NS / 4;                                // sequences per lane
     // tile row -> sequence of this workgroup (or -1: padding)
-    auto row_seq = [](int row) { return NS == LH_SEQ ? row : ((row & 3) < 2 ? (row >> 2) * 2 + (row & 1) : -1); };
+    auto row_seq = [](int row) { return NS == LH_SEQ ? row : ((row & 3) < NR ? (row >> 2) * NR + (row & 3) : -1); };
     const int s0 = blockIdx.x * NS;
     // streaming (eab_time_window): steps [t_lo, t_hi) only
     const int t_lo = t_pos ? *t_pos : 0;
@@ -302,10 +303,10 @@ __global__ __launch_bounds__(256) void lstm64_h3_kernel(const float* __restrict_
 // training forward in bf16 (eab_lstm64_train_fwd_prec_f32, csrc/lstm.hip): the bf16 kernel that also stores the gates
 int eab_lstm64_bf_train_launch(const float* x, const float* wcat, const float* bias, float* h_out, float* gates, int T, int F, int S,
                                hipStream_t stream) {
-    // up to 2048 sequences (the training batch of configs[3] is 966): 8 sequences per workgroup -- the step is the cell update's
-    // exp / rcp chain per lane, not the 16 MFMAs, and twice the workgroups halve it
-    if (S <= 2048)
-        hipLaunchKernelGGL((lstm64_h3_kernel<false, true, true, 8>), dim3((S + 7) / 8), dim3(256), 0, stream, x, nullptr, nullptr, 0.0f,
+    // up to 4096 sequences (the training batch of configs[3] is 966): 4 sequences per workgroup -- the step is the cell update's
+    // exp / rcp chain per lane, not the 16 MFMAs, and four times the workgroups quarter it (measured up to 2,576 sequences)
+    if (S <= 4096)
+        hipLaunchKernelGGL((lstm64_h3_kernel<false, true, true, 4>), dim3((S + 3) / 4), dim3(256), 0, stream, x, nullptr, nullptr, 0.0f,
                            wcat, bias, h_out, T, F, S, nullptr, 0, nullptr, gates);
     else
         hipLaunchKernelGGL((lstm64_h3_kernel<false, true, true>), dim3((S + LH_SEQ - 1) / LH_SEQ), dim3(256), 0, stream, x, nullptr,

@@ -281,7 +281,8 @@ def _bf(t):
     return t.float().bfloat16().to(t.dtype)
 
 
-@pytest.mark.parametrize("B,T,Fq", [(1, 9, 21), (2, 40, 161), (13, 7, 161)])      # the last: > 2048 sequences
+# (2093 sequences: the 16-sequence reverse kernel in bf16; 4186: also the 16-sequence forward instead of the 4-sequence form)
+@pytest.mark.parametrize("B,T,Fq", [(1, 9, 21), (2, 40, 161), (13, 7, 161), (26, 4, 161)])
 def test_lstm_training_kernels_in_bf16(lib, B, T, Fq):
     """The bf16 training programs run the LSTM's recurrent products on the bf16 matrix cores (precision EAB_PREC_BF16 of
     eab_lstm64_train_fwd_prec_f32 / eab_lstm64_bwd_prec_f32): operands rounded to bf16, everything else fp32.  Reference: the same
