@@ -389,6 +389,18 @@ __global__ __launch_bounds__(256) void lstm64_q_kernel(const float* __restrict__
                 }
             }
         }
+        if (G == 1) {
+            // the compiler's own order kept one LDS read ahead of its four MFMAs (40 cycles of multiply per ~100 cycles of read
+            // latency: the matrix pipe idled most of the step); six reads ahead instead
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);        // DS read
+#pragma unroll
+            for (int i = 0; i < 26; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);    // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         norm_store(xq, nxt);                            // x_{t+1}: its buffer was last read one step ago
         // ---- activations, cell update (redundant in the quad), h_t -> LDS
 #pragma unroll

@@ -209,16 +209,27 @@ __global__ __launch_bounds__(256) void lstm64_bwd_q_kernel(const float* __restri
 
     float dhr = 0.f, dcc = 0.f;
     float pf[LBQ_PF][7];                                            // (i, f, g, o, c_t, c_{t-1}, dh_out) of the next LBQ_PF steps
+    // buffer loads with an out-of-range offset for "nothing to load" (returns 0): no branch around a load, so the number of
+    // loads outstanding at every point of the unrolled loop is a compile-time fact and the waits before a step's operands are
+    // counted ones (with predicated global loads the compiler fell back to vmcnt(0) once per unrolled round)
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gates), 0,
+                                                                         (unsigned)((size_t)S * T * 5 * LB_H * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dh_out), 0,
+                                                                         (unsigned)((size_t)S * T * LB_H * 4), 0x00020000);
+    const unsigned gb = (unsigned)(goff * 4), hb = (unsigned)(hoff * 4), g_tb = (unsigned)(g_t * 4), h_tb = (unsigned)(h_t * 4);
     auto load = [&](int t, float (&q)[7]) {
         const bool v = ok && t >= 0;
-        const float* gp = gates + goff + (size_t)(t >= 0 ? t : 0) * g_t;
-        q[0] = v ? gp[0] : 0.f;
-        q[1] = v ? gp[LB_H] : 0.f;
-        q[2] = v ? gp[2 * LB_H] : 0.f;
-        q[3] = v ? gp[3 * LB_H] : 0.f;
-        q[4] = v ? gp[4 * LB_H] : 0.f;
-        q[5] = (v && t > 0) ? *(gp - LB_H) : 0.f;                   // c_{t-1}
-        q[6] = v ? dh_out[hoff + (size_t)(t >= 0 ? t : 0) * h_t] : 0.f;
+        const unsigned go_ = v ? gb + (unsigned)t * g_tb : LB_OOB;
+        auto ld = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off) {
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+        };
+        q[0] = ld(rs_g, go_);
+        q[1] = ld(rs_g, v ? go_ + LB_H * 4 : LB_OOB);
+        q[2] = ld(rs_g, v ? go_ + 2 * LB_H * 4 : LB_OOB);
+        q[3] = ld(rs_g, v ? go_ + 3 * LB_H * 4 : LB_OOB);
+        q[4] = ld(rs_g, v ? go_ + 4 * LB_H * 4 : LB_OOB);
+        q[5] = ld(rs_g, (v && t > 0) ? go_ - LB_H * 4 : LB_OOB);   // c_{t-1}: slot 4 of step t-1 sits 64 floats below slot 0 of step t
+        q[6] = ld(rs_h, v ? hb + (unsigned)t * h_tb : LB_OOB);
     };
 #pragma unroll
     for (int k = 0; k < LBQ_PF; ++k) load(T - 1 - k, pf[k]);
@@ -251,13 +262,19 @@ __global__ __launch_bounds__(256) void lstm64_bwd_q_kernel(const float* __restri
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* arow = &dg[buf][(lane & 3) * LBQ_LD + 64 * wave];
+        // all sixteen A reads first (64 registers; one wave per SIMD has them): read-by-read the compiler kept one LDS read ahead
+        // of its four MFMAs -- 40 cycles of multiply per ~100 cycles of read latency
+        f32x4 ar[16];
 #pragma unroll
-        for (int k4 = 0; k4 < 16; ++k4) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 4 * k4);
+        for (int k4 = 0; k4 < 16; ++k4) ar[k4] = *reinterpret_cast<const f32x4*>(arow + 4 * k4);
+#pragma unroll
+        for (int k4 = 0; k4 < 16; ++k4)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
-                acc[(4 * k4 + kk) & 7] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[kk], wh[4 * k4 + kk], acc[(4 * k4 + kk) & 7], 0, 0, 0);
-        }
+                acc[(4 * k4 + kk) & 7] = __builtin_amdgcn_mfma_f32_4x4x1f32(ar[k4][kk], wh[4 * k4 + kk], acc[(4 * k4 + kk) & 7], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);          // (the scheduler would sink the reads back to their uses)
+        __builtin_amdgcn_sched_group_barrier(0x008, 64, 0);
+        __builtin_amdgcn_sched_barrier(0);
         const f32x4 p = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[wave][r][lane] = p[r];
@@ -288,7 +305,7 @@ extern "C" int eab_lstm64_bwd_prec_f32(const float* gates, const float* dh_out, 
                            dh_out, wcat, dgates, T, F, (int)S);
         EAB_RETURN_LAUNCH_STATUS();
     }
-    if (S <= 2048) {
+    if (S <= 2048 && S * T * 5 * LB_H * 4 < (1ll << 32)) {       // (32-bit byte offsets in the 4-sequence kernel's buffer descriptors)
         hipLaunchKernelGGL(lstm64_bwd_q_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, eab_stream(stream), gates, dh_out, wcat,
                            dgates, T, F, (int)S);
         EAB_RETURN_LAUNCH_STATUS();
