@@ -37,6 +37,10 @@ def main():
                                                                  B, T, F, prec, st))
             tb = timed(lambda: lib.eab_lstm64_bwd_prec_f32(gates.data_ptr(), dh.data_ptr(), w.data_ptr(), dg.data_ptr(), B, T, F, prec, st))
             out.append(f"{name}: fwd {tf:7.1f} us ({tf / T:5.2f}/step)  bwd {tb:7.1f} us ({tb / T:5.2f}/step)")
+        # the same layers without the gate store (the inference entry: same kernels, DUMP = false)
+        for prec, name in ((0, "f32"), (2, "bf16")):
+            ti = timed(lambda: lib.eab_lstm64_prec_f32(x.data_ptr(), None, None, 0.0, w.data_ptr(), b.data_ptr(), h.data_ptr(), B, T, F, prec, st))
+            out.append(f"{name} no gate store: fwd {ti:7.1f} us ({ti / T:5.2f}/step)")
         print(f"B={B} T={T} S={B * F}: " + " | ".join(out), flush=True)
 
 
