@@ -100,17 +100,19 @@ def _overlap(a: torch.cuda.Stream, b: torch.cuda.Stream, device: torch.device) -
     return time.perf_counter() - t0
 
 
-def _pick(device: torch.device, n: int, fixed: List[torch.cuda.Stream], pool: List[torch.cuda.Stream]) -> None:
+def _pick(device: torch.device, n: int, fixed: List[torch.cuda.Stream], pool: List[torch.cuda.Stream], priority: int = 0) -> None:
     """extend `pool` to n streams that overlap with every stream of `fixed` and with each other (best effort: when fewer
     such streams are found among the candidates the rest are ordinary new streams -- correctness never depends on overlap)"""
+    def make():
+        return torch.cuda.Stream(device=device, priority=priority)
     if not hasattr(torch.cuda, "_sleep") or torch.cuda.is_current_stream_capturing():
-        pool += [torch.cuda.Stream(device=device) for _ in range(n - len(pool))]
+        pool += [make() for _ in range(n - len(pool))]
         return
     with torch.cuda.device(device):
         ref = fixed[0] if fixed else torch.cuda.current_stream(device)
         _overlap(ref, torch.cuda.Stream(device=device), device)             # (first launch: module load)
         alone = min(_overlap(ref, ref, device) for _ in range(2)) / 2.0      # one spin kernel
-        cands = [torch.cuda.Stream(device=device) for _ in range(8)]
+        cands = [make() for _ in range(8)]
         for c in cands:
             if len(pool) >= n:
                 break
@@ -135,10 +137,11 @@ def side_streams(device: torch.device, n: int) -> List[torch.cuda.Stream]:
         return pool[:n]
 
 
-def overlapping_streams(device: torch.device, n: int) -> List[torch.cuda.Stream]:
-    """n new streams that overlap with each other (the executor's batches in flight, model.Pipeline)."""
+def overlapping_streams(device: torch.device, n: int, beside: Sequence[torch.cuda.Stream] = (), priority: int = 0) -> List[torch.cuda.Stream]:
+    """n new streams that overlap with each other and with every stream of `beside` (the executor's batches in flight and the
+    upload stream next to them, model.Pipeline / model._HostStager)."""
     pool: List[torch.cuda.Stream] = []
-    _pick(device, n, [], pool)
+    _pick(device, n, list(beside), pool, priority)
     return pool[:n]
 
 

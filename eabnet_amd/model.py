@@ -725,6 +725,8 @@ class Pipeline:
                     from .graphs import overlapping_streams
                     _PIPE_STREAMS[key] = overlapping_streams(device, self.depth)   # (probed: on distinct hardware queues)
                 self._streams = _PIPE_STREAMS[key]
+            if takes_host and not all(x.is_cuda for x in inputs):
+                _stager(device).run_beside(self._streams)              # the upload stream on a hardware queue of its own
             slot = self._n % self.depth
             self._n += 1
             st = self._streams[slot]
@@ -1076,6 +1078,20 @@ class _HostStager:
         # high priority: the copy kernel is a few dozen workgroups that must get their CU slots while other batches compute --
         # on a normal-priority stream its workgroups queue behind the convolutions' and every pipeline slot waits for its upload
         self.stream = torch.cuda.Stream(device=device, priority=-1)
+        self._beside: tuple = ()
+
+    def run_beside(self, streams) -> None:
+        """The copy stream must not share a hardware queue with a stream whose batches it feeds: a queue is in order, so an
+        upload behind a whole program of another batch arrives a step late (measured: 7-9 ms per step became 17-22 whenever the
+        creation-order lottery put the two together).  Picks -- once per set of streams -- a high-priority stream that a spin-kernel
+        probe shows overlapping with all of them (graphs.overlapping_streams)."""
+        key = tuple(s.cuda_stream for s in streams)
+        if key == self._beside:
+            return
+        from .graphs import overlapping_streams
+        torch.cuda.synchronize(self.device)
+        self.stream = overlapping_streams(self.device, 1, beside=list(streams), priority=-1)[0]
+        self._beside = key
 
     def upload(self, t: torch.Tensor, role: int = 0) -> Tuple[torch.Tensor, "torch.cuda.Event"]:
         """CPU tensor -> contiguous fp32 device tensor, ordered on the CURRENT stream.  Returns (tensor, consumed):
@@ -1122,14 +1138,18 @@ class _HostStager:
 _STAGERS: Dict[str, _HostStager] = {}
 
 
+def _stager(device: torch.device) -> _HostStager:
+    st = _STAGERS.get(str(device))
+    if st is None:
+        st = _STAGERS[str(device)] = _HostStager(device)
+    return st
+
+
 def _upload(t: torch.Tensor, device: torch.device, role: int = 0):
     """(device tensor, event to record after its consumers) for any input of prepare_data"""
     if t.is_cuda:
         return t.to(device), None
-    st = _STAGERS.get(str(device))
-    if st is None:
-        st = _STAGERS[str(device)] = _HostStager(device)
-    return st.upload(t, role)
+    return _stager(device).upload(t, role)
 
 
 def prepare_data(x: torch.Tensor, target: torch.Tensor, device, args):
