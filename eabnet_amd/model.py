@@ -1060,6 +1060,29 @@ def stft_compress(wav: torch.Tensor, n_fft: int, hop: int, window: torch.Tensor,
     return out
 
 
+_COPY_POOL = None
+_COPY_THREADS = 4
+
+
+def _host_copy(dst: torch.Tensor, src: torch.Tensor) -> None:
+    """dst.copy_(src) on the host; a large contiguous fp32 tensor is copied as _COPY_THREADS slices on worker threads (the copy
+    is one memcpy per call and releases the GIL): the 33 MB of a batch of waves are 3.3 ms of ONE core otherwise, and on a busy host
+    that single memcpy is what a pipelined step waits for."""
+    global _COPY_POOL
+    n = src.numel()
+    if n < (1 << 21) or not (src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype):
+        dst.copy_(src)
+        return
+    if _COPY_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _COPY_POOL = ThreadPoolExecutor(max_workers=_COPY_THREADS, thread_name_prefix="eab-stage")
+    d, s_ = dst.view(-1), src.view(-1)
+    step = (n + _COPY_THREADS - 1) // _COPY_THREADS
+    futs = [_COPY_POOL.submit(d[a:a + step].copy_, s_[a:a + step]) for a in range(0, n, step)]
+    for f in futs:
+        f.result()
+
+
 class _HostStager:
     """Host -> device path of ``prepare_data`` (train_distributed.py:76-77 does two blocking ``.to(device)``): a ring of
     pinned staging buffers and resident device buffers plus a dedicated copy stream.  The upload of batch k+1 is
@@ -1117,7 +1140,7 @@ class _HostStager:
             self.stream.wait_event(slot["consumed"])     # the device buffer's readers were enqueued before this
         src = t
         if self.always_stage or not (t.is_pinned() and t.is_contiguous() and t.dtype == torch.float32):
-            slot["pin"].copy_(t)                         # pageable / strided / other dtype: one host pass into pinned memory
+            _host_copy(slot["pin"], t)                   # pageable / strided / other dtype: one host pass into pinned memory
             src = slot["pin"]
         with torch.cuda.stream(self.stream):
             # a copy KERNEL reading the pinned buffer over the bus (device-visible under unified addressing), not
