@@ -4,6 +4,8 @@ north_star; both max-abs/max and L2-rel, tests/util.py); STFT frame indexing
 bit-exact."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -34,6 +36,9 @@ def test_side_streams_overlap_with_the_launch_stream(dev):
     stream (HIP maps streams onto a few hardware queues in creation order; two streams on one queue run back to back -- the
     post-filter's streamed hop was 2.64 instead of 2.11 ms whenever that happened)."""
     from eabnet_amd import graphs
+    if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 3:
+        pytest.skip("three streams cannot overlap on fewer than three hardware queues (the lanes still replay correctly: "
+                    "profiles/r04_scarce_queues.txt)")
     for _ in range(5):                                   # shift the creation-order lottery a little
         torch.cuda.Stream(device=dev)
     main = torch.cuda.current_stream(dev)
