@@ -3,13 +3,15 @@
 //   esti.permute(0,3,2,1) -> view_as_complex -> torch.istft(n_fft=320, hop=160, win=320, hann)
 // i.e. (torch.istft defaults: center, onesided, not normalized, length=None)
 //   frame_t = irfft(X[:, t]) * w;   y = overlap_add(frame) / overlap_add(w^2);   trim n_fft/2 per side.
-// Any hop that divides n_fft with R = n_fft/hop <= 8 frames per sample (the reference: 320/160, R = 2): a hop-long segment of
-// the output is covered by R consecutive frames, so there is no scatter and no envelope buffer --
-//   y[p] = sum_r w[r hop + n] x_{s-r}[r hop + n] / sum_r w[r hop + n]^2,   p = s hop + n, frames outside [0, T) skipped.
+// Any hop with R = ceil(n_fft/hop) <= 8 frames per sample (the reference: 320/160, R = 2; the hop need not divide n_fft): the
+// padded position p is covered by the frames t = floor(p/hop), floor(p/hop)-1, ... while t hop + n_fft > p, so there is no
+// scatter and no envelope buffer --
+//   y[p] = sum_t w[p - t hop] x_t[p - t hop] / sum_t w[p - t hop]^2,   frames outside [0, T) skipped.
 //
-// One workgroup inverts FFT_SIGS consecutive frames of one utterance in LDS and emits the
-// FFT_SIGS-(R-1) segments they cover completely (the next workgroup re-inverts the R-1 shared frames:
-// no inter-workgroup dependency).  Real inverse FFT by the even/odd split: with
+// One workgroup inverts FFT_SIGS consecutive frames t0 .. t0+7 of one utterance in LDS and emits the positions whose
+// covering frames it holds completely: [(t0-1) hop + n_fft, (t0+8) hop); consecutive workgroups start per = FFT_SIGS-(R-1)
+// frames apart, so their ranges tile the wave (the next workgroup re-inverts the R-1 shared frames: no inter-workgroup
+// dependency).  Real inverse FFT by the even/odd split: with
 // E = (X[k] + conj X[N/2-k])/2 and O = (X[k] - conj X[N/2-k])/2 * e^{+2 pi i k/N},
 // z = IDFT_{N/2}(E + iO) holds x[2n] + i x[2n+1]; the inverse transform runs as
 // conj(FFT(conj .)) on the forward Stockham passes of fft_lds.h.  As in a C2R transform the
@@ -27,7 +29,7 @@ __global__ __launch_bounds__(ISTFT_THREADS) void istft_kernel(const float* __res
                                                               int T, int n_fft, int hop, int chunks, FftPlan plan) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int NH = n_fft / 2, F = NH + 1;
-    const int R = n_fft / hop;                                    // frames that cover one output sample (2 for the reference)
+    const int R = (n_fft + hop - 1) / hop;                        // most frames that cover one output sample (2 for the reference)
     float2* tw = reinterpret_cast<float2*>(smem);                 // [n_fft] exp(-2 pi i j / n_fft)
     float2* buf0 = tw + n_fft;                                    // [FFT_SIGS][NH]
     float2* buf1 = buf0 + FFT_SIGS * NH;
@@ -68,21 +70,24 @@ __global__ __launch_bounds__(ISTFT_THREADS) void istft_kernel(const float* __res
     // x_c[2j] = Re y_c[j] / NH,  x_c[2j+1] = -Im y_c[j] / NH
     const float inv = 1.0f / (float)NH;
     const float* yf = reinterpret_cast<const float*>(y);
-    // Overlap-add over the R frames that cover a sample, divided by the squared-window envelope of the frames that exist
-    // (torch.istft), then the centre trim: segment s = padded positions [s hop, (s+1) hop) is covered by frames s-R+1 .. s.
-    // This workgroup holds frames t0 .. t0+7 and emits the segments whose frames it holds completely (the first one: from 0).
-    const int s_lo = chunk == 0 ? 0 : t0 + R - 1;
+    // Overlap-add over the frames that cover a sample, divided by the squared-window envelope of the frames that exist
+    // (torch.istft), then the centre trim.  This workgroup holds frames t0 .. t0+7 and emits the padded positions
+    // [p_lo, p_hi) whose covering frames it holds completely (the first workgroup: from 0); highest frame first.
+    const int per = FFT_SIGS - (R - 1);
+    const int p_lo = chunk == 0 ? 0 : t0 * hop + n_fft - hop;
+    const int p_hi = (t0 + per) * hop + n_fft - hop;
     const int out_len = hop * (T - 1);
-    for (int e = tid; e < (t0 + FFT_SIGS - s_lo) * hop; e += ISTFT_THREADS) {
-        const int sg = e / hop, n = e - sg * hop;
-        const int sI = s_lo + sg;
-        const int j = sI * hop + n - NH;                           // output sample (centre trim of n_fft/2)
+    for (int e = tid; e < p_hi - p_lo; e += ISTFT_THREADS) {
+        const int p = p_lo + e;
+        const int j = p - NH;                                      // output sample (centre trim of n_fft/2)
         if (j < 0 || j >= out_len) continue;
+        const int th = p / hop;
         float acc = 0.0f, env = 0.0f;
         for (int r = 0; r < R; ++r) {
-            const int t = sI - r;
-            if (t < 0 || t >= T) continue;
-            const int idx = r * hop + n;                           // sample of frame t; float index = idx (re/im interleave)
+            const int t = th - r;
+            const int idx = p - t * hop;                           // sample of frame t; float index = idx (re/im interleave)
+            if (t < 0 || idx >= n_fft) break;
+            if (t >= T) continue;
             float a = yf[(t - t0) * n_fft + idx];
             if (idx & 1) a = -a;
             const float w = win[idx];
@@ -98,14 +103,15 @@ extern "C" int eab_istft_f32(const float* spec, const float* window, const float
     EAB_CHECK_ARG(spec && window && twiddle && wav);
     EAB_CHECK_ARG(B > 0 && T >= 2 && hop > 0);
     EAB_CHECK_ARG(n_fft >= 4 && n_fft <= ISTFT_MAX_NFFT && (n_fft % 2) == 0);
-    // hop must divide n_fft and at most FFT_SIGS frames may cover a sample (R = n_fft / hop <= 8: 87.5 % overlap)
-    if (n_fft % hop != 0 || n_fft / hop > FFT_SIGS) return EAB_EUNSUPPORTED;
+    // at most FFT_SIGS frames may cover a sample (R = ceil(n_fft / hop) <= 8: 87.5 % overlap); torch.istft wants hop <= win
+    if (hop > n_fft || (n_fft + hop - 1) / hop > FFT_SIGS) return EAB_EUNSUPPORTED;
     FftPlan plan;
     if (!fft_plan(n_fft / 2, &plan)) return EAB_EUNSUPPORTED;
-    const int R = n_fft / hop, per = FFT_SIGS - (R - 1);
-    // segments [0, s_max) carry the trimmed output; the workgroup of chunk c ends at segment c*per + FFT_SIGS
-    const int s_max = (n_fft / 2 + hop * (T - 1) + hop - 1) / hop;
-    const int chunks = s_max <= FFT_SIGS ? 1 : 1 + (s_max - FFT_SIGS + per - 1) / per;
+    const int R = (n_fft + hop - 1) / hop, per = FFT_SIGS - (R - 1);
+    // padded positions [0, n_fft/2 + hop (T-1)) carry the trimmed output; the workgroup of chunk c ends at
+    // (c+1) per hop + n_fft - hop
+    const long long need = (long long)n_fft / 2 + (long long)hop * (T - 1) - (n_fft - hop);
+    const int chunks = need <= 0 ? 1 : (int)((need + (long long)per * hop - 1) / ((long long)per * hop));
     EAB_CHECK_ARG((long long)B * chunks < (1ll << 31));
     const size_t sh = (size_t)(2 * n_fft + 2 * FFT_SIGS * n_fft + n_fft + FFT_SIGS * 2 * (n_fft / 2 + 1)) * sizeof(float);
     hipLaunchKernelGGL(istft_kernel, dim3(B * chunks), dim3(ISTFT_THREADS), sh, eab_stream(stream), spec, window, twiddle,

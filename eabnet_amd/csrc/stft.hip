@@ -117,7 +117,17 @@ __global__ __launch_bounds__(STFT_THREADS) void stft_fft_kernel(
         const unsigned G = gridDim.x, G8 = G >> 3, rem = G & 7, xcd = vblk & 7, idx = vblk >> 3;
         vblk = xcd * G8 + (xcd < rem ? xcd : rem) + idx;
     }
-    const int b = (int)(vblk / (unsigned)T), t = (int)(vblk - (unsigned)b * T);
+    // b = vblk / T by a float reciprocal with one correction step (exact for vblk < 2^24; the 32-bit division it replaces is
+    // ~25 vector instructions per workgroup); larger grids take the division
+    int b;
+    if (gridDim.x < (1u << 24)) {
+        b = (int)((float)vblk * __builtin_amdgcn_rcpf((float)T));
+        const int r = (int)vblk - b * T;
+        b += (r >= T) - (r < 0);
+    } else {
+        b = (int)(vblk / (unsigned)T);
+    }
+    const int t = (int)vblk - b * T;
     const int tid = threadIdx.x;
     if (!DUMP)
         for (int k = tid; k < n_fft; k += STFT_THREADS) {   // table is (cos, sin)(+theta); the passes use exp(-i theta)
@@ -131,9 +141,10 @@ __global__ __launch_bounds__(STFT_THREADS) void stft_fft_kernel(
         const int first = t * hop - NH;                                   // first sample of the frame (reflect padding: may be < 0)
         if (first >= 0 && first + n_fft <= L && ((first | L | n_fft) & 3) == 0) {
             // interior frame (all but the first and last of an utterance): no reflection, four samples per load
-            const int n4 = n_fft >> 2;
-            for (int e = tid; e < FFT_SIGS * n4; e += STFT_THREADS) {
-                const int mm = e / n4, q = e - mm * n4;
+            // 32 threads per microphone walk its n_fft / 4 four-sample groups (no index division)
+            const int n4 = n_fft >> 2, mm = tid >> 5;
+            static_assert(STFT_THREADS == 32 * FFT_SIGS, "one 32-thread group per staged signal");
+            for (int q = tid & 31; q < n4; q += 32) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (m0 + mm < M) {
                     const f32x4 x4 = *reinterpret_cast<const f32x4*>(&wav[((size_t)b * M + m0 + mm) * L + first + 4 * q]);
@@ -179,28 +190,38 @@ __global__ __launch_bounds__(STFT_THREADS) void stft_fft_kernel(
         } else {
             src = fft_run(buf0, buf1, tw, NH, n_fft, plan, tid, STFT_THREADS);
         }
-        // X[k] = E[k] + W_N^k O[k],  E = (Z[k] + conj Z[NH-k]) / 2,  O = (Z[k] - conj Z[NH-k]) / 2i;  k = 0..NH
-        for (int e = tid; e < F * FFT_SIGS; e += STFT_THREADS) {
-            const int f = e / FFT_SIGS, mm = e - f * FFT_SIGS;           // consecutive threads -> consecutive mics
+        // X[k] = E[k] + W_N^k O[k],  E = (Z[k] + conj Z[NH-k]) / 2,  O = (Z[k] - conj Z[NH-k]) / 2i;  k = 0..NH.
+        // Bins k and NH-k are made by ONE thread from the same two values: E[NH-k] = conj E[k], O[NH-k] = conj O[k] and
+        // W^(NH-k) = -conj W^k, so X[NH-k] = conj(E[k] - W^k O[k]) -- half the LDS reads and one complex product per pair
+        // (k = 0 pairs DC with Nyquist: Z[NH] = Z[0]; NH even: k = NH/2 is its own partner and is stored once).
+        const int NP = NH / 2 + 1;                                       // pairs (k, NH-k), k = 0 .. NH/2
+        for (int e = tid; e < NP * FFT_SIGS; e += STFT_THREADS) {
+            const int k = e / FFT_SIGS, mm = e - k * FFT_SIGS;           // consecutive threads -> consecutive mics
             const int m = m0 + mm;
             if (m >= M) continue;
-            const float2 z = src[mm * NH + (f == NH ? 0 : f)];
-            const float2 zc = src[mm * NH + ((f == 0 || f == NH) ? 0 : NH - f)];
+            const float2 z = src[mm * NH + k];
+            const float2 zc = src[mm * NH + (k == 0 ? 0 : NH - k)];
             const float2 E = make_float2(0.5f * (z.x + zc.x), 0.5f * (z.y - zc.y));
             const float2 O = make_float2(0.5f * (z.y + zc.y), 0.5f * (zc.x - z.x));
-            const float2 w = (f == NH) ? make_float2(-1.0f, 0.0f) : tw[f];
-            const float2 wo = cmul(w, O);
-            const float re = E.x + wo.x, im = E.y + wo.y;
+            const float2 wo = cmul(tw[k], O);
+            const float re0 = E.x + wo.x, im0 = E.y + wo.y;              // X[k]
+            const float re1 = E.x - wo.x, im1 = wo.y - E.y;              // X[NH-k]
             // sqrt-magnitude compression with the phase kept: X * |X|^-1/2, 0 -> 0
             // |X|^-1/2 = (re^2 + im^2)^-1/4 on the hardware rsq / sqrt (1 ulp each; the IEEE sqrtf and division sequences this
             // replaces were ~40 VALU instructions per bin); p = 0 or denormal -> 0
-            const float p2 = re * re + im * im;
-            const float sc = p2 > 1e-37f ? __builtin_amdgcn_sqrtf(__builtin_amdgcn_rsqf(p2)) : 0.0f;
+            const float p0 = re0 * re0 + im0 * im0, p1 = re1 * re1 + im1 * im1;
+            const float sc0 = p0 > 1e-37f ? __builtin_amdgcn_sqrtf(__builtin_amdgcn_rsqf(p0)) : 0.0f;
+            const float sc1 = p1 > 1e-37f ? __builtin_amdgcn_sqrtf(__builtin_amdgcn_rsqf(p1)) : 0.0f;
+            const bool twice = 2 * k != NH;
             if (layout == EAB_STFT_LAYOUT_BTFM2) {
-                *reinterpret_cast<float2*>(&out[((((size_t)b * T + t) * F + f) * M + m) * 2]) = make_float2(re * sc, im * sc);
+                float* o = &out[(((size_t)b * T + t) * F * M + m) * 2];
+                *reinterpret_cast<float2*>(o + (size_t)k * M * 2) = make_float2(re0 * sc0, im0 * sc0);
+                if (twice) *reinterpret_cast<float2*>(o + (size_t)(NH - k) * M * 2) = make_float2(re1 * sc1, im1 * sc1);
             } else {                                        // (B,2,T,F), M == 1
-                out[(((size_t)b * 2 + 0) * T + t) * F + f] = re * sc;
-                out[(((size_t)b * 2 + 1) * T + t) * F + f] = im * sc;
+                float* o0 = &out[(((size_t)b * 2 + 0) * T + t) * F], *o1 = &out[(((size_t)b * 2 + 1) * T + t) * F];
+                o0[k] = re0 * sc0;
+                o1[k] = im0 * sc0;
+                if (twice) { o0[NH - k] = re1 * sc1; o1[NH - k] = im1 * sc1; }
             }
         }
     }

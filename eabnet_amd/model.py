@@ -1212,9 +1212,10 @@ _NOLA: Dict[tuple, bool] = {}
 def _check_nola(window: torch.Tensor, fft_num: int, hop: int, T: int) -> None:
     """torch.istft's window-overlap condition, on the host, before the kernel divides by the envelope: the squared-window
     overlap-add over the frames that exist must stay above 1e-11 at every output sample (a short zero-padded window with a
-    large hop leaves gaps).  The envelope's two rims and its periodic interior are those of a signal of 2R+2 frames."""
+    large hop leaves gaps).  The envelope's two rims and its interior (periodic in the hop, whether or not the hop divides
+    fft_num) are those of a signal of 2R+2 frames, R = ceil(fft_num / hop)."""
     w = window.detach().to("cpu", torch.float64).numpy()                     # (already zero-padded to fft_num by the caller)
-    key = (w.tobytes(), fft_num, hop, min(T, 2 * (fft_num // hop) + 2))     # by content: a pointer can be reused by another window
+    key = (w.tobytes(), fft_num, hop, min(T, 2 * -(-fft_num // hop) + 2))   # by content: a pointer can be reused by another window
     ok = _NOLA.get(key)
     if ok is None:
         w2 = w ** 2
@@ -1243,12 +1244,14 @@ def istft(esti_stft: torch.Tensor, fft_num: int, win_shift: int, window: torch.T
         raise ValueError(f"expected (B,2,T,{fft_num // 2 + 1}), got {tuple(esti_stft.shape)}")
     if window.numel() > fft_num:
         raise RuntimeError(f"window ({window.numel()} samples) must not exceed fft_num ({fft_num}), as in torch.istft")
+    if not 0 < win_shift <= window.numel():
+        raise RuntimeError(f"istft: expected 0 < win_shift <= win_length, got {win_shift} and {window.numel()} (as torch.istft)")
     if window.numel() < fft_num:                  # torch.istft(win_length < n_fft): zero-padded on both sides, centred
         left = (fft_num - window.numel()) // 2
         window = torch.nn.functional.pad(window, (left, fft_num - window.numel() - left))
-    if win_shift <= 0 or fft_num % win_shift != 0 or fft_num // win_shift > 8:
-        raise NotImplementedError("the HIP back end implements hops that divide fft_num with at most 8 overlapping frames "
-                                  "(fft_num / win_shift in 1..8; the reference's 320/160 is 2)")
+    if -(-fft_num // win_shift) > 8:
+        raise NotImplementedError("the HIP back end implements any hop with at most 8 overlapping frames "
+                                  "(ceil(fft_num / win_shift) in 1..8; the reference's 320/160 is 2)")
     lib = _lib.load()
     B, _, T, _ = esti_stft.shape
     _check_nola(window, fft_num, win_shift, T)

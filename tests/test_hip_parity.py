@@ -135,8 +135,8 @@ def test_istft_full_size_vs_oracle_and_properties(dev):
     yc = eabnet_amd.istft(c.to(dev), 320, 160, win)
     changed = (yc != ya).any(0).nonzero().flatten()
     assert changed.min() >= 160 * 199 and changed.max() < 160 * 201
-    with pytest.raises(NotImplementedError):              # a hop that does not divide fft_num (other hops: see
-        eabnet_amd.istft(a.to(dev), 320, 100, win)        # test_istft_other_hops_and_windows_vs_torch)
+    with pytest.raises(NotImplementedError):              # more than 8 frames over a sample (other hops, dividing fft_num or
+        eabnet_amd.istft(a.to(dev), 320, 39, win)         # not: test_istft_other_hops_and_windows_vs_torch)
 
 
 def test_filter_sum_vs_oracle_and_linearity(dev):
@@ -2080,25 +2080,29 @@ def test_istft_refuses_a_window_that_violates_nola(dev):
     a large hop and for a Hann window without overlap."""
     import eabnet_amd
     x = torch.randn(1, 2, 12, 161, device=dev)
-    with pytest.raises(RuntimeError, match="NOLA"):
-        eabnet_amd.istft(x, 320, 160, torch.hann_window(100))
-    with pytest.raises(RuntimeError):
-        torch.istft(torch.view_as_complex(x.permute(0, 3, 2, 1).contiguous()).cpu(), 320, 160, 100, torch.hann_window(100))
+    for wl, what in ((160, "NOLA"), (100, "win_shift <= win_length")):   # a gap in the envelope; a hop beyond the window
+        with pytest.raises(RuntimeError, match=what):
+            eabnet_amd.istft(x, 320, 160, torch.hann_window(wl))
+        with pytest.raises(RuntimeError):
+            torch.istft(torch.view_as_complex(x.permute(0, 3, 2, 1).contiguous()).cpu(), 320, 160, wl, torch.hann_window(wl))
     with pytest.raises(RuntimeError, match="NOLA"):
         eabnet_amd.istft(torch.randn(1, 2, 12, 129, device=dev), 256, 256, torch.hann_window(256))
     assert torch.isfinite(eabnet_amd.istft(x, 320, 160, torch.hann_window(320))).all()
 
 
-@pytest.mark.parametrize("n_fft,hop,win", [(320, 80, 320), (256, 64, 256), (512, 128, 400), (320, 40, 320), (320, 160, 200), (256, 256, 256)])
+@pytest.mark.parametrize("n_fft,hop,win", [(320, 80, 320), (256, 64, 256), (512, 128, 400), (320, 40, 320), (320, 160, 200), (256, 256, 256),
+                                           (320, 100, 320), (320, 96, 320), (320, 130, 320), (320, 200, 320), (320, 41, 320),
+                                           (512, 150, 400), (256, 77, 200), (320, 159, 320), (320, 161, 320), (320, 319, 320)])
 def test_istft_other_hops_and_windows_vs_torch(dev, n_fft, hop, win):
-    """The back end for any hop that divides fft_num (up to 8 overlapping frames) and any win_length <= fft_num, against
+    """The back end for any hop (dividing fft_num or not, up to 8 overlapping frames) and any win_length <= fft_num, against
     torch.istft called as enhance.py:59-62 calls it (the reference only ever passes 320/160/320; test.py / enhance.py take
     the three numbers from args).  Rectangular window for the hop == n_fft case (a Hann window has no valid envelope there)."""
     import eabnet_amd
     torch.manual_seed(n_fft + hop)
-    B, T, F = 2, 11, n_fft // 2 + 1
+    B, T, F = 2, 37, n_fft // 2 + 1                   # several workgroups per utterance
     esti = torch.randn(B, 2, T, F)
-    window = torch.ones(win) if hop == n_fft else torch.hann_window(win)
+    # a window without zeros where a Hann window has no valid envelope (no or nearly no overlap)
+    window = torch.ones(win) if hop == n_fft else (torch.hamming_window(win) if hop * 2 > win else torch.hann_window(win))
     want = torch.istft(torch.view_as_complex(esti.permute(0, 3, 2, 1).contiguous()), n_fft, hop, win, window)
     got = eabnet_amd.istft(esti.to(dev), n_fft, hop, window)
     assert got.shape == want.shape == (B, hop * (T - 1))
