@@ -11,11 +11,7 @@ struct FftPlan {
     int radix[FFT_MAX_PASSES];
 };
 
-// (explicit fused multiply-adds: the build runs with -ffp-contract=off, and the transforms are bound by their vector
-// instruction count -- four instructions per complex product instead of six, one rounding fewer per component)
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
-}
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
 // One Stockham pass (decimation in frequency, autosort) of NT-point transforms: sub-length n,
 // stride s, radix R:
@@ -78,10 +74,10 @@ __device__ __forceinline__ void fft_pass(const float2* __restrict__ x, float2* _
             const float2 t1 = make_float2(a[1].x + a[4].x, a[1].y + a[4].y), t2 = make_float2(a[2].x + a[3].x, a[2].y + a[3].y);
             const float2 t3 = make_float2(a[1].x - a[4].x, a[1].y - a[4].y), t4 = make_float2(a[2].x - a[3].x, a[2].y - a[3].y);
             o[0] = make_float2(a[0].x + t1.x + t2.x, a[0].y + t1.y + t2.y);
-            const float2 m1 = make_float2(fmaf(c2, t2.x, fmaf(c1, t1.x, a[0].x)), fmaf(c2, t2.y, fmaf(c1, t1.y, a[0].y)));
-            const float2 m2 = make_float2(fmaf(c1, t2.x, fmaf(c2, t1.x, a[0].x)), fmaf(c1, t2.y, fmaf(c2, t1.y, a[0].y)));
-            const float2 n1 = make_float2(fmaf(s1, t3.x, s2 * t4.x), fmaf(s1, t3.y, s2 * t4.y));
-            const float2 n2 = make_float2(fmaf(s2, t3.x, -(s1 * t4.x)), fmaf(s2, t3.y, -(s1 * t4.y)));
+            const float2 m1 = make_float2(a[0].x + c1 * t1.x + c2 * t2.x, a[0].y + c1 * t1.y + c2 * t2.y);
+            const float2 m2 = make_float2(a[0].x + c2 * t1.x + c1 * t2.x, a[0].y + c2 * t1.y + c1 * t2.y);
+            const float2 n1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+            const float2 n2 = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
             o[1] = make_float2(m1.x + n1.y, m1.y - n1.x);
             o[4] = make_float2(m1.x - n1.y, m1.y + n1.x);
             o[2] = make_float2(m2.x + n2.y, m2.y - n2.x);
