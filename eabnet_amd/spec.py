@@ -58,8 +58,8 @@ class NetConfig:
 
     def check_supported(self) -> None:
         """Every switch of the reference constructor is implemented (U2/plain U-Net, lstm/cnn
-        beam-former, mimo/miso, cat/add, IN/BN, causal or not).  The kernel geometry (64-channel
-        layers, (2,3)/(1,3) kernels) is fixed; ``cLN`` cannot be constructed in the reference
+        beam-former, mimo/miso, cat/add, IN/BN, causal or not) and the time extent of the gated convolutions
+        (k1 = (2..5, 3)).  The rest of the kernel geometry (64-channel layers, 3-bin kernels, (1,3) units) is fixed; ``cLN`` cannot be constructed in the reference
         either (EaBNet.py:689-691 pass the string dim_size as num_features)."""
         bad = []
         if self.bf_type not in ("lstm", "cnn"):
@@ -74,8 +74,12 @@ class NetConfig:
             bad.append("norm_type='cLN' is built for the default topology (U2, 'cat' skips, causal)")
         if not self.is_causal and (self.kd1 - 1) % 2:
             bad.append("is_causal=False with even kd1 (the reference's residual add fails on the shorter branch)")
-        if tuple(self.k1) != (2, 3) or tuple(self.k2) != (1, 3):
-            bad.append(f"k1={self.k1} k2={self.k2}")
+        # the gated convolutions' time extent is free (causal pad / chomp of k_t - 1 rows, EaBNet.py:447-452,477-482; k_t * 3 taps
+        # must fit the kernels' tap table); k_t = 1 would rename the state-dict keys (no pad module: EaBNet.py:452-454).
+        # The frequency extent is tied to the 161 -> 79 -> 39 -> 19 -> 9 -> 4 chain (other widths do not meet their skip
+        # connections in the reference either), and a unit kernel with k_t > 1 shortens the utterance (Conv2dunit has no pad).
+        if len(tuple(self.k1)) != 2 or self.k1[1] != 3 or not 2 <= self.k1[0] <= 5 or tuple(self.k2) != (1, 3):
+            bad.append(f"k1={self.k1} (supported: (2..5, 3)) k2={self.k2} (supported: (1, 3))")
         if self.c != 64 or self.embed_dim != 64 or self.cd1 != 64:
             bad.append("c/embed_dim/cd1 != 64")
         if self.d_feat != self.c_end * 4:
@@ -283,8 +287,10 @@ class GagConfig:
         # (the post-filter is offered with BN / IN only: train_distributed.py:318 `--gagnet_norm_type`, choices ["BN", "IN"])
         if self.norm_type not in ("IN", "BN"):
             bad.append(f"norm_type={self.norm_type!r}")
-        if tuple(self.k1) != (2, 3) or tuple(self.k2) != (1, 3) or self.c != 64 or self.cd1 != 64:
-            bad.append("k1/k2/c/cd1 away from (2,3)/(1,3)/64/64")
+        # (k1 = (k_t, 3): the gated convolutions' time extent is free, as in NetConfig.check_supported)
+        if len(tuple(self.k1)) != 2 or self.k1[1] != 3 or not 2 <= self.k1[0] <= 5 or tuple(self.k2) != (1, 3) \
+                or self.c != 64 or self.cd1 != 64:
+            bad.append("k1/k2/c/cd1 away from (2..5,3)/(1,3)/64/64")
         if self.d_feat != self.c_end * 4 or self.fft_num != 320:
             bad.append("d_feat != 256 or fft_num != 320")
         if not self.is_causal and any(((self.kd1 - 1) * d) % 2 for d in self.dilas):

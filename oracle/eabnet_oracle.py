@@ -296,13 +296,20 @@ def unet_decoder(x, skips, P: Params, bn: bool):
 def eabnet_forward(P: Params, inpt: torch.Tensor, p: int = 6, q: int = 3, kd: int = 5,
                    fast_lstm: bool = False, taps: Optional[dict] = None, *, is_causal: bool = True,
                    is_u2: bool = True, bf_type: str = "lstm", topo_type: str = "mimo",
-                   intra_connect: str = "cat", norm_type: str = "IN", bn_train: bool = False) -> torch.Tensor:
+                   intra_connect: str = "cat", norm_type: str = "IN", bn_train: bool = False,
+                   k1: Optional[tuple] = None, k2: Optional[tuple] = None) -> torch.Tensor:
     """EaBNet.forward (EaBNet.py:88-125).
     inpt (B,T,F,M,2) [or (B,T,F,2)] -> (B,2,T,F)  [(B,2,T) for topo_type="miso", as the reference].
-    bn_train: norm_type="BN" with the module in train mode (batch statistics; see _norm)."""
+    bn_train: norm_type="BN" with the module in train mode (batch statistics; see _norm).
+    k1 / k2: the constructor's kernel sizes -- the convolutions take their extents (and the causal pad / chomp of k_t - 1 rows,
+    EaBNet.py:447-452,477-482) from the weight shapes, so these are only checked against the parameters."""
     if inpt.ndim == 4:
         inpt = inpt.unsqueeze(-2)
     B, T, Fq, M, _ = inpt.shape
+    for pre, want in (("de.", k1), ("en.", k2)):
+        if want is not None:
+            key = next((k for k in P if k.startswith(pre) and (".enco.0.conv.0.weight" if pre == "en." else ".in_conv.0.conv.0.weight") in k), None)
+            assert key is None or tuple(P[key].shape[2:]) == tuple(want), (key, tuple(P[key].shape), want)
     assert norm_type in ("IN", "BN", "cLN") and intra_connect in ("cat", "add")
     bn, add = {"BN": "train" if bn_train else True, "IN": False, "cLN": "cLN"}[norm_type], intra_connect == "add"
     # (B,T,F,M,2) -> (B,2M,T,F), channel = ri*M + m   (EaBNet.py:96-97)
@@ -402,10 +409,13 @@ def gag_chain(x, P: Params, pre: str, p: int, dilas, kd, bn, causal):
 def gagnet_forward(P: Params, inpt: torch.Tensor, pre_x: torch.Tensor, *, kd1: int = 3, p: int = 2, q: int = 3,
                    dilas=(1, 2, 5, 9), is_u2: bool = True, is_causal: bool = True, is_squeezed: bool = False,
                    acti_type: str = "sigmoid", intra_connect: str = "cat", norm_type: str = "IN",
-                   bn_train: bool = False) -> List[torch.Tensor]:
+                   bn_train: bool = False, k1: Optional[tuple] = None) -> List[torch.Tensor]:
     """GaGNet.forward (GaGNet.py:76-90): inpt, pre_x (B,2,T,F) -> q stage outputs (B,2,F,T).
-    bn_train: norm_type="BN" with the module in train mode (batch statistics; see _norm)."""
+    bn_train: norm_type="BN" with the module in train mode (batch statistics; see _norm).
+    k1: the constructor's gated-kernel size; the convolutions take it from the weight shapes, so it is only checked."""
     B, _, T, Fq = inpt.shape
+    if k1 is not None and "en.last_conv.0.conv.1.weight" in P:
+        assert tuple(P["en.last_conv.0.conv.1.weight"].shape[2:]) == tuple(k1)
     bn, add = ("train" if bn_train else True) if norm_type == "BN" else False, intra_connect == "add"
     x = torch.cat([inpt, pre_x], dim=1)
     if is_u2:

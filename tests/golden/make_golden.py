@@ -45,6 +45,9 @@ VARIANTS = {          # constructor branches away from the default (SURVEY §8c 
     "unet_bn_cnn_noncausal": dict(is_u2=False, norm_type="BN", bf_type="cnn", is_causal=False),
     "add_bn_miso": dict(intra_connect="add", norm_type="BN", topo_type="miso"),
     "cln": dict(norm_type="cLN"),       # needs the reference's NormSwitch constructor fixed: see _fixed_norm_switch()
+    # the time extent of the gated convolutions (causal pad / chomp of k_t - 1 rows, EaBNet.py:447-452,477-482)
+    "k1_33": dict(k1=(3, 3)),
+    "k1_53_bn_add": dict(k1=(5, 3), norm_type="BN", intra_connect="add"),
 }
 
 
@@ -233,17 +236,21 @@ GAG_VARIANTS = {
     "bn_squeezed_tanh": dict(norm_type="BN", is_squeezed=True, acti_type="tanh", p=1, q=2),
     "unet_add_noncausal_relu": dict(is_u2=False, intra_connect="add", is_causal=False, acti_type="relu", p=1, q=2,
                                     dilas=(1, 2)),
+    "k1_33": dict(k1=(3, 3), p=1, q=2, dilas=(1, 2)),    # gated convolutions three frames long (GaGNet.py's GateConv2d, as EaBNet's)
 }
 
 
-def main_gagnet():
+def main_gagnet(only=None):
     """Post-filter: the reference's GaGNet on CPU (its factory make_gag_net calls
     .cuda(), the class itself does not) and the two-stage composition of EaBNetWithPostNet.forward
     (EaBNet.py:138-148) spelled out with the reference's two classes."""
     from GaGNet import GaGNet as RefGaGNet, stagewise_com_mag_mse_loss as ref_stage_loss
     from eabnet_amd.spec import GagConfig, gag_param_specs
-    inventory = {}
+    inv_path = os.path.join(HERE, "keys_gagnet.json")
+    inventory = json.load(open(inv_path)) if (only and os.path.exists(inv_path)) else {}
     for i, (name, kw) in enumerate(GAG_VARIANTS.items()):
+        if only and name != only:
+            continue
         full = dict(GAG_BASE); full.update(kw)
         net = RefGaGNet(**{**full, "dilas": list(full["dilas"])}).eval()
         specs = gag_param_specs(GagConfig(**full))
@@ -264,6 +271,8 @@ def main_gagnet():
              **{f"out{j}": o.numpy() for j, o in enumerate(outs)}, **extra)
     with open(os.path.join(HERE, "keys_gagnet.json"), "w") as f:
         json.dump(inventory, f)
+    if only:
+        return
 
     # two-stage wrapper: reference EaBNet -> reference GaGNet, composed as EaBNetWithPostNet.forward does
     M, B, T, ref_mic = 4, 1, 12, 1
@@ -371,6 +380,10 @@ if __name__ == "__main__":
             main_gagnet()
         elif sys.argv[1:] == ["variants"]:
             main_variants()
+        elif len(sys.argv) == 3 and sys.argv[1] == "variant":
+            main_variants(only=sys.argv[2])
+        elif len(sys.argv) == 3 and sys.argv[1] == "gag_variant":
+            main_gagnet(only=sys.argv[2])
         elif sys.argv[1:] == ["istft"]:
             main_istft()
         elif sys.argv[1:] == ["bn_train"]:

@@ -884,6 +884,20 @@ def test_streaming_equals_offline_bit_for_bit(dev, chunk, use_graph):
     assert torch.equal(y2, off2)
 
 
+@pytest.mark.parametrize("k1,chunk", [((3, 3), 1), ((5, 3), 4)])
+def test_streaming_with_longer_gated_kernels_equals_offline(dev, k1, chunk):
+    """k1 = (k_t, 3) with k_t > 2 (the gated convolutions reach k_t - 1 frames back; reference fixtures var_k1_33 /
+    var_k1_53_bn_add pin the offline path): a frame-synchronous run returns the frames of the offline call bit for bit."""
+    net = _model(4, 620, dev, norm_type="BN", k1=k1, p=2, q=2)
+    B, T = 2, 23
+    x = torch.from_numpy(paramgen.make_spec_input(B, T, 161, 4, 621)).to(dev)
+    with torch.no_grad():
+        off = net(x)
+    st = net.stream_begin(B, T_max=24, chunk=chunk)
+    y = torch.cat([st.step(x[:, t:t + chunk]) for t in range(0, T, chunk)], dim=2)
+    assert torch.equal(y, off)
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
 def test_streaming_s_tcn_runs_as_one_chain_launch(dev, precision, monkeypatch):
     """A frame-synchronous step (BatchNorm norms, chunk <= 16) runs the 1-D convolutions of the whole S-TCN as ONE launch
