@@ -93,8 +93,8 @@ int eab_stft_frames_f32(const float* wav, float* frames, int B, int M, int L, in
  *   spec    [B][2][T][F]  estimate, F = n_fft/2+1, T >= 2
  *   window  [n_fft], twiddle [n_fft][2] as for eab_stft_compress_f32
  *   wav     [B][hop*(T-1)]
- * hop must divide n_fft with n_fft / hop <= 8 frames per sample (the reference's 320/160: 2), n_fft/2 = 2^a 5^b, else
- * EAB_EUNSUPPORTED.  A window shorter than n_fft is passed zero-padded to n_fft (centred), as torch.istft pads it.
+ * Any hop <= n_fft with ceil(n_fft / hop) <= 8 frames per sample (the reference's 320/160: 2; the hop need not divide
+ * n_fft), n_fft/2 = 2^a 5^b, else EAB_EUNSUPPORTED.  A window shorter than n_fft is passed zero-padded to n_fft (centred), as torch.istft pads it.
  * ------------------------------------------------------------------------ */
 int eab_istft_f32(const float* spec, const float* window, const float* twiddle, float* wav, int B, int T,
                   int n_fft, int hop, eab_stream_t stream);
