@@ -100,6 +100,10 @@ __global__ __launch_bounds__(256) void bfw_filter_sum_kernel(
         pos = p_lo + rr;
         return j0 + r < nbins && pos < TF;
     };
+    // Whole-utterance call (no streaming window) on utterances of at least one tile: index j IS the bin, a tile's rows are
+    // consecutive bins and (b, t F + f) of a row needs at most one carry -- straight-line address arithmetic instead of the
+    // loops above (which the compiler keeps as branches around every row of the fetch and of the store)
+    const bool flat = t_pos == nullptr && TF >= BFW_ROWS;
     // stage weights and activations (float4, coalesced)
     for (int e = tid; e < 2 * M * (BFW_K / 4); e += 256) {
         int r = e / (BFW_K / 4), c4 = e % (BFW_K / 4);
@@ -123,9 +127,14 @@ __global__ __launch_bounds__(256) void bfw_filter_sum_kernel(
 #pragma unroll
         for (int k = 0; k < TPT; ++k) {
             const int e = tid + k * 256, r = e / (BFW_K / 4), c4 = e % (BFW_K / 4);
+            pre[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (flat) {
+                const int idx = tl * BFW_ROWS + r;                  // (tl >= ntiles: idx >= nbins)
+                if (idx < nbins) pre[k] = *reinterpret_cast<const f32x4*>(&y1[(size_t)idx * BFW_K + c4 * 4]);
+                continue;
+            }
             int bb, pos;
             const bool ok = tl < ntiles && row_bin(b_, rem_, tl * BFW_ROWS, r, bb, pos);
-            pre[k] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (ok) pre[k] = *reinterpret_cast<const f32x4*>(&y1[(size_t)(bb * TF + pos) * BFW_K + c4 * 4]);
         }
     };
@@ -149,7 +158,18 @@ __global__ __launch_bounds__(256) void bfw_filter_sum_kernel(
     // the HBM round trip runs under the two matrix products instead of behind them
     const int r = tid >> 2, p = tid & 3;
     int ob, opos;
-    const bool valid = row_bin(tb, trem, row0, r, ob, opos);
+    bool valid;
+    if (flat) {
+        ob = tb;
+        opos = trem + r;
+        if (opos >= TF) {
+            opos -= TF;
+            ++ob;
+        }
+        valid = row0 + r < nbins;
+    } else {
+        valid = row_bin(tb, trem, row0, r, ob, opos);
+    }
     const size_t bin = (size_t)(ob * TF + opos);
     float2 xpre[4];
 #pragma unroll

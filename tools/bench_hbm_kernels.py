@@ -37,6 +37,22 @@ with torch.no_grad():
     rows = [("stft_compress", lambda: eabnet_amd.stft_compress(wav, 320, 160, window), B * T * (160 * M * 4 + 161 * M * 2 * 4)),
             ("filter_sum", lambda: eabnet_amd.filter_and_sum(wts, ns), B * T * F * (4 * M + 2) * 4),
             ("istft", lambda: eabnet_amd.istft(est, 320, 160, window), B * T * (2 * F + 160) * 4)]
+    # the head of the beam-former as the program runs it: w_dnn (Linear 64 -> 64 + ReLU, Linear 64 -> 2M) + filter-and-sum on the
+    # LSTM output h, one launch (eab_mlp_bfw_filter_sum_f32); algorithmic bytes: h + X read, the estimate written
+    import ctypes as C
+    from eabnet_amd import _lib
+    lib = _lib.load()
+    h = torch.randn(B * T * F, 64, device=dev)
+    w1, b1 = 0.1 * torch.randn(64, 64, device=dev), 0.1 * torch.randn(64, device=dev)
+    w2, b2 = 0.1 * torch.randn(2 * M, 64, device=dev), 0.1 * torch.randn(2 * M, device=dev)
+    out = torch.empty(B, 2, T, F, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def head():
+        _lib.check(lib.eab_mlp_bfw_filter_sum_f32(h.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                                  ns.data_ptr(), out.data_ptr(), None, B, T, F, M, _lib.TimeWindow(None, 0), st),
+                   "eab_mlp_bfw_filter_sum_f32")
+    rows.append(("mlp_bfw_fs", head, B * T * F * (64 + 2 * M + 2) * 4))
     for name, fn, by in rows:
         t = timed(fn)
         print(f"{name:14s} {1e6 * t:8.2f} us  {by / t / 1e12:6.3f} TB/s  frac {by / t / 8e12:.3f}", flush=True)
