@@ -26,7 +26,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .spec import GagConfig, NetConfig, gag_param_specs, param_specs, unet_decoder_layers, unet_encoder_layers
+from .spec import GagConfig, NetConfig, gag_param_specs, gate_key, param_specs, unet_decoder_layers, unet_encoder_layers
 
 # mirrors of the C enums (include/eabnet_hip.h)
 XF_NONE, XF_NORM_PRELU, XF_PRELU_NORM = 0, 1, 2
@@ -759,6 +759,7 @@ class Lowering:
         """Strided causal Conv2d [(kt,kf), stride (1,2)] (+GLU) -> raw output with
         norm+PReLU pending (norm=None: PReLU only).  Reference GateConv2d EaBNet.py:434-460 /
         Conv2dunit :391-407."""
+        wkey = gate_key(self.P, wkey)
         w = self.P[f"{wkey}.weight"]                       # (N, Cin, kt, kf)
         N, Cin, kt, kf = w.shape
         if in_perm is not None:
@@ -800,6 +801,7 @@ class Lowering:
           out[t][2o+ph] = sum_{kt} sum_{kf = ph, ph+2, ..} W[kt][kf] . in[t-kt][o-(kf-ph)/2]
         Reference GateConvTranspose2d EaBNet.py:463-490 + Chomp_T :617-624 /
         Deconv2dunit :410-431."""
+        wkey = gate_key(self.P, wkey)
         w = self.P[f"{wkey}.weight"]                       # (Cin, N, kt, kf)
         if summed:
             # Skip_connect 'add' (EaBNet.py:499-500): W.(f(a) + g(b)) = [W | W].cat(f(a), g(b)) -- the two

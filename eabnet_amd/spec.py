@@ -59,7 +59,7 @@ class NetConfig:
     def check_supported(self) -> None:
         """Every switch of the reference constructor is implemented (U2/plain U-Net, lstm/cnn
         beam-former, mimo/miso, cat/add, IN/BN, causal or not) and the time extent of the gated convolutions
-        (k1 = (2..5, 3)).  The rest of the kernel geometry (64-channel layers, 3-bin kernels, (1,3) units) is fixed; ``cLN`` cannot be constructed in the reference
+        (k1 = (1..5, 3)).  The rest of the kernel geometry (64-channel layers, 3-bin kernels, (1,3) units) is fixed; ``cLN`` cannot be constructed in the reference
         either (EaBNet.py:689-691 pass the string dim_size as num_features)."""
         bad = []
         if self.bf_type not in ("lstm", "cnn"):
@@ -75,11 +75,12 @@ class NetConfig:
         if not self.is_causal and (self.kd1 - 1) % 2:
             bad.append("is_causal=False with even kd1 (the reference's residual add fails on the shorter branch)")
         # the gated convolutions' time extent is free (causal pad / chomp of k_t - 1 rows, EaBNet.py:447-452,477-482; k_t * 3 taps
-        # must fit the kernels' tap table); k_t = 1 would rename the state-dict keys (no pad module: EaBNet.py:452-454).
+        # must fit the kernels' tap table); k_t = 1 has no pad / chomp module and with it other state-dict keys (".conv.weight"
+        # instead of ".conv.1.weight" / ".conv.0.weight", EaBNet.py:452-454,482-484): _gate_conv and gate_key() follow that.
         # The frequency extent is tied to the 161 -> 79 -> 39 -> 19 -> 9 -> 4 chain (other widths do not meet their skip
         # connections in the reference either), and a unit kernel with k_t > 1 shortens the utterance (Conv2dunit has no pad).
-        if len(tuple(self.k1)) != 2 or self.k1[1] != 3 or not 2 <= self.k1[0] <= 5 or tuple(self.k2) != (1, 3):
-            bad.append(f"k1={self.k1} (supported: (2..5, 3)) k2={self.k2} (supported: (1, 3))")
+        if len(tuple(self.k1)) != 2 or self.k1[1] != 3 or not 1 <= self.k1[0] <= 5 or tuple(self.k2) != (1, 3):
+            bad.append(f"k1={self.k1} (supported: (1..5, 3)) k2={self.k2} (supported: (1, 3))")
         if self.c != 64 or self.embed_dim != 64 or self.cd1 != 64:
             bad.append("c/embed_dim/cd1 != 64")
         if self.d_feat != self.c_end * 4:
@@ -126,14 +127,21 @@ def _norm_prelu(tab, prefix_norm: str, prefix_act: str, c: int, bn: bool = False
     tab[f"{prefix_act}.weight"] = ParamSpec((c,), "prelu", c)
 
 
+def gate_key(params, wkey: str) -> str:
+    """Parameter prefix of a gated convolution: ``wkey`` ("...conv.1" behind the causal pad, "...conv.0" in front of the chomp)
+    or, for a one-frame kernel, the bare "...conv" the reference then registers (EaBNet.py:452-454,482-484)."""
+    return wkey if f"{wkey}.weight" in params else wkey.rsplit(".", 1)[0]
+
+
 def _gate_conv(tab, prefix: str, cin: int, cout: int, k, transposed: bool) -> None:
     kt, kf = k
     if transposed:
         # ConvTranspose2d weight is (cin, 2*cout, kt, kf); PyTorch's default
         # initialiser takes fan_in from dim 1.
-        idx = 0
-        tab[f"{prefix}.conv.{idx}.weight"] = ParamSpec((cin, 2 * cout, kt, kf), "convT_w", 2 * cout * kt * kf)
-        tab[f"{prefix}.conv.{idx}.bias"] = ParamSpec((2 * cout,), "bias", 2 * cout * kt * kf)
+        # (k_t = 1: no Chomp_T behind the transposed convolution, hence no nn.Sequential and no index in the key, EaBNet.py:482-484)
+        name = f"{prefix}.conv.0" if kt > 1 else f"{prefix}.conv"
+        tab[f"{name}.weight"] = ParamSpec((cin, 2 * cout, kt, kf), "convT_w", 2 * cout * kt * kf)
+        tab[f"{name}.bias"] = ParamSpec((2 * cout,), "bias", 2 * cout * kt * kf)
     else:
         idx = 1 if kt > 1 else None
         name = f"{prefix}.conv.{idx}" if idx is not None else f"{prefix}.conv"
@@ -288,9 +296,9 @@ class GagConfig:
         if self.norm_type not in ("IN", "BN"):
             bad.append(f"norm_type={self.norm_type!r}")
         # (k1 = (k_t, 3): the gated convolutions' time extent is free, as in NetConfig.check_supported)
-        if len(tuple(self.k1)) != 2 or self.k1[1] != 3 or not 2 <= self.k1[0] <= 5 or tuple(self.k2) != (1, 3) \
+        if len(tuple(self.k1)) != 2 or self.k1[1] != 3 or not 1 <= self.k1[0] <= 5 or tuple(self.k2) != (1, 3) \
                 or self.c != 64 or self.cd1 != 64:
-            bad.append("k1/k2/c/cd1 away from (2..5,3)/(1,3)/64/64")
+            bad.append("k1/k2/c/cd1 away from (1..5,3)/(1,3)/64/64")
         if self.d_feat != self.c_end * 4 or self.fft_num != 320:
             bad.append("d_feat != 256 or fft_num != 320")
         if not self.is_causal and any(((self.kd1 - 1) * d) % 2 for d in self.dilas):

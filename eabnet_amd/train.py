@@ -39,7 +39,7 @@ from . import _lib
 from . import program as prg
 from .graphs import LaneGraphs, plan_segments, single_lane
 from .program import ALIGN, EPS_IN, EPS_LN, Ref, conv_tiles, glu_row_order
-from .spec import NetConfig, param_specs
+from .spec import NetConfig, gate_key, param_specs
 
 XF_NORM_PRELU, XF_PRELU_NORM = prg.XF_NORM_PRELU, prg.XF_PRELU_NORM
 (OP_GATHER, OP_IN_STATS, OP_TR_NORM_ACT, OP_NORM_BWD, OP_GLU_BWD, OP_GATE_FWD, OP_GATE_BWD, OP_ADD, OP_RELU_BWD, OP_COLSUM,
@@ -453,6 +453,7 @@ class TrainLowering:
     def conv2d_fwd(self, name: str, srcs: Sequence[TVar], wkey: str, glu: bool, norm: str, act: str,
                    in_perm: Optional[np.ndarray] = None, add: Optional[TVar] = None) -> TVar:
         """Strided causal Conv2d (+GLU) + InstanceNorm + PReLU (GateConv2d EaBNet.py:434-460 / Conv2dunit :391-407)."""
+        wkey = gate_key({f"{k}": 1 for k in self.specs}, wkey)
         wi = self.idx(f"{wkey}.weight")                                      # (N, Cin, kt, kf) flat indices
         N, Cin, kt, kf = wi.shape
         if in_perm is not None:
@@ -508,6 +509,7 @@ class TrainLowering:
     def conv2d_transposed(self, name: str, srcs: Sequence[TVar], wkey: str, glu: bool, norm: str, act: str,
                           add: Optional[TVar] = None) -> TVar:
         """ConvTranspose2d (+chomp, +GLU) + InstanceNorm + PReLU as two gather-form launches (program.py), EaBNet.py:463-490, 410-431."""
+        wkey = gate_key({f"{k}": 1 for k in self.specs}, wkey)
         wi = self.idx(f"{wkey}.weight")                                      # (Cin, N, kt, kf)
         Cin, N, kt, kf = wi.shape
         assert Cin == sum(s.C for s in srcs)

@@ -184,9 +184,15 @@ def gate_deconv2d(x, w, b):
     return a * torch.sigmoid(g)
 
 
+def _gk(P: Params, wkey: str) -> str:
+    """prefix of a gated convolution's parameters: "...conv.1" (behind the causal pad) / "...conv.0" (in front of the chomp), or
+    the bare "...conv" the reference registers for a one-frame kernel (no pad / chomp module, EaBNet.py:452-454,482-484)"""
+    return wkey if f"{wkey}.weight" in P else wkey.rsplit(".", 1)[0]
+
+
 def unet_module(x, P: Params, pre: str, scale: int, is_deconv: bool, taps=None, bn: bool = False, add: bool = False):
     """En_unet_module.forward (EaBNet.py:372-388); Skip_connect (:493-503) cat or add."""
-    wk = f"{pre}.in_conv.0.conv.{0 if is_deconv else 1}"
+    wk = _gk(P, f"{pre}.in_conv.0.conv.{0 if is_deconv else 1}")
     gated = (gate_deconv2d if is_deconv else gate_conv2d)(x, P[f"{wk}.weight"], P[f"{wk}.bias"])
     resi = _in_prelu(gated, P, f"{pre}.in_conv.1", f"{pre}.in_conv.2", bn)
     if taps is not None:
@@ -275,7 +281,7 @@ def unet_encoder(x, P: Params, bn: bool):
     but no norm (:217-224)."""
     skips = []
     for i in range(5):
-        x = gate_conv2d(x, P[f"en.unet_list.{i}.0.conv.1.weight"], P[f"en.unet_list.{i}.0.conv.1.bias"])
+        x = gate_conv2d(x, P[_gk(P, f"en.unet_list.{i}.0.conv.1") + ".weight"], P[_gk(P, f"en.unet_list.{i}.0.conv.1") + ".bias"])
         if i in (1, 2):
             x = F.prelu(x, P[f"en.unet_list.{i}.1.weight"])
         else:
@@ -287,8 +293,8 @@ def unet_encoder(x, P: Params, bn: bool):
 def unet_decoder(x, skips, P: Params, bn: bool):
     """UNet_Decoder.forward (EaBNet.py:324-328)."""
     for i in range(5):
-        x = gate_deconv2d(torch.cat((x, skips[-(i + 1)]), dim=1), P[f"de.unet_list.{i}.0.conv.0.weight"],
-                          P[f"de.unet_list.{i}.0.conv.0.bias"])
+        x = gate_deconv2d(torch.cat((x, skips[-(i + 1)]), dim=1), P[_gk(P, f"de.unet_list.{i}.0.conv.0") + ".weight"],
+                          P[_gk(P, f"de.unet_list.{i}.0.conv.0") + ".bias"])
         x = _in_prelu(x, P, f"de.unet_list.{i}.1", f"de.unet_list.{i}.2", bn)
     return x
 
@@ -324,7 +330,7 @@ def eabnet_forward(P: Params, inpt: torch.Tensor, p: int = 6, q: int = 3, kd: in
             skips.append(x)
             if taps is not None:
                 taps[f"en.{i}"] = x
-        x = gate_conv2d(x, P["en.last_conv.0.conv.1.weight"], P["en.last_conv.0.conv.1.bias"])
+        x = gate_conv2d(x, P[_gk(P, "en.last_conv.0.conv.1") + ".weight"], P[_gk(P, "en.last_conv.0.conv.1") + ".bias"])
         x = _in_prelu(x, P, "en.last_conv.1", "en.last_conv.2", bn)
         skips.append(x)
     if taps is not None:
@@ -351,8 +357,8 @@ def eabnet_forward(P: Params, inpt: torch.Tensor, p: int = 6, q: int = 3, kd: in
                             bn, add)
             if taps is not None:
                 taps[f"de.{i}"] = x
-        x = gate_deconv2d(torch.cat((x, skips[0]), dim=1), P["de.last_conv.0.conv.0.weight"],
-                          P["de.last_conv.0.conv.0.bias"])
+        x = gate_deconv2d(torch.cat((x, skips[0]), dim=1), P[_gk(P, "de.last_conv.0.conv.0") + ".weight"],
+                          P[_gk(P, "de.last_conv.0.conv.0") + ".bias"])
         x = _in_prelu(x, P, "de.last_conv.1", "de.last_conv.2", bn)
     if taps is not None:
         taps["de.4"] = x
@@ -415,17 +421,17 @@ def gagnet_forward(P: Params, inpt: torch.Tensor, pre_x: torch.Tensor, *, kd1: i
     k1: the constructor's gated-kernel size; the convolutions take it from the weight shapes, so it is only checked."""
     B, _, T, Fq = inpt.shape
     if k1 is not None and "en.last_conv.0.conv.1.weight" in P:
-        assert tuple(P["en.last_conv.0.conv.1.weight"].shape[2:]) == tuple(k1)
+        assert tuple(P[_gk(P, "en.last_conv.0.conv.1") + ".weight"].shape[2:]) == tuple(k1)
     bn, add = ("train" if bn_train else True) if norm_type == "BN" else False, intra_connect == "add"
     x = torch.cat([inpt, pre_x], dim=1)
     if is_u2:
         for i in range(4):
             x = unet_module(x, P, f"en.meta_unet_list.{i}", 4 - i, False, None, bn, add)
-        x = _in_prelu(gate_conv2d(x, P["en.last_conv.0.conv.1.weight"], P["en.last_conv.0.conv.1.bias"]), P,
+        x = _in_prelu(gate_conv2d(x, P[_gk(P, "en.last_conv.0.conv.1") + ".weight"], P[_gk(P, "en.last_conv.0.conv.1") + ".bias"]), P,
                       "en.last_conv.1", "en.last_conv.2", bn)
     else:
         for i in range(5):
-            x = _in_prelu(gate_conv2d(x, P[f"en.unet_list.{i}.0.conv.1.weight"], P[f"en.unet_list.{i}.0.conv.1.bias"]), P,
+            x = _in_prelu(gate_conv2d(x, P[_gk(P, f"en.unet_list.{i}.0.conv.1") + ".weight"], P[_gk(P, f"en.unet_list.{i}.0.conv.1") + ".bias"]), P,
                           f"en.unet_list.{i}.1", f"en.unet_list.{i}.2", bn)
     feat = x.transpose(-2, -1).contiguous().view(B, -1, T)
     pre = pre_x.transpose(-2, -1).contiguous()                       # (B,2,F,T)

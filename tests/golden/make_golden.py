@@ -48,6 +48,8 @@ VARIANTS = {          # constructor branches away from the default (SURVEY §8c 
     # the time extent of the gated convolutions (causal pad / chomp of k_t - 1 rows, EaBNet.py:447-452,477-482)
     "k1_33": dict(k1=(3, 3)),
     "k1_53_bn_add": dict(k1=(5, 3), norm_type="BN", intra_connect="add"),
+    # one-frame gated kernels: no pad / chomp module, ".conv.weight" keys (EaBNet.py:452-454,482-484)
+    "k1_13": dict(k1=(1, 3)),
 }
 
 
@@ -237,6 +239,7 @@ GAG_VARIANTS = {
     "unet_add_noncausal_relu": dict(is_u2=False, intra_connect="add", is_causal=False, acti_type="relu", p=1, q=2,
                                     dilas=(1, 2)),
     "k1_33": dict(k1=(3, 3), p=1, q=2, dilas=(1, 2)),    # gated convolutions three frames long (GaGNet.py's GateConv2d, as EaBNet's)
+    "k1_13": dict(k1=(1, 3), p=1, q=2, dilas=(1, 2)),    # ... and one frame long (".conv.weight" keys)
 }
 
 

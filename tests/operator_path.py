@@ -49,12 +49,23 @@ def _glu(y):
     return a * torch.sigmoid(g)
 
 
+def _gkey(m, key: str) -> str:
+    """"...conv.1" / "...conv.0", or the bare "...conv" of a one-frame gated kernel (EaBNet.py:452-454,482-484)"""
+    try:
+        m.get_parameter(f"{key}.weight")
+        return key
+    except AttributeError:
+        return key.rsplit(".", 1)[0]
+
+
 def _gate_conv(m, x, key: str):
+    key = _gkey(m, key)
     w, b = m.get_parameter(f"{key}.weight"), m.get_parameter(f"{key}.bias")
     return _glu(F.conv2d(F.pad(x, (0, 0, w.shape[2] - 1, 0)), w, b, stride=(1, 2)))      # causal top pad
 
 
 def _gate_deconv(m, x, key: str):
+    key = _gkey(m, key)
     w, b = m.get_parameter(f"{key}.weight"), m.get_parameter(f"{key}.bias")
     y = F.conv_transpose2d(x, w, b, stride=(1, 2))
     kt = w.shape[2]

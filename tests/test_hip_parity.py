@@ -884,10 +884,11 @@ def test_streaming_equals_offline_bit_for_bit(dev, chunk, use_graph):
     assert torch.equal(y2, off2)
 
 
-@pytest.mark.parametrize("k1,chunk", [((3, 3), 1), ((5, 3), 4)])
+@pytest.mark.parametrize("k1,chunk", [((3, 3), 1), ((5, 3), 4), ((1, 3), 2)])
 def test_streaming_with_longer_gated_kernels_equals_offline(dev, k1, chunk):
-    """k1 = (k_t, 3) with k_t > 2 (the gated convolutions reach k_t - 1 frames back; reference fixtures var_k1_33 /
-    var_k1_53_bn_add pin the offline path): a frame-synchronous run returns the frames of the offline call bit for bit."""
+    """k1 = (k_t, 3) with k_t != 2 (the gated convolutions reach k_t - 1 frames back; k_t = 1: none, and ".conv.weight" keys;
+    reference fixtures var_k1_33 / var_k1_53_bn_add / var_k1_13 pin the offline path): a frame-synchronous run returns the frames
+    of the offline call bit for bit."""
     net = _model(4, 620, dev, norm_type="BN", k1=k1, p=2, q=2)
     B, T = 2, 23
     x = torch.from_numpy(paramgen.make_spec_input(B, T, 161, 4, 621)).to(dev)
