@@ -1394,8 +1394,9 @@ def _grad_errors(got: dict, ref: dict):
 
 @pytest.mark.parametrize("M,B,T,pq,smooth", [(4, 2, 30, (2, 2), True), (8, 1, 70, (6, 3), True), (4, 2, 30, (2, 2), False),
                                              (8, 1, 70, (6, 3), False), (9, 2, 24, (2, 2), True),       # M = 9: the reference's default
-                                             (1, 1, 17, (1, 1), True), (16, 2, 19, (1, 2), True)])     # one microphone; config 5's 16
-def test_hip_training_gradients_vs_oracle_autograd(dev, M, B, T, pq, smooth):
+                                             (1, 1, 17, (1, 1), True), (16, 2, 19, (1, 2), True),      # one microphone; config 5's 16
+                                             (8, 2, 301, (6, 3), True)])    # three seconds: ~190 row tiles per utterance and layer, split-K
+def test_hip_training_gradients_vs_oracle_autograd(dev, M, B, T, pq, smooth):     # weight gradients, the LSTM's long recurrence
     _check_training_gradients(dev, M, B, T, pq, smooth)
 
 
@@ -1572,8 +1573,21 @@ def _check_training_gradients(dev, M, B, T, pq, smooth, taps=None, **extra):
           f"gradients l2-rel {[(n, f'{e:.1e}') for n, e in acts.items()]}")
     if smooth:
         bad = sorted(((e, k) for k, e in per.items() if e > 1e-4), reverse=True)
+        act_bar = {n: 1e-4 for n in acts}
+        if B * T >= 512:
+            # Long utterances: a weight gradient is a sum over B * T * F positions and the LSTM's reverse pass a recurrence over
+            # T steps; fp32 accumulation of that many terms leaves more than 1e-4 whatever the arithmetic -- the reference's own
+            # fp32 autograd (the oracle in fp32) is the yardstick, per tensor and per tap: not worse than 3 x its error.
+            _, taps32, g32 = _oracle_grads(P, x, label, frames, dtype=torch.float32, **kw)
+            floor, per32 = _grad_errors(g32, ref)
+            acts32 = {n: rel_errs(taps32[n].double().numpy(), ref_taps[n].numpy())[1] for n in acts}
+            print(f"fp32 reference arithmetic: global l2-rel {floor:.2e}, worst tensor {max(per32.values()):.2e}; activation "
+                  f"gradients l2-rel {[(n, f'{e:.1e}') for n, e in acts32.items()]}")
+            bad = [(e, k) for e, k in bad if e > 3.0 * per32.get(k, 0.0)]
+            act_bar = {n: max(1e-4, 3.0 * acts32[n]) for n in acts}
+            assert total <= max(1e-4, 3.0 * floor)
         assert total <= 1e-4 and not bad, f"global l2-rel {total:.3e}; tensors over 1e-4: {bad[:8]}"
-        assert max(acts.values()) <= 1e-4, acts
+        assert all(acts[n] <= act_bar[n] for n in acts), (acts, act_bar)
     else:
         _, taps32, g32 = _oracle_grads(P, x, label, frames, dtype=torch.float32, **kw)
         floor, _ = _grad_errors(g32, ref)
